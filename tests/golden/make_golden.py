@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the UNMODIFIED reference (oracle/_ref/libbcnn_ref.so).
+
+Run in the build container (where /root/reference exists) after `make -C oracle ref`:
+    python tests/golden/make_golden.py
+Each fixture holds a case's shape parameters, its seeded inputs (in__*) and the reference's
+outputs (out__*). The reference publishes no golden vectors of its own,
+so these ARE the pins: oracle/bcnn_oracle.c and the HIP path are both checked against them.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import ref_bind as rb  # noqa: E402
+from oracle import ref_cases as rc  # noqa: E402
+
+A = rb
+CASES = [
+    # ---- conv: plain, strides, pads, groups, quirks --------------------------------------------
+    rc.make_conv(1, 2, 3, 8, 8, 8, 3, 1, 1, name="conv_k3s1p1"),
+    rc.make_conv(2, 2, 4, 9, 7, 8, 3, 2, 1, act=A.ACT_RELU, name="conv_k3s2p1_relu_ragged"),
+    rc.make_conv(3, 2, 8, 6, 6, 4, 1, 1, 0, name="conv_k1s1_pointwise"),
+    rc.make_conv(4, 2, 4, 8, 8, 8, 1, 2, 0, name="conv_k1s2_quirk1"),
+    rc.make_conv(5, 2, 3, 16, 16, 4, 7, 2, 3, act=A.ACT_LRELU, name="conv_k7s2p3_lrelu"),
+    rc.make_conv(6, 2, 4, 8, 8, 8, 3, 1, 1, g=2, name="conv_groups2"),
+    rc.make_conv(7, 2, 3, 8, 8, 8, 3, 1, 1, bias_one=True, name="conv_bias_one_quirk2"),
+    rc.make_conv(8, 2, 3, 8, 8, 8, 3, 1, 1, bn=1, act=A.ACT_RELU, name="conv_bn_relu"),
+    rc.make_conv(9, 3, 8, 5, 5, 16, 1, 1, 0, bn=1, name="conv_bn_k1"),
+    rc.make_conv(10, 2, 3, 8, 8, 8, 3, 1, 1, input_grad=False, name="conv_input_layer_no_dx"),
+    rc.make_conv(11, 1, 2, 12, 9, 5, 5, 1, 0, act=A.ACT_TANH, name="conv_k5p0_tanh_nonsquare"),
+    rc.make_conv(12, 2, 3, 8, 8, 8, 3, 1, 1, carry=True, name="conv_momentum_carry"),
+    rc.make_conv(13, 2, 3, 8, 8, 8, 3, 1, 1, bn=1, act=A.ACT_RELU, carry=True, name="conv_bn_carry"),
+    rc.make_conv(14, 2, 6, 10, 10, 6, 3, 2, 1, g=3, act=A.ACT_RELU, name="conv_groups3_s2"),
+    rc.make_conv(15, 2, 3, 8, 8, 8, 3, 1, 1, bn=1, act=A.ACT_RELU, mode=A.MODE_VALID, input_grad=False,
+                 name="conv_bn_valid_mode"),
+    rc.make_conv(16, 2, 3, 9, 9, 8, 5, 2, 2, bn=1, mode=A.MODE_PREDICT, input_grad=False,
+                 name="conv_bn_predict_mode"),
+    rc.make_conv(17, 4, 16, 14, 14, 32, 3, 1, 1, act=A.ACT_RELU, name="conv_c16_f32_14x14"),
+    rc.make_conv(18, 2, 32, 7, 7, 64, 3, 1, 1, bn=1, act=A.ACT_RELU, name="conv_c32_f64_7x7_bn"),
+    rc.make_conv(19, 1, 3, 33, 35, 64, 3, 1, 1, name="conv_stem_like_33x35"),
+    rc.make_conv(20, 2, 3, 8, 8, 4, 3, 1, 0, act=A.ACT_RAMP, name="conv_k3p0_ramp"),
+    rc.make_conv(21, 2, 2, 6, 6, 3, 3, 1, 2, act=A.ACT_LOGISTIC, name="conv_pad2_logistic"),
+    rc.make_conv(22, 2, 2, 6, 6, 3, 3, 1, 1, act=A.ACT_CLAMP, name="conv_clamp"),
+    rc.make_conv(23, 2, 2, 6, 6, 3, 3, 1, 1, act=A.ACT_ABS, name="conv_abs"),
+    rc.make_conv(24, 2, 2, 6, 6, 3, 3, 1, 1, act=A.ACT_SOFTPLUS, name="conv_softplus"),
+    # ---- stand-alone batchnorm -----------------------------------------------------------------
+    rc.make_bn(30, 2, 3, 5, 5, name="bn_train"),
+    rc.make_bn(31, 4, 8, 7, 9, carry=True, name="bn_train_carry"),
+    rc.make_bn(32, 2, 3, 5, 5, mode=A.MODE_VALID, name="bn_valid"),
+    rc.make_bn(33, 2, 3, 5, 5, mode=A.MODE_PREDICT, name="bn_predict"),
+    rc.make_bn(34, 3, 4, 16, 16, shift=2.0, name="bn_train_shifted_mean"),
+    rc.make_bn(35, 1, 5, 1, 1, name="bn_train_1x1_n1"),
+    # ---- maxpool -------------------------------------------------------------------------------
+    rc.make_maxpool(40, 2, 3, 8, 8, 2, 2, A.PADDING_SAME, name="maxpool_2x2s2"),
+    rc.make_maxpool(41, 2, 3, 7, 9, 3, 2, A.PADDING_SAME, name="maxpool_3x3s2_same_ragged"),
+    rc.make_maxpool(42, 2, 3, 7, 9, 3, 2, A.PADDING_VALID, name="maxpool_3x3s2_valid"),
+    rc.make_maxpool(43, 2, 3, 7, 9, 3, 2, A.PADDING_CAFFE, name="maxpool_3x3s2_caffe"),
+    rc.make_maxpool(44, 2, 4, 8, 8, 3, 1, A.PADDING_SAME, ties=True, name="maxpool_3x3s1_ties_nan"),
+    rc.make_maxpool(45, 1, 2, 5, 5, 2, 1, A.PADDING_VALID, ties=True, name="maxpool_2x2s1_ties"),
+    rc.make_maxpool(46, 2, 8, 14, 14, 3, 2, A.PADDING_SAME, name="maxpool_resnet_stem_like"),
+    # ---- avgpool -------------------------------------------------------------------------------
+    rc.make_avgpool(50, 2, 3, 7, 7, name="avgpool_7x7"),
+    rc.make_avgpool(51, 3, 5, 1, 1, name="avgpool_1x1"),
+    rc.make_avgpool(52, 2, 4, 13, 9, name="avgpool_13x9"),
+    # ---- activation map ------------------------------------------------------------------------
+] + [rc.make_act(60 + a, a, name="act_%d" % a) for a in range(10)] + [
+    # ---- depthwise -----------------------------------------------------------------------------
+    rc.make_dw(80, 2, 4, 8, 8, 3, 1, 1, name="dw_k3s1p1"),
+    rc.make_dw(81, 2, 4, 9, 7, 3, 2, 1, act=A.ACT_RELU, name="dw_k3s2p1_relu"),
+    rc.make_dw(82, 2, 3, 8, 8, 3, 1, 1, input_grad=False, name="dw_no_src_grad_skips_dw"),
+    rc.make_dw(83, 2, 3, 8, 8, 5, 1, 2, bias_one=True, act=A.ACT_LRELU, name="dw_k5p2_bias_one"),
+    rc.make_dw(84, 1, 2, 6, 6, 3, 1, 0, name="dw_k3p0"),
+    # ---- raw kernels ---------------------------------------------------------------------------
+    rc.make_im2col(90, 3, 8, 8, 3, 1, 1, name="im2col_k3s1p1"),
+    rc.make_im2col(91, 2, 9, 7, 3, 2, 1, name="im2col_k3s2p1"),
+    rc.make_im2col(92, 2, 11, 11, 5, 2, 2, name="im2col_k5s2p2"),
+    rc.make_im2col(93, 1, 6, 6, 3, 1, 0, name="im2col_k3p0"),
+    rc.make_gemm(100, 0, 0, 8, 50, 27, name="gemm_nn"),
+    rc.make_gemm(101, 0, 1, 8, 27, 50, name="gemm_nt"),
+    rc.make_gemm(102, 1, 0, 27, 50, 8, beta=0.0, name="gemm_tn_beta0"),
+    rc.make_gemm(103, 1, 1, 13, 17, 19, alpha=0.5, beta=2.0, name="gemm_tt"),
+    rc.make_gemm(104, 0, 0, 70, 300, 200, name="gemm_nn_multi_panel"),
+]
+
+
+def main():
+    assert rb.available(), "build oracle/_ref first: make -C oracle ref"
+    out_dir = os.path.dirname(os.path.abspath(__file__))
+    names = set()
+    for case in CASES:
+        name = case["name"]
+        assert name not in names, name
+        names.add(name)
+        outs = rc.run_ref(case)
+        blob = {}
+        for k, v in case.items():
+            if isinstance(v, np.ndarray):
+                blob["in__" + k] = v
+            elif k != "name":
+                blob["p__" + k] = np.array(v)
+        for k, v in outs.items():
+            blob["out__" + k] = v
+        np.savez_compressed(os.path.join(out_dir, name + ".npz"), **blob)
+        print("%-34s %s" % (name, " ".join("%s%s" % (k, tuple(v.shape)) for k, v in outs.items())))
+    print("%d fixtures written to %s" % (len(CASES), out_dir))
+
+
+if __name__ == "__main__":
+    main()
