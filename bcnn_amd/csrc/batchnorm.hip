@@ -1,0 +1,273 @@
+// batchnorm.hip -- batch normalisation forward/backward (HBM-bound streaming + wave64 reductions).
+//
+// Reference semantics: src/layers/bcnn_batchnorm_layer.c:196-242 (forward), :301-332 (backward):
+//   mean = sum(x)/M, var = sum(x^2)/M - mean^2 (biased, one pass), M = N*H*W;
+//   running = 0.9*running + 0.1*batch; y = ((x-mean)/sqrtf(var+1e-6)) * scale + bias;
+//   backward uses eps = 1e-5 and writes the input gradient over dy in place.
+// Passes over the activation tensor: TRAIN forward = 1 read (statistics) + 1 read + 1 write (apply,
+// with the activation fused); backward = 1 pass of reads (sums) + 1 read/write pass (apply). The
+// reference CPU path makes ~10 forward sweeps (two copies, x_norm, scale and bias passes).
+#include "chan_reduce.h"
+
+namespace bcnn_hip {
+
+// ---- forward statistics --------------------------------------------------------------------------
+struct StatsF {
+    const float* x;
+    __device__ void operator()(long long off, int, float (&acc)[2]) const {
+        const float v = x[off];
+        acc[0] += v;
+        acc[1] += v * v;
+    }
+    __device__ void vec4(long long off, int, float (&acc)[2]) const {
+        const float4 v = *reinterpret_cast<const float4*>(x + off);
+        acc[0] += (v.x + v.y) + (v.z + v.w);
+        acc[1] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+};
+
+__global__ void bn_stats_finalize_kernel(const float* __restrict__ partials, int C, int splits, int M,
+                                         float* __restrict__ saved_mean, float* __restrict__ saved_var,
+                                         float* __restrict__ run_mean, float* __restrict__ run_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, ss = 0.0;
+    for (int i = 0; i < splits; ++i) {
+        s += (double)partials[((long long)c * splits + i) * 2 + 0];
+        ss += (double)partials[((long long)c * splits + i) * 2 + 1];
+    }
+    const float inv = 1.0f / (float)M;
+    const float mean = __fmul_rn((float)s, inv);                                        // bcnn_scal(c, scale, mean)
+    const float var = __fsub_rn(__fmul_rn((float)ss, inv), __fmul_rn(mean, mean));      // bcnn_varmean
+    saved_mean[c] = mean;
+    saved_var[c] = var;
+    run_mean[c] = __fadd_rn(__fmul_rn(mean, 0.1f), __fmul_rn(run_mean[c], 0.9f));        // scal 0.9, axpy 0.1
+    run_var[c] = __fadd_rn(__fmul_rn(var, 0.1f), __fmul_rn(run_var[c], 0.9f));
+}
+
+// ---- forward apply ---------------------------------------------------------------------------------
+// mode TRAIN/VALID: y = act(scale*((x - mean)/sqrtf(var + 1e-6)) + bias);  PREDICT: y = act(x*scale + bias)
+// Optional side outputs: ws (copy of x, when ws != x) and xn (normalised values).
+struct BnApplyArgs {
+    const float* x;
+    float* y;
+    float* ws;
+    float* xn;
+    const float* mean;
+    const float* var;
+    const float* scale;
+    const float* bias;
+    int C, HW, predict, act;
+    long long total;
+};
+
+__device__ __forceinline__ float bn_one(float x, float mean, float rs, float sc, float b, int predict,
+                                        int act, float* xn_out) {
+    float v;
+    if (predict) {
+        v = __fadd_rn(__fmul_rn(x, sc), b);  // scale_and_add_bias, bcnn_batchnorm_layer.c:183-194
+    } else {
+        v = __fdiv_rn(__fsub_rn(x, mean), rs);
+        *xn_out = v;
+        if (sc == 0.0f) v = 0.f;             // bcnn_scal: a == 0 -> memset
+        else if (sc != 1.0f) v = __fmul_rn(v, sc);
+        if (b != 0.0f && b != 1.0f) v = __fadd_rn(v, b);  // bcnn_add_scalar quirk
+    }
+    return act_fwd(v, act, 0.f);
+}
+
+struct BnApplyBody {
+    BnApplyArgs a;
+    bool al;
+    __device__ void operator()(unsigned off, int c, int cnt) const {
+        const float mean = a.predict ? 0.f : a.mean[c];
+        const float rs = a.predict ? 1.f : sqrtf(a.var[c] + 0.000001f);
+        const float sc = a.scale[c], b = a.bias[c];
+        const bool side_ws = a.ws && a.ws != a.x, side_xn = a.xn && !a.predict;
+        if (cnt == 4 && al && (off & 3u) == 0) {
+            const float4 xv = *reinterpret_cast<const float4*>(a.x + off);
+            float4 yv, nv;
+            yv.x = bn_one(xv.x, mean, rs, sc, b, a.predict, a.act, &nv.x);
+            yv.y = bn_one(xv.y, mean, rs, sc, b, a.predict, a.act, &nv.y);
+            yv.z = bn_one(xv.z, mean, rs, sc, b, a.predict, a.act, &nv.z);
+            yv.w = bn_one(xv.w, mean, rs, sc, b, a.predict, a.act, &nv.w);
+            if (side_ws) *reinterpret_cast<float4*>(a.ws + off) = xv;
+            if (side_xn) *reinterpret_cast<float4*>(a.xn + off) = nv;
+            *reinterpret_cast<float4*>(a.y + off) = yv;
+        } else {
+            for (int k = 0; k < cnt; ++k) {
+                const float xv = a.x[off + k];
+                float nv = 0.f;
+                const float yv = bn_one(xv, mean, rs, sc, b, a.predict, a.act, &nv);
+                if (side_ws) a.ws[off + k] = xv;
+                if (side_xn) a.xn[off + k] = nv;
+                a.y[off + k] = yv;
+            }
+        }
+    }
+};
+
+// ---- backward sums ---------------------------------------------------------------------------------
+// g' = dy * act'(y) (optional fused activation backward);  S1 = sum g',  S2 = sum g' * (x - mean)
+struct BwdSumsF {
+    const float* dy;
+    const float* y;   // post-activation output, used only when act != NONE
+    const float* x;   // pre-normalisation input (workspace)
+    const float* mean;
+    int act, C, HW;
+    __device__ void operator()(long long off, int c, float (&acc)[2]) const {
+        float g = dy[off];
+        if (act != BCNN_HIP_ACT_NONE) g *= act_bwd_factor(y[off], act, 0.f);
+        acc[0] += g;
+        acc[1] += g * (x[off] - mean[c]);
+    }
+    __device__ void vec4(long long off, int c, float (&acc)[2]) const {
+        const float m = mean[c];
+        float4 g = *reinterpret_cast<const float4*>(dy + off);
+        const float4 xv = *reinterpret_cast<const float4*>(x + off);
+        if (act != BCNN_HIP_ACT_NONE) {
+            const float4 yv = *reinterpret_cast<const float4*>(y + off);
+            g.x *= act_bwd_factor(yv.x, act, 0.f); g.y *= act_bwd_factor(yv.y, act, 0.f);
+            g.z *= act_bwd_factor(yv.z, act, 0.f); g.w *= act_bwd_factor(yv.w, act, 0.f);
+        }
+        acc[0] += (g.x + g.y) + (g.z + g.w);
+        acc[1] += (g.x * (xv.x - m) + g.y * (xv.y - m)) + (g.z * (xv.z - m) + g.w * (xv.w - m));
+    }
+};
+
+// dbias += S1 ; dscales += S2/sqrt(var+1e-6) ; dmean = scale*S1 * (-1/sqrt(var+1e-5)) ;
+// dvar = scale*S2 * (-0.5/(var*sqrt(var)+1e-5))          (bcnn_batchnorm_layer.c:263-281, bcnn_mat.c:692-727)
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int C, int splits,
+                                       const float* __restrict__ scale, const float* __restrict__ var,
+                                       float* __restrict__ dbias, float* __restrict__ dscales,
+                                       float* __restrict__ dmean, float* __restrict__ dvar) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = 0; i < splits; ++i) {
+        s1 += (double)partials[((long long)c * splits + i) * 2 + 0];
+        s2 += (double)partials[((long long)c * splits + i) * 2 + 1];
+    }
+    const float v = var[c], sc = scale[c];
+    dbias[c] += (float)s1;
+    dscales[c] += (float)(s2 / (double)sqrtf(v + 0.000001f));
+    float md = (float)(s1 * (double)sc);
+    float vd = (float)(s2 * (double)sc);
+    md *= (-1.0f / sqrtf(v + 0.00001f));
+    vd *= -0.5f / (v * sqrtf(v) + 0.00001f);
+    dmean[c] = md;
+    dvar[c] = vd;
+}
+
+struct BnBwdApplyArgs {
+    float* dy;        // in/out
+    float* dx;        // optional copy
+    const float* y;   // post-activation (act != NONE)
+    const float* x;   // workspace
+    const float* mean;
+    const float* var;
+    const float* scale;
+    const float* dmean;
+    const float* dvar;
+    int C, HW, act, M;
+    long long total;
+};
+
+__device__ __forceinline__ float bn_bwd_one(float g, float yv, float xv, float mean, float rs, float sc,
+                                            float dm_m, float dv, float fM, int act) {
+    if (act != BCNN_HIP_ACT_NONE) g *= act_bwd_factor(yv, act, 0.f);
+    if (sc == 0.0f) g = 0.f;
+    else if (sc != 1.0f) g = __fmul_rn(g, sc);
+    // grad*1.0f/sqrtf(var+1e-5) + dvar*2*(x-mean)/M + dmean/M     (bcnn_batchnorm_layer.c:292-296)
+    const float t1 = __fdiv_rn(g, rs);
+    const float t2 = __fdiv_rn(__fmul_rn(__fmul_rn(dv, 2.0f), __fsub_rn(xv, mean)), fM);
+    return __fadd_rn(__fadd_rn(t1, t2), dm_m);
+}
+
+struct BnBwdApplyBody {
+    BnBwdApplyArgs a;
+    bool al;
+    __device__ void operator()(unsigned off, int c, int cnt) const {
+        const float fM = (float)a.M;
+        const bool use_y = a.act != BCNN_HIP_ACT_NONE;
+        const float mean = a.mean[c], rs = sqrtf(a.var[c] + 0.00001f), sc = a.scale[c];
+        const float dmm = __fdiv_rn(a.dmean[c], fM), dv = a.dvar[c];
+        if (cnt == 4 && al && (off & 3u) == 0) {
+            const float4 g = *reinterpret_cast<const float4*>(a.dy + off);
+            const float4 xv = *reinterpret_cast<const float4*>(a.x + off);
+            float4 yv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (use_y) yv = *reinterpret_cast<const float4*>(a.y + off);
+            float4 o;
+            o.x = bn_bwd_one(g.x, yv.x, xv.x, mean, rs, sc, dmm, dv, fM, a.act);
+            o.y = bn_bwd_one(g.y, yv.y, xv.y, mean, rs, sc, dmm, dv, fM, a.act);
+            o.z = bn_bwd_one(g.z, yv.z, xv.z, mean, rs, sc, dmm, dv, fM, a.act);
+            o.w = bn_bwd_one(g.w, yv.w, xv.w, mean, rs, sc, dmm, dv, fM, a.act);
+            *reinterpret_cast<float4*>(a.dy + off) = o;
+            if (a.dx) *reinterpret_cast<float4*>(a.dx + off) = o;
+        } else {
+            for (int k = 0; k < cnt; ++k) {
+                const float o = bn_bwd_one(a.dy[off + k], use_y ? a.y[off + k] : 0.f, a.x[off + k], mean, rs,
+                                           sc, dmm, dv, fM, a.act);
+                a.dy[off + k] = o;
+                if (a.dx) a.dx[off + k] = o;
+            }
+        }
+    }
+};
+
+}  // namespace bcnn_hip
+
+using namespace bcnn_hip;
+
+extern "C" {
+
+void bcnn_hip_batchnorm_forward(const float* x, float* y, float* run_mean, float* run_var,
+                                const float* scales, const float* bias, float* saved_mean,
+                                float* saved_var, float* x_norm, float* workspace, int n, int c, int hw,
+                                int mode, int act) {
+    const long long M = (long long)n * hw, total = M * c;
+    if (!total) return;
+    BnApplyArgs a;
+    a.x = x; a.y = y; a.ws = workspace; a.xn = x_norm; a.scale = scales; a.bias = bias;
+    a.C = c; a.HW = hw; a.act = act; a.total = total;
+    a.predict = (mode == BCNN_HIP_MODE_PREDICT);
+    a.mean = run_mean; a.var = run_var;
+    if (mode == BCNN_HIP_MODE_PREDICT) a.ws = nullptr;  // the reference keeps no copy in PREDICT mode
+    if (mode == BCNN_HIP_MODE_VALID) a.xn = nullptr;    // x_norm is only written in TRAIN mode (:230)
+    if (mode == BCNN_HIP_MODE_TRAIN) {
+        const int splits = chan_splits(c, M);
+        float* part = reduce_scratch((size_t)c * splits * 2);
+        launch_chan_reduce<2>(StatsF{x}, c, hw, M, splits, part);
+        bn_stats_finalize_kernel<<<ceil_div(c, 256), 256, 0, current_stream()>>>(
+            part, c, splits, (int)M, saved_mean, saved_var, run_mean, run_var);
+        KERNEL_CHECK();
+        a.mean = saved_mean; a.var = saved_var;
+    }
+    auto al16 = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    launch_chan_map(BnApplyBody{a, al16(x) && al16(y) && al16(a.ws) && al16(a.xn)}, n, c, hw);
+}
+
+void bcnn_hip_batchnorm_backward(float* dy, float* dx, const float* y, int act, const float* scales,
+                                 float* dscales, float* dbias, const float* saved_mean,
+                                 const float* saved_var, float* dmean, float* dvar, const float* x_norm,
+                                 const float* workspace, int n, int c, int hw) {
+    (void)x_norm;  // recomputed from workspace/mean/var: saves a full-tensor read (and its write in forward)
+    const long long M = (long long)n * hw, total = M * c;
+    if (!total) return;
+    const int splits = chan_splits(c, M);
+    float* part = reduce_scratch((size_t)c * splits * 2);
+    BwdSumsF f;
+    f.dy = dy; f.y = y; f.x = workspace; f.mean = saved_mean; f.act = act; f.C = c; f.HW = hw;
+    launch_chan_reduce<2>(f, c, hw, M, splits, part);
+    bn_bwd_finalize_kernel<<<ceil_div(c, 256), 256, 0, current_stream()>>>(part, c, splits, scales, saved_var,
+                                                                          dbias, dscales, dmean, dvar);
+    KERNEL_CHECK();
+    BnBwdApplyArgs a;
+    a.dy = dy; a.dx = (dx && dx != dy) ? dx : nullptr; a.y = y; a.x = workspace;
+    a.mean = saved_mean; a.var = saved_var; a.scale = scales; a.dmean = dmean; a.dvar = dvar;
+    a.C = c; a.HW = hw; a.act = act; a.M = (int)M; a.total = total;
+    auto al16 = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    launch_chan_map(BnBwdApplyBody{a, al16(dy) && al16(a.dx) && al16(workspace) && al16(y)}, n, c, hw);
+}
+
+}  // extern "C"

@@ -1,0 +1,192 @@
+// blas1.hip -- streaming BLAS-1 and per-channel helpers (HBM-bound; 16-byte accesses, grid-stride).
+// Reference semantics: src/kernels/bcnn_mat.c:52-115 (axpy), :319-364 (scal), :366-412 (add_scalar),
+// :761-811 (add_bias / scales / grad_scales / grad_bias); src/bcnn_learner.c:67-83 (SGD step).
+#include "chan_reduce.h"
+
+namespace bcnn_hip {
+
+// ---- per-thread reduction scratch ---------------------------------------------------------------
+struct Scratch {
+    float* p = nullptr;
+    size_t cap = 0;
+    int dev = -1;
+};
+static thread_local Scratch g_scratch;
+
+float* reduce_scratch(size_t floats) {
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    if (g_scratch.p == nullptr || g_scratch.cap < floats || g_scratch.dev != dev) {
+        if (g_scratch.p && g_scratch.dev == dev) HIP_CHECK(hipFree(g_scratch.p));  // hipFree syncs the device
+        size_t cap = floats < (1u << 16) ? (1u << 16) : floats * 2;
+        HIP_CHECK(hipMalloc((void**)&g_scratch.p, cap * sizeof(float)));
+        g_scratch.cap = cap;
+        g_scratch.dev = dev;
+    }
+    return g_scratch.p;
+}
+
+// ---- elementwise -------------------------------------------------------------------------------
+template <class Op>
+__global__ __launch_bounds__(256) void map2_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                   size_t n, Op op) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const bool al = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+    if (al) {
+        const size_t n4 = n / 4;
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+        float4* y4 = reinterpret_cast<float4*>(y);
+        for (size_t j = i; j < n4; j += stride) {
+            const float4 a = x4[j];
+            float4 b = y4[j];
+            b.x = op(a.x, b.x); b.y = op(a.y, b.y); b.z = op(a.z, b.z); b.w = op(a.w, b.w);
+            y4[j] = b;
+        }
+        for (size_t j = n4 * 4 + i; j < n; j += stride) y[j] = op(x[j], y[j]);
+    } else {
+        for (size_t j = i; j < n; j += stride) y[j] = op(x[j], y[j]);
+    }
+}
+
+struct AxpyOp { float a; __device__ float operator()(float x, float y) const { return __fadd_rn(__fmul_rn(x, a), y); } };
+struct CopyOp { __device__ float operator()(float x, float) const { return x; } };
+struct ScalOp { float a; __device__ float operator()(float, float y) const { return y * a; } };
+
+// ---- per-channel maps --------------------------------------------------------------------------
+// mode 0: y += bias[c] (skipped for bias == 0.0f / 1.0f exactly, bcnn_add_scalar quirk)
+// mode 1: y *= scale[c] (scale == 0 -> 0, scale == 1 -> untouched, bcnn_scal)
+struct ChanMapBody {
+    float* y;
+    const float* p;
+    int mode;
+    bool al;  // 16-byte accesses allowed
+    __device__ float one(float v, float q) const {
+        if (mode == 0) return (q != 0.0f && q != 1.0f) ? v + q : v;
+        return (q == 0.0f) ? 0.f : ((q != 1.0f) ? v * q : v);
+    }
+    __device__ void operator()(unsigned off, int c, int cnt) const {
+        const float q = p[c];
+        if (cnt == 4 && al && (off & 3u) == 0) {
+            float4 v = *reinterpret_cast<float4*>(y + off);
+            v.x = one(v.x, q); v.y = one(v.y, q); v.z = one(v.z, q); v.w = one(v.w, q);
+            *reinterpret_cast<float4*>(y + off) = v;
+        } else {
+            for (int k = 0; k < cnt; ++k) y[off + k] = one(y[off + k], q);
+        }
+    }
+};
+
+// ---- per-channel reductions ---------------------------------------------------------------------
+struct SumF {
+    const float* g;
+    __device__ void operator()(long long off, int, float (&acc)[1]) const { acc[0] += g[off]; }
+    __device__ void vec4(long long off, int, float (&acc)[1]) const {
+        const float4 v = *reinterpret_cast<const float4*>(g + off);
+        acc[0] += (v.x + v.y) + (v.z + v.w);
+    }
+};
+struct DotF {
+    const float* g;
+    const float* x;
+    __device__ void operator()(long long off, int, float (&acc)[1]) const { acc[0] += g[off] * x[off]; }
+    __device__ void vec4(long long off, int, float (&acc)[1]) const {
+        const float4 a = *reinterpret_cast<const float4*>(g + off);
+        const float4 b = *reinterpret_cast<const float4*>(x + off);
+        acc[0] += (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
+    }
+};
+
+// out[c] += sum over splits (fixed order, double)
+__global__ void chan_accumulate_kernel(const float* __restrict__ partials, int C, int splits,
+                                       float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int i = 0; i < splits; ++i) s += (double)partials[(long long)c * splits + i];
+    out[c] += (float)s;
+}
+
+// ---- SGD -----------------------------------------------------------------------------------------
+// one pass per buffer instead of the reference's axpy/axpy/scal sequence; identical arithmetic:
+//   g' = g + (decay*B)*w ; w' = w + (-lr/B)*g' ; g'' = g'*momentum        (bcnn_learner.c:76-80)
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ w, float* __restrict__ g, size_t n,
+                                                  float wd_b, float neg_lr_b, float momentum) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float gi = g[i], wi = w[i];
+        if (wd_b != 0.f) gi = __fadd_rn(__fmul_rn(wi, wd_b), gi);
+        wi = __fadd_rn(__fmul_rn(gi, neg_lr_b), wi);
+        w[i] = wi;
+        g[i] = (momentum == 0.0f) ? 0.f : ((momentum == 1.0f) ? gi : gi * momentum);
+    }
+}
+
+}  // namespace bcnn_hip
+
+using namespace bcnn_hip;
+
+extern "C" {
+
+void bcnn_hip_axpy(size_t n, float a, const float* x, float* y) {
+    if (!n) return;
+    map2_kernel<<<stream_grid(n / 4 + 1, 256), 256, 0, current_stream()>>>(x, y, n, AxpyOp{a});
+    KERNEL_CHECK();
+}
+
+void bcnn_hip_scal(size_t n, float a, float* x) {
+    if (!n) return;
+    if (a == 0.0f) { HIP_CHECK(hipMemsetAsync(x, 0, n * sizeof(float), current_stream())); return; }
+    if (a == 1.0f) return;
+    map2_kernel<<<stream_grid(n / 4 + 1, 256), 256, 0, current_stream()>>>((const float*)x, x, n, ScalOp{a});
+    KERNEL_CHECK();
+}
+
+void bcnn_hip_copy_f32(size_t n, const float* x, float* y) {
+    if (!n || x == y) return;
+    HIP_CHECK(hipMemcpyAsync(y, x, n * sizeof(float), hipMemcpyDeviceToDevice, current_stream()));
+}
+
+void bcnn_hip_add_bias(float* y, const float* bias, int n, int c, int hw) {
+    launch_chan_map(ChanMapBody{y, bias, 0, (reinterpret_cast<uintptr_t>(y) & 15) == 0}, n, c, hw);
+}
+
+void bcnn_hip_scales(float* y, const float* scales, int n, int c, int hw) {
+    launch_chan_map(ChanMapBody{y, scales, 1, (reinterpret_cast<uintptr_t>(y) & 15) == 0}, n, c, hw);
+}
+
+void bcnn_hip_grad_bias(float* dbias, const float* g, int n, int c, int hw) {
+    const long long M = (long long)n * hw;
+    if (!M || !c) return;
+    const int splits = chan_splits(c, M);
+    float* part = reduce_scratch((size_t)c * splits);
+    launch_chan_reduce<1>(SumF{g}, c, hw, M, splits, part);
+    chan_accumulate_kernel<<<ceil_div(c, 256), 256, 0, current_stream()>>>(part, c, splits, dbias);
+    KERNEL_CHECK();
+}
+
+void bcnn_hip_grad_scales(const float* x_norm, const float* g, int n, int c, int hw, float* dscales) {
+    const long long M = (long long)n * hw;
+    if (!M || !c) return;
+    const int splits = chan_splits(c, M);
+    float* part = reduce_scratch((size_t)c * splits);
+    launch_chan_reduce<1>(DotF{g, x_norm}, c, hw, M, splits, part);
+    chan_accumulate_kernel<<<ceil_div(c, 256), 256, 0, current_stream()>>>(part, c, splits, dscales);
+    KERNEL_CHECK();
+}
+
+void bcnn_hip_sgd_update(float* w, float* b, float* dw, float* db, size_t w_size, size_t b_size,
+                         int batch_size, float lr, float momentum, float decay) {
+    const float neg_lr_b = -lr / batch_size;
+    if (b && db && b_size) {
+        sgd_kernel<<<stream_grid(b_size, 256), 256, 0, current_stream()>>>(b, db, b_size, 0.f, neg_lr_b, momentum);
+        KERNEL_CHECK();
+    }
+    if (w && dw && w_size) {
+        sgd_kernel<<<stream_grid(w_size, 256), 256, 0, current_stream()>>>(w, dw, w_size, decay * batch_size,
+                                                                         neg_lr_b, momentum);
+        KERNEL_CHECK();
+    }
+}
+
+}  // extern "C"

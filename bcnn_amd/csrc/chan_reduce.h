@@ -1,0 +1,123 @@
+// chan_reduce.h -- deterministic per-channel reductions over dense NCHW tensors (HBM-bound).
+//
+// Used by batch-norm statistics / backward sums, bias and scale gradients. Two levels:
+//   1. chan_reduce_partial: grid (C, splits); each 256-thread workgroup streams its slice of the
+//      channel's N*HW elements with 16-byte loads (when HW % 4 == 0), reduces with wave64 shuffles
+//      (DPP row moves) and a tiny LDS cross-wave step, and writes NV partial sums;
+//   2. the caller's finalize kernel combines the `splits` partials in a fixed order (in double),
+// so results do not depend on scheduling -- unlike the reference CUDA kernels' unsynchronised
+// `+=` (src/kernels/bcnn_mat.cu:377-379).
+#pragma once
+#include "common.h"
+
+namespace bcnn_hip {
+
+inline int chan_splits(int channels, long long per_channel) {
+    // aim for >= ~4 workgroups per CU overall, but keep >= 4096 elements per workgroup
+    long long want = (4LL * kCUs + channels - 1) / channels;
+    long long maxs = (per_channel + 4095) / 4096;
+    if (want > maxs) want = maxs;
+    if (want < 1) want = 1;
+    if (want > 1024) want = 1024;
+    return (int)want;
+}
+
+#ifdef __HIPCC__
+// F: struct with  __device__ void operator()(long long off, int c, float (&acc)[NV]) const  (one element)
+// and             __device__ void vec4(long long off, int c, float (&acc)[NV]) const        (4 consecutive)
+template <int NV, class F>
+__global__ __launch_bounds__(256) void chan_reduce_partial(const F f, int C, int HW, int M /* N*HW */,
+                                                           int splits, float* __restrict__ partials) {
+    __shared__ float red[4][NV];
+    const int c = blockIdx.x, sp = blockIdx.y;
+    // slice [lo, hi) of the channel's virtual index space, multiples of 4
+    const int per = (((M + splits - 1) / splits) + 3) & ~3;
+    const int lo = sp * per;
+    int hi = lo + per;
+    if (hi > M) hi = M;
+    float acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v] = 0.f;
+    if ((HW & 3) == 0) {
+        for (int idx = lo + threadIdx.x * 4; idx < hi; idx += 256 * 4) {
+            const int n = idx / HW, i = idx - n * HW;
+            f.vec4(((long long)n * C + c) * HW + i, c, acc);
+        }
+    } else {
+        for (int idx = lo + threadIdx.x; idx < hi; idx += 256) {
+            const int n = idx / HW, i = idx - n * HW;
+            f(((long long)n * C + c) * HW + i, c, acc);
+        }
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const float t = wave_sum(acc[v]);
+        if (lane == 0) red[wid][v] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        const int v = threadIdx.x;
+        partials[((long long)c * splits + sp) * NV + v] = (red[0][v] + red[1][v]) + (red[2][v] + red[3][v]);
+    }
+}
+
+template <int NV, class F>
+inline void launch_chan_reduce(const F& f, int C, int HW, long long M, int splits, float* partials) {
+    dim3 grid((unsigned)C, (unsigned)splits);
+    chan_reduce_partial<NV, F><<<grid, 256, 0, current_stream()>>>(f, C, HW, (int)M, splits, partials);
+    KERNEL_CHECK();
+}
+#endif
+
+#ifdef __HIPCC__
+// Per-channel elementwise maps over NCHW: one workgroup per (plane, 4096-element chunk) when planes
+// are large (channel index is then workgroup-uniform: no per-element division), else a flat
+// grid-stride loop with 32-bit index math. Body: __device__ void operator()(unsigned off, int c, int cnt)
+// processes cnt (1..4) consecutive elements starting at `off` (cnt == 4 => 16-byte aligned when
+// HW % 4 == 0 and the tensor base is 16-byte aligned).
+template <class Body>
+__global__ __launch_bounds__(256) void plane_map_kernel(const Body body, int C, int HW, int chunks) {
+    const int plane = blockIdx.x / chunks, chunk = blockIdx.x - plane * chunks;
+    const int c = plane % C;
+    const unsigned base = (unsigned)plane * (unsigned)HW;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int i = chunk * 4096 + it * 1024 + threadIdx.x * 4;
+        if (i < HW) body(base + i, c, (HW - i) >= 4 ? 4 : (HW - i));
+    }
+}
+template <class Body>
+__global__ __launch_bounds__(256) void flat_map_kernel(const Body body, int C, int HW, unsigned total) {
+    const unsigned stride = gridDim.x * blockDim.x * 4u;
+    for (unsigned i = (blockIdx.x * blockDim.x + threadIdx.x) * 4u; i < total; i += stride) {
+        const unsigned plane = i / (unsigned)HW, in = i - plane * (unsigned)HW;
+        const int c = (int)(plane % (unsigned)C);
+        const int cnt = (total - i) >= 4u ? 4 : (int)(total - i);
+        if (in + (unsigned)cnt <= (unsigned)HW) { body(i, c, cnt); continue; }
+        // the 4 elements straddle a plane boundary: one at a time
+        for (int k = 0; k < cnt; ++k) {
+            const unsigned pl = (i + k) / (unsigned)HW;
+            body(i + k, (int)(pl % (unsigned)C), 1);
+        }
+    }
+}
+template <class Body>
+inline void launch_chan_map(const Body& body, int N, int C, int HW) {
+    const long long total = (long long)N * C * HW;
+    if (total == 0) return;
+    if (HW >= 1024) {
+        const int chunks = (HW + 4095) / 4096;
+        plane_map_kernel<Body><<<(unsigned)(N * C * chunks), 256, 0, current_stream()>>>(body, C, HW, chunks);
+    } else {
+        flat_map_kernel<Body><<<stream_grid((size_t)(total / 4 + 1), 256), 256, 0, current_stream()>>>(
+            body, C, HW, (unsigned)total);
+    }
+    KERNEL_CHECK();
+}
+#endif
+
+// Small per-stream scratch for reduction partials (grow-only, freed at process exit).
+float* reduce_scratch(size_t floats);  // blas1.hip
+
+}  // namespace bcnn_hip

@@ -1,0 +1,111 @@
+// common.h -- shared device/host helpers for the gfx950 kernels (not part of the C-ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+
+#include "../../include/bcnn_hip.h"
+
+// Reference convention (src/bcnn_utils.h:174-195): print and exit on any device error.
+#define HIP_CHECK(expr)                                                                        \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            fprintf(stderr, "[bcnn_hip] %s:%d: %s failed: %s\n", __FILE__, __LINE__, #expr,    \
+                    hipGetErrorString(_e));                                                    \
+            exit((int)_e);                                                                     \
+        }                                                                                      \
+    } while (0)
+
+#define KERNEL_CHECK() HIP_CHECK(hipGetLastError())
+
+namespace bcnn_hip {
+
+hipStream_t current_stream();  // runtime.hip
+
+constexpr int kWave = 64;      // CDNA wavefront
+constexpr int kCUs = 256;      // MI355X
+constexpr int kXCDs = 8;
+
+inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// grid for a grid-stride streaming kernel: enough blocks to fill the chip, capped (guide G11).
+inline int stream_grid(size_t work_items, int block) {
+    size_t need = (work_items + block - 1) / block;
+    size_t cap = (size_t)kCUs * 8;
+    if (need < 1) need = 1;
+    return (int)(need < cap ? need : cap);
+}
+
+#ifdef __HIPCC__
+// XCD-aware block remap: the dispatcher places block b on XCD b % 8; give each XCD a contiguous run
+// of logical tiles so neighbours (which share operand panels / halos) hit the same L2.
+// Bijective for any nblk (guide section 5 "XCD swizzle must be bijective").
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk / kXCDs, r = nblk % kXCDs;
+    const int xcd = bid % kXCDs, idx = bid / kXCDs;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// block-wide sum of one value; result valid in thread 0. `red` holds >= blockDim/64 floats.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    float t = 0.f;
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x + 63) >> 6;
+        for (int i = 0; i < nw; ++i) t += red[i];
+    }
+    return t;
+}
+
+// The activation map, bcnn_activation_layer.c:90-146. exp/log are evaluated in double exactly
+// where the reference does, so results agree to rounding of the final float conversion.
+__device__ __forceinline__ float act_fwd(float x, int act, float slope) {
+    switch (act) {
+        case BCNN_HIP_ACT_TANH: {
+            const float t = 2 * x;
+            const double e = exp((double)t);
+            return (float)(e - 1) / ((float)e + 1);
+        }
+        case BCNN_HIP_ACT_RELU: return x * (float)(x > 0);  // a multiply: -0.0f for negatives, NaN propagates
+        case BCNN_HIP_ACT_LRELU: return x > 0 ? x : 0.1f * x;
+        case BCNN_HIP_ACT_RAMP: return x * (float)(x > 0) + 0.1f * x;
+        case BCNN_HIP_ACT_SOFTPLUS: return (float)log((double)(1.0f + (float)exp((double)x)));
+        case BCNN_HIP_ACT_ABS: return fabsf(x);
+        case BCNN_HIP_ACT_CLAMP: return (x < 0) ? 0.f : ((x > 1) ? 1.f : x);
+        case BCNN_HIP_ACT_LOGISTIC: return 1.0f / (1.0f + (float)exp((double)(-x)));
+        case BCNN_HIP_ACT_PRELU: return x > 0 ? x : slope * x;
+        default: return x;
+    }
+}
+
+// derivative factor from the POST-activation value, bcnn_activation_layer.c:165-226
+__device__ __forceinline__ float act_bwd_factor(float y, int act, float slope) {
+    switch (act) {
+        case BCNN_HIP_ACT_TANH: return 1 - y * y;
+        case BCNN_HIP_ACT_RELU: return (float)(y > 0);
+        case BCNN_HIP_ACT_LRELU: return y > 0 ? 1.0f : 0.1f;
+        case BCNN_HIP_ACT_RAMP: return (float)(y > 0) + 0.1f;
+        case BCNN_HIP_ACT_SOFTPLUS: return 1.0f / (1.0f + (float)exp((double)(-y)));
+        case BCNN_HIP_ACT_ABS: return y >= 0 ? 1.0f : -1.0f;
+        case BCNN_HIP_ACT_CLAMP: return (float)(y > 0.0f && y < 1.0f);
+        case BCNN_HIP_ACT_LOGISTIC: return (1 - y) * y;
+        case BCNN_HIP_ACT_PRELU: return y > 0 ? 1.0f : slope;
+        default: return 1.0f;
+    }
+}
+#endif  // __HIPCC__
+
+}  // namespace bcnn_hip

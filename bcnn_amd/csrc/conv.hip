@@ -1,0 +1,67 @@
+// conv.hip -- C-ABI entry points of the convolution node (include/bcnn_hip.h), composing the
+// implicit-GEMM kernels (conv_fwd.hip, conv_bwd.hip) with the batch-norm / activation kernels the way
+// bcnn_forward_conv_layer_cpu / bcnn_backward_conv_layer_cpu do (reference bcnn_conv_layer.c:367-587).
+#include "conv_common.h"
+
+namespace bcnn_hip {
+void conv_forward_dispatch(const float* x, const float* w, const float* bias, const float* slopes, float* y,
+                           const ConvShape& s, int act, int raw);
+size_t conv_dw_workspace_floats(const ConvShape& s);
+bool conv_backward_weights(const float* x, const float* dy, float* dw, float* dbias, const ConvShape& s,
+                           float* workspace, size_t workspace_floats, bool want_bias);
+void conv_backward_data(const float* w, const float* dy, float* dx, const ConvShape& s);
+}  // namespace bcnn_hip
+
+using namespace bcnn_hip;
+
+extern "C" {
+
+size_t bcnn_hip_conv_workspace_size(int n, int c, int h, int w, int f, int k, int stride, int pad, int groups) {
+    return conv_dw_workspace_floats(make_conv_shape(n, c, h, w, f, k, stride, pad, groups));
+}
+
+void bcnn_hip_conv_forward(const float* x, const float* w, const float* bias, float* y, int n, int c, int h,
+                           int wd, int f, int k, int stride, int pad, int groups, int act, const float* slopes,
+                           int batch_norm, float* run_mean, float* run_var, const float* scales,
+                           float* saved_mean, float* saved_var, float* x_norm, float* bn_workspace, int mode) {
+    const ConvShape s = make_conv_shape(n, c, h, wd, f, k, stride, pad, groups);
+    if (!batch_norm) {
+        conv_forward_dispatch(x, w, bias, slopes, y, s, act, /*raw=*/0);
+        return;
+    }
+    // conv -> (pre-normalisation values, kept for backward) -> statistics -> normalise+scale+bias+act
+    float* raw = (bn_workspace && mode != BCNN_HIP_MODE_PREDICT) ? bn_workspace : y;
+    conv_forward_dispatch(x, w, nullptr, nullptr, raw, s, BCNN_HIP_ACT_NONE, /*raw=*/1);
+    const int fused_act = (act == BCNN_HIP_ACT_PRELU) ? BCNN_HIP_ACT_NONE : act;
+    bcnn_hip_batchnorm_forward(raw, y, run_mean, run_var, scales, bias, saved_mean, saved_var, x_norm, raw, n, f,
+                               s.OHOW, mode, fused_act);
+    if (act == BCNN_HIP_ACT_PRELU)
+        bcnn_hip_activation_forward(y, (size_t)n * f * s.OHOW, act, slopes, s.OHOW, f);
+}
+
+void bcnn_hip_conv_backward(const float* x, const float* w, const float* y, float* dy, float* dx, float* dw,
+                            float* dbias, int n, int c, int h, int wd, int f, int k, int stride, int pad,
+                            int groups, int act, const float* slopes, float* dslopes, int batch_norm,
+                            const float* scales, float* dscales, const float* saved_mean,
+                            const float* saved_var, float* dmean, float* dvar, const float* x_norm,
+                            const float* bn_workspace, float* workspace, size_t workspace_elems) {
+    const ConvShape s = make_conv_shape(n, c, h, wd, f, k, stride, pad, groups);
+    const size_t ysize = (size_t)n * f * s.OHOW;
+    if (batch_norm) {
+        int fused_act = act;
+        if (act == BCNN_HIP_ACT_PRELU) {
+            bcnn_hip_activation_backward(y, dy, ysize, act, slopes, dslopes, s.OHOW, f);
+            fused_act = BCNN_HIP_ACT_NONE;
+        }
+        bcnn_hip_batchnorm_backward(dy, nullptr, y, fused_act, scales, dscales, dbias, saved_mean, saved_var,
+                                    dmean, dvar, x_norm, bn_workspace, n, f, s.OHOW);
+    } else {
+        bcnn_hip_activation_backward(y, dy, ysize, act, slopes, dslopes, s.OHOW, f);
+    }
+    const bool bias_done = conv_backward_weights(x, dy, dw, dbias, s, workspace, workspace_elems,
+                                                 /*want_bias=*/!batch_norm);
+    if (!batch_norm && !bias_done) bcnn_hip_grad_bias(dbias, dy, n, f, s.OHOW);
+    if (dx) conv_backward_data(w, dy, dx, s);
+}
+
+}  // extern "C"

@@ -1,0 +1,45 @@
+// conv_common.h -- shapes and MFMA helpers shared by the convolution kernels.
+#pragma once
+#include "common.h"
+
+namespace bcnn_hip {
+
+// One convolution problem, whole batch. Derived fields filled by make_conv_shape().
+struct ConvShape {
+    int N, C, H, W, F, ksz, stride, pad, groups;
+    int OH, OW, OHOW, HW, Cg, Mg, K;  // Cg = C/groups, Mg = F/groups, K = Cg*ksz*ksz
+    long long total_q;                // N*OH*OW output pixel columns (batch folded into GEMM-N)
+    long long total_p;                // N*H*W input pixel columns (for dX)
+    int pointwise;                    // ksz == 1: source read as a raw [Cg][OH*OW] matrix (quirk 1)
+};
+
+inline ConvShape make_conv_shape(int n, int c, int h, int w, int f, int k, int stride, int pad,
+                                 int groups) {
+    ConvShape s;
+    s.N = n; s.C = c; s.H = h; s.W = w; s.F = f; s.ksz = k; s.stride = stride; s.pad = pad;
+    s.groups = groups;
+    s.OH = (h + 2 * pad - k) / stride + 1;  // reference bcnn_conv_layer.c:126-134
+    s.OW = (w + 2 * pad - k) / stride + 1;
+    s.OHOW = s.OH * s.OW; s.HW = h * w;
+    s.Cg = c / groups; s.Mg = f / groups; s.K = s.Cg * k * k;
+    s.total_q = (long long)n * s.OHOW;
+    s.total_p = (long long)n * s.HW;
+    s.pointwise = (k == 1);
+    return s;
+}
+
+#ifdef __HIPCC__
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// v_mfma_f32_32x32x2_f32: D[32x32] += A[32x2] * B[2x32], exact fp32 fma chain (guide section 3).
+// lane l holds A[i = l&31][k = l>>5], B[k = l>>5][j = l&31];
+// D: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5) for accumulator register r in [0,16).
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int mfma_row(int r, int lane) {
+    return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+}
+#endif
+
+}  // namespace bcnn_hip

@@ -1,0 +1,133 @@
+// pool.hip -- max pooling (bit-exact indices) and global average pooling. HBM-bound.
+//
+// Reference semantics: src/layers/bcnn_maxpool_layer.c:145-191 (forward), :258-273 (backward),
+// src/layers/bcnn_avgpool_layer.c:82-99, 109-125.
+#include <cfloat>
+
+#include "common.h"
+
+namespace bcnn_hip {
+
+// One thread per output element; consecutive lanes take consecutive output columns, so the window
+// rows they read are contiguous (stride `stride` floats) and the value/index stores are coalesced.
+// Window origin (i*stride, j*stride): padding exists only at the bottom/right; out-of-range taps
+// read as -FLT_MAX; scan rows outer / cols inner; replace only on `>`: the first maximum wins and a
+// NaN never wins. The index is the flat offset into the WHOLE source tensor (int32), as stored by
+// the reference -- compared bit-for-bit in tests.
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          int* __restrict__ idx, int planes, int H, int W,
+                                                          int OH, int OW, int size, int stride,
+                                                          unsigned total) {
+    const unsigned gstride = gridDim.x * blockDim.x;
+    for (unsigned o = blockIdx.x * blockDim.x + threadIdx.x; o < total; o += gstride) {
+        const unsigned j = o % (unsigned)OW, t = o / (unsigned)OW;
+        const unsigned i = t % (unsigned)OH, plane = t / (unsigned)OH;
+        const int base = (int)plane * H * W;
+        float best = -FLT_MAX;
+        int bi = -1;
+        for (int r = 0; r < size; ++r) {
+            const int hh = (int)i * stride + r;
+            for (int q = 0; q < size; ++q) {
+                const int ww = (int)j * stride + q;
+                const int si = base + hh * W + ww;
+                const bool ok = hh < H && ww < W;
+                const float v = ok ? x[si] : -FLT_MAX;
+                if (v > best) { best = v; bi = si; }
+            }
+        }
+        y[o] = best;
+        idx[o] = bi;
+    }
+}
+
+// Gather form of `dx[idx[o]] += dy[o]`: one thread per SOURCE element visits the (at most
+// ceil(size/stride)^2) outputs whose window covers it, in ascending output order, and adds those
+// that selected it. Same per-element addition order as the reference's ascending-o loop, no atomics.
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const int* __restrict__ idx,
+                                                          float* __restrict__ dx, int H, int W, int OH, int OW,
+                                                          int size, int stride, unsigned total) {
+    const unsigned gstride = gridDim.x * blockDim.x;
+    for (unsigned s = blockIdx.x * blockDim.x + threadIdx.x; s < total; s += gstride) {
+        const unsigned w = s % (unsigned)W, t = s / (unsigned)W;
+        const unsigned h = t % (unsigned)H, plane = t / (unsigned)H;
+        // outputs i with i*stride <= h <= i*stride + size - 1
+        int i0 = ((int)h - size + stride) / stride; if ((int)h - size + 1 <= 0) i0 = 0;
+        int j0 = ((int)w - size + stride) / stride; if ((int)w - size + 1 <= 0) j0 = 0;
+        int i1 = (int)h / stride; if (i1 > OH - 1) i1 = OH - 1;
+        int j1 = (int)w / stride; if (j1 > OW - 1) j1 = OW - 1;
+        float acc = dx[s];
+        bool hit = false;
+        const int obase = (int)plane * OH * OW;
+        for (int i = i0; i <= i1; ++i)
+            for (int j = j0; j <= j1; ++j) {
+                const int o = obase + i * OW + j;
+                if (idx[o] == (int)s) { acc += dy[o]; hit = true; }
+            }
+        if (hit) dx[s] = acc;
+    }
+}
+
+// Global average pooling: one wave64 per (n,c) plane, shuffle reduction, then / (H*W).
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          int planes, int HW) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int p = wave; p < planes; p += nwaves) {
+        const float* src = x + (long long)p * HW;
+        float s = 0.f;
+        for (int i = lane; i < HW; i += 64) s += src[i];
+        s = wave_sum(s);
+        if (lane == 0) y[p] = s / (float)HW;
+    }
+}
+
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx,
+                                                          int HW, unsigned total) {
+    const unsigned gstride = gridDim.x * blockDim.x;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gstride) {
+        const unsigned p = i / (unsigned)HW;
+        dx[i] += dy[p] / (float)HW;  // dst.grad / (h*w), int divisor promoted (bcnn_avgpool_layer.c:118-120)
+    }
+}
+
+}  // namespace bcnn_hip
+
+using namespace bcnn_hip;
+
+extern "C" {
+
+void bcnn_hip_maxpool_forward(const float* x, float* y, int* indexes, int n, int c, int h, int w, int out_h,
+                              int out_w, int size, int stride) {
+    const long long total = (long long)n * c * out_h * out_w;
+    if (!total) return;
+    maxpool_fwd_kernel<<<stream_grid((size_t)total, 256), 256, 0, current_stream()>>>(
+        x, y, indexes, n * c, h, w, out_h, out_w, size, stride, (unsigned)total);
+    KERNEL_CHECK();
+}
+
+void bcnn_hip_maxpool_backward(const float* dy, const int* indexes, float* dx, int n, int c, int h, int w,
+                               int out_h, int out_w, int size, int stride) {
+    const long long total = (long long)n * c * h * w;
+    if (!total || !(out_h * out_w)) return;
+    maxpool_bwd_kernel<<<stream_grid((size_t)total, 256), 256, 0, current_stream()>>>(
+        dy, indexes, dx, h, w, out_h, out_w, size, stride, (unsigned)total);
+    KERNEL_CHECK();
+}
+
+void bcnn_hip_avgpool_forward(const float* x, float* y, int n, int c, int h, int w) {
+    const int planes = n * c;
+    if (!planes) return;
+    const int grid = stream_grid((size_t)planes * 64, 256);
+    avgpool_fwd_kernel<<<grid, 256, 0, current_stream()>>>(x, y, planes, h * w);
+    KERNEL_CHECK();
+}
+
+void bcnn_hip_avgpool_backward(const float* dy, float* dx, int n, int c, int h, int w) {
+    const long long total = (long long)n * c * h * w;
+    if (!total) return;
+    avgpool_bwd_kernel<<<stream_grid((size_t)total, 256), 256, 0, current_stream()>>>(dy, dx, h * w, (unsigned)total);
+    KERNEL_CHECK();
+}
+
+}  // extern "C"

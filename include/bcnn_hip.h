@@ -1,0 +1,205 @@
+/*
+ * bcnn_hip.h -- C-ABI of the MI355X (gfx950) back-end for bcnn's conv/GEMM hot path.
+ *
+ * This is the drop-in boundary: a C99 host (bcnn_net / bcnn_node, the reference's own layer code)
+ * links against libbcnn_hip.so and calls these entry points where the reference's CUDA build calls
+ * its `bcnn_cuda_*` helper family and per-layer `*_gpu` workers. Only plain pointers, ints, floats
+ * and size_t cross the boundary; every pointer named `*_d` / documented "device" is HBM memory
+ * obtained from bcnn_hip_malloc_*. Unlike the reference helpers, operator entry points take
+ * WHOLE-BATCH shapes (one launch per direction, not one cublasSgemm per image).
+ *
+ * Error convention (reference: src/bcnn_utils.h:174-195): a failing HIP call prints
+ * file:line + the HIP error string to stderr and exit()s; entry points therefore return void.
+ *
+ * Each declaration cites the reference interface it replaces (file:line in jnbraun/bcnn).
+ * All tensors: dense NCHW fp32, idx(n,c,h,w) = ((n*C + c)*H + h)*W + w.
+ */
+#ifndef BCNN_HIP_H
+#define BCNN_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* enum bcnn_activation values (inc/bcnn/bcnn.h:164-175) -- passed as int `act`. */
+enum {
+    BCNN_HIP_ACT_NONE = 0, BCNN_HIP_ACT_TANH, BCNN_HIP_ACT_RELU, BCNN_HIP_ACT_RAMP,
+    BCNN_HIP_ACT_SOFTPLUS, BCNN_HIP_ACT_LRELU, BCNN_HIP_ACT_ABS, BCNN_HIP_ACT_CLAMP,
+    BCNN_HIP_ACT_PRELU, BCNN_HIP_ACT_LOGISTIC
+};
+/* enum bcnn_mode values (inc/bcnn/bcnn.h:105-112) -- passed as int `mode`. */
+enum { BCNN_HIP_MODE_PREDICT = 0, BCNN_HIP_MODE_TRAIN = 1, BCNN_HIP_MODE_VALID = 2 };
+
+/* ---------------------------------------------------------------------------------------------
+ * Runtime: device, memory, stream, events.  Replaces src/bcnn_utils.h:197-213 / bcnn_utils.c:101-201
+ * (bcnn_cuda_set_device, bcnn_cuda_malloc_f32/i32, bcnn_cuda_memcpy_*, bcnn_cuda_free,
+ *  bcnn_cuda_fill_f32) -- no library-global handle singletons, one explicit stream per thread.
+ * ------------------------------------------------------------------------------------------- */
+int bcnn_hip_device_count(void);
+void bcnn_hip_set_device(int id);                 /* bcnn_cuda_set_device, bcnn_utils.c:201 */
+int bcnn_hip_get_device(void);
+const char *bcnn_hip_device_name(void);           /* gcnArchName of the current device, e.g. "gfx950:..." */
+float *bcnn_hip_malloc_f32(size_t n);             /* bcnn_cuda_malloc_f32, bcnn_utils.c:133-140; zero-filled here */
+int *bcnn_hip_malloc_i32(size_t n);               /* bcnn_cuda_malloc_i32, bcnn_utils.c:124-131; zero-filled here */
+void bcnn_hip_free(void *p_d);                    /* bcnn_cuda_free, bcnn_utils.c:182-185 */
+void bcnn_hip_memcpy_h2d(void *dst_d, const void *src_h, size_t bytes); /* bcnn_cuda_memcpy_host2dev */
+void bcnn_hip_memcpy_d2h(void *dst_h, const void *src_d, size_t bytes); /* bcnn_cuda_memcpy_dev2host */
+void bcnn_hip_memcpy_d2d(void *dst_d, const void *src_d, size_t bytes);
+void bcnn_hip_fill_f32(float *x_d, size_t n, float value); /* bcnn_cuda_fill_f32, bcnn_mat.cu:52-60 */
+void bcnn_hip_sync(void);                         /* waits for the calling thread's stream */
+/* The stream all entry points launch on (per host thread). NULL = the device's null stream, which
+ * is also PyTorch-ROCm's default stream. bcnn_hip_stream_create returns an opaque hipStream_t. */
+void *bcnn_hip_stream_create(void);
+void bcnn_hip_stream_destroy(void *stream);
+void bcnn_hip_set_stream(void *stream);
+void *bcnn_hip_get_stream(void);
+/* HIP events recorded on the CURRENT stream (used by bench.py for per-kernel durations). */
+void *bcnn_hip_event_create(void);
+void bcnn_hip_event_destroy(void *ev);
+void bcnn_hip_event_record(void *ev);
+void bcnn_hip_event_sync(void *ev);
+float bcnn_hip_event_elapsed_ms(void *start, void *stop);
+
+/* ---------------------------------------------------------------------------------------------
+ * BLAS-1 / per-channel helpers.  Replaces bcnn_cuda_axpy/scal/copy (bcnn_mat.cu:44-100),
+ * bcnn_cuda_add_bias / bcnn_cuda_grad_bias (bcnn_mat.cu:348-391), bcnn_scales_gpu /
+ * bcnn_grad_scales_gpu (bcnn_mat.cu:393-438); CPU semantics bcnn_mat.c:52-115, 319-412, 761-811.
+ * ------------------------------------------------------------------------------------------- */
+void bcnn_hip_axpy(size_t n, float a, const float *x_d, float *y_d);   /* y += a*x */
+void bcnn_hip_scal(size_t n, float a, float *x_d);                      /* x *= a (a==0 -> zero-fill) */
+void bcnn_hip_copy_f32(size_t n, const float *x_d, float *y_d);
+/* y[b][c][:] += bias[c]; channels whose bias is exactly 0.0f or 1.0f are left untouched, as in
+ * the reference AVX build (bcnn_add_scalar, bcnn_mat.c:366-412). */
+void bcnn_hip_add_bias(float *y_d, const float *bias_d, int n, int c, int hw);
+void bcnn_hip_grad_bias(float *dbias_d, const float *g_d, int n, int c, int hw);  /* dbias[c] += sum */
+void bcnn_hip_scales(float *y_d, const float *scales_d, int n, int c, int hw);
+void bcnn_hip_grad_scales(const float *x_norm_d, const float *g_d, int n, int c, int hw,
+                          float *dscales_d);                                     /* dscales[c] += sum g*x_norm */
+
+/* ---------------------------------------------------------------------------------------------
+ * GEMM / im2col / col2im.  Replaces bcnn_cuda_gemm (bcnn_mat.cu:31-42), bcnn_cuda_im2col (:477-524),
+ * bcnn_cuda_col2im (:526-576); semantics of bcnn_gemm (bcnn_mat.c:2627-2650), bcnn_im2col (:817-854),
+ * bcnn_col2im (:935-970, zero-fills then scatter-adds => OVERWRITES im).
+ * Row-major C[m x n] = alpha * op(A) * op(B) + beta * C on the fp32 MFMA path.
+ * ------------------------------------------------------------------------------------------- */
+void bcnn_hip_gemm(int trans_a, int trans_b, int m, int n, int k, float alpha, const float *a_d,
+                   int lda, const float *b_d, int ldb, float beta, float *c_d, int ldc);
+void bcnn_hip_im2col(const float *im_d, int channels, int height, int width, int ksize, int pad,
+                     int stride, float *col_d);
+void bcnn_hip_col2im(const float *col_d, int channels, int height, int width, int ksize, int pad,
+                     int stride, float *im_d);
+
+/* ---------------------------------------------------------------------------------------------
+ * Activation map.  Replaces bcnn_forward/backward_activation_gpu (bcnn_activation_layer.cu:32-113);
+ * semantics of bcnn_forward_activation_cpu / bcnn_backward_activation_cpu
+ * (bcnn_activation_layer.c:90-146, 165-226), incl. softplus/abs/prelu which the CUDA build lacks.
+ * In place. `slopes_d` (PReLU, one per channel) may be NULL otherwise. Backward uses the
+ * POST-activation values `x_d`; `dslopes_d` accumulates (PReLU only, may be NULL to skip).
+ * ------------------------------------------------------------------------------------------- */
+void bcnn_hip_activation_forward(float *x_d, size_t size, int act, const float *slopes_d,
+                                 int spatial, int channels);
+void bcnn_hip_activation_backward(const float *x_d, float *dx_d, size_t size, int act,
+                                  const float *slopes_d, float *dslopes_d, int spatial, int channels);
+
+/* ---------------------------------------------------------------------------------------------
+ * Batch normalisation.  Replaces bcnn_forward/backward_batchnorm_gpu (bcnn_batchnorm_layer.cu:187-377);
+ * semantics of the CPU path (bcnn_batchnorm_layer.c:196-242, 301-332): biased one-pass variance,
+ * eps 1e-6 forward / 1e-5 backward, running = 0.9*running + 0.1*batch.
+ *   forward : x_d -> y_d (may alias). TRAIN: writes saved_mean/saved_var, updates run_mean/run_var,
+ *             keeps the pre-normalisation input in workspace_d (needed by backward; may alias x_d when
+ *             x_d != y_d) and, if x_norm_d != NULL, the normalised values. VALID: normalises with the
+ *             running statistics. PREDICT: y = x*scale + bias.
+ *   backward: dy_d is transformed IN PLACE into the gradient w.r.t. the BN input (as the reference
+ *             does) and copied to dx_d if dx_d != NULL && dx_d != dy_d; dbias_d/dscales_d accumulate;
+ *             dmean_d/dvar_d (saved_mean.grad / saved_variance.grad) are overwritten.
+ *             x_norm_d may be NULL (recomputed from workspace_d, mean, var).
+ * `act`/`y_d` in backward: optional fused activation-backward (conv+BN+act nodes): pass the
+ * post-activation output and its activation, or act = NONE.
+ * ------------------------------------------------------------------------------------------- */
+void bcnn_hip_batchnorm_forward(const float *x_d, float *y_d, float *run_mean_d, float *run_var_d,
+                                const float *scales_d, const float *bias_d, float *saved_mean_d,
+                                float *saved_var_d, float *x_norm_d, float *workspace_d, int n, int c,
+                                int hw, int mode, int act);
+void bcnn_hip_batchnorm_backward(float *dy_d, float *dx_d, const float *y_d, int act,
+                                 const float *scales_d, float *dscales_d, float *dbias_d,
+                                 const float *saved_mean_d, const float *saved_var_d, float *dmean_d,
+                                 float *dvar_d, const float *x_norm_d, const float *workspace_d, int n,
+                                 int c, int hw);
+
+/* ---------------------------------------------------------------------------------------------
+ * Convolution (implicit GEMM on fp32 MFMA; no materialised im2col buffer).
+ * Replaces bcnn_forward_conv_layer_gpu / bcnn_backward_conv_layer_gpu (bcnn_conv_layer.c:589-792)
+ * with the semantics of the CPU workers (bcnn_conv_layer.c:367-485, 487-587):
+ *   - weights [f][c/groups][k][k], bias [f]; out size (h + 2*pad - k)/stride + 1;
+ *   - 1x1 kernels read the source as a raw [c/groups][oh*ow] matrix regardless of stride/pad (:445-446);
+ *   - forward: y = act(conv + bias) (bias skipped for channels with bias == 0.0f or 1.0f exactly), or
+ *     with batch_norm != 0: y = act(BN(conv)) using the bn_* arguments (see batchnorm_forward);
+ *   - backward: dy_d <- dy_d * act'(y_d) in place; then BN backward or dbias += sum; dw += (beta = 1);
+ *     dx_d (if non-NULL) is OVERWRITTEN (col2im zero-fill semantics); 1x1 writes only the
+ *     [c/groups][oh*ow] prefix of each image-group of dx_d.
+ * workspace_d: scratch of at least bcnn_hip_conv_workspace_size(...) floats (split-K partials of dw;
+ * the reference's per-net conv workspace, bcnn_net.c:337-352, plays the same role).
+ * PReLU slopes: slopes_d (one per output channel), else NULL.
+ * ------------------------------------------------------------------------------------------- */
+size_t bcnn_hip_conv_workspace_size(int n, int c, int h, int w, int f, int k, int stride, int pad,
+                                    int groups);
+void bcnn_hip_conv_forward(const float *x_d, const float *w_d, const float *bias_d, float *y_d, int n,
+                           int c, int h, int w, int f, int k, int stride, int pad, int groups, int act,
+                           const float *slopes_d,
+                           /* fused batch-norm (batch_norm == 0: all NULL) */
+                           int batch_norm, float *run_mean_d, float *run_var_d, const float *scales_d,
+                           float *saved_mean_d, float *saved_var_d, float *x_norm_d,
+                           float *bn_workspace_d, int mode);
+void bcnn_hip_conv_backward(const float *x_d, const float *w_d, const float *y_d, float *dy_d,
+                            float *dx_d, float *dw_d, float *dbias_d, int n, int c, int h, int w, int f,
+                            int k, int stride, int pad, int groups, int act, const float *slopes_d,
+                            float *dslopes_d, int batch_norm, const float *scales_d, float *dscales_d,
+                            const float *saved_mean_d, const float *saved_var_d, float *dmean_d,
+                            float *dvar_d, const float *x_norm_d, const float *bn_workspace_d,
+                            float *workspace_d, size_t workspace_elems);
+
+/* ---------------------------------------------------------------------------------------------
+ * Pooling.  Replaces bcnn_forward/backward_maxpool_layer_gpu (bcnn_maxpool_layer.cu:28-166) and
+ * bcnn_forward/backward_avgpool_layer_gpu (bcnn_avgpool_layer.cu:29-90); CPU semantics
+ * bcnn_maxpool_layer.c:145-191, 258-273 and bcnn_avgpool_layer.c:82-125.
+ *   maxpool: window at (i*stride, j*stride) (bottom/right padding only), rows outer / cols inner,
+ *   first strict maximum wins, NaN never wins, indexes = flat int32 offset into the whole source
+ *   tensor -- BIT-EXACT with the CPU path. backward: dx[indexes[o]] += dy[o], applied in ascending
+ *   output order per source element (deterministic, same order as the CPU loop).
+ *   avgpool: global mean per (n,c); backward dx += dy/(h*w).
+ * ------------------------------------------------------------------------------------------- */
+void bcnn_hip_maxpool_forward(const float *x_d, float *y_d, int *indexes_d, int n, int c, int h, int w,
+                              int out_h, int out_w, int size, int stride);
+void bcnn_hip_maxpool_backward(const float *dy_d, const int *indexes_d, float *dx_d, int n, int c,
+                               int h, int w, int out_h, int out_w, int size, int stride);
+void bcnn_hip_avgpool_forward(const float *x_d, float *y_d, int n, int c, int h, int w);
+void bcnn_hip_avgpool_backward(const float *dy_d, float *dx_d, int n, int c, int h, int w);
+
+/* ---------------------------------------------------------------------------------------------
+ * Depthwise convolution.  Replaces the kernels of bcnn_depthwise_conv_layer.cu:33-200; CPU semantics
+ * bcnn_depthwise_conv_layer.c:165-293, 295-547: weights [c][k][k]; y = act(dwconv + bias);
+ * backward: dy *= act'(y) in place, dbias += ..., and ONLY IF dx_d != NULL: dw += ..., dx += ...
+ * (accumulating, no zero-fill). No unsynchronised `+=` races (the CUDA kernel at :113 has one).
+ * ------------------------------------------------------------------------------------------- */
+void bcnn_hip_depthwise_forward(const float *x_d, const float *w_d, const float *bias_d, float *y_d,
+                                int n, int c, int h, int w, int k, int stride, int pad, int act);
+void bcnn_hip_depthwise_backward(const float *x_d, const float *w_d, const float *y_d, float *dy_d,
+                                 float *dx_d, float *dw_d, float *dbias_d, int n, int c, int h, int w,
+                                 int k, int stride, int pad, int act);
+
+/* ---------------------------------------------------------------------------------------------
+ * SGD step on a parameter arena.  Replaces bcnn_sgd_update_gpu (bcnn_learner.c:86-104); semantics
+ * of bcnn_sgd_update_cpu (:67-83) fused into one pass per buffer:
+ *   b -= (lr/batch)*db; db *= momentum; dw += (decay*batch)*w; w -= (lr/batch)*dw; dw *= momentum.
+ * Either pair may be NULL.
+ * ------------------------------------------------------------------------------------------- */
+void bcnn_hip_sgd_update(float *w_d, float *b_d, float *dw_d, float *db_d, size_t w_size,
+                         size_t b_size, int batch_size, float learning_rate, float momentum,
+                         float decay);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BCNN_HIP_H */

@@ -1,0 +1,38 @@
+"""CPU checks of the drop-in boundary: the C-ABI library builds for gfx950, loads without a GPU and
+exports every symbol include/bcnn_hip.h declares (no compute calls here)."""
+import ctypes
+import os
+
+from bcnn_amd import _lib
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    _lib.build()
+    assert os.path.exists(_lib.LIB_PATH)
+    declared = _lib.declared_symbols()
+    assert len(declared) >= 40
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [s for s in declared if not hasattr(raw, s)]
+    assert not missing, missing
+    # the Python signature table covers the header exactly
+    assert set(declared) == set(_lib.SIGNATURES)
+
+
+def test_no_cpu_fallback_when_library_missing(tmp_path, monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    try:
+        _lib.load()
+    except RuntimeError as e:
+        assert "no CPU fallback" in str(e)
+    else:
+        raise AssertionError("load() must fail loudly without the HIP library")
+
+
+def test_product_does_not_import_oracle():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for dirpath, _, files in os.walk(os.path.join(root, "bcnn_amd")):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".c", ".cpp")):
+                text = open(os.path.join(dirpath, fn), errors="ignore").read()
+                assert "orc_bind" not in text and "bcnn_oracle" not in text and "ref_bind" not in text, fn
