@@ -73,7 +73,7 @@ __device__ __forceinline__ float bn_one(float x, float mean, float rs, float sc,
         else if (sc != 1.0f) v = __fmul_rn(v, sc);
         if (b != 0.0f && b != 1.0f) v = __fadd_rn(v, b);  // bcnn_add_scalar quirk
     }
-    return act_fwd(v, act, 0.f);
+    return act_fwd_cheap(v, act, 0.f);
 }
 
 struct BnApplyBody {
@@ -117,7 +117,7 @@ struct BwdSumsF {
     int act, C, HW;
     __device__ void operator()(long long off, int c, float (&acc)[2]) const {
         float g = dy[off];
-        if (act != BCNN_HIP_ACT_NONE) g *= act_bwd_factor(y[off], act, 0.f);
+        if (act != BCNN_HIP_ACT_NONE) g *= act_bwd_cheap(y[off], act, 0.f);
         acc[0] += g;
         acc[1] += g * (x[off] - mean[c]);
     }
@@ -127,8 +127,8 @@ struct BwdSumsF {
         const float4 xv = *reinterpret_cast<const float4*>(x + off);
         if (act != BCNN_HIP_ACT_NONE) {
             const float4 yv = *reinterpret_cast<const float4*>(y + off);
-            g.x *= act_bwd_factor(yv.x, act, 0.f); g.y *= act_bwd_factor(yv.y, act, 0.f);
-            g.z *= act_bwd_factor(yv.z, act, 0.f); g.w *= act_bwd_factor(yv.w, act, 0.f);
+            g.x *= act_bwd_cheap(yv.x, act, 0.f); g.y *= act_bwd_cheap(yv.y, act, 0.f);
+            g.z *= act_bwd_cheap(yv.z, act, 0.f); g.w *= act_bwd_cheap(yv.w, act, 0.f);
         }
         acc[0] += (g.x + g.y) + (g.z + g.w);
         acc[1] += (g.x * (xv.x - m) + g.y * (xv.y - m)) + (g.z * (xv.z - m) + g.w * (xv.w - m));
@@ -175,7 +175,7 @@ struct BnBwdApplyArgs {
 
 __device__ __forceinline__ float bn_bwd_one(float g, float yv, float xv, float mean, float rs, float sc,
                                             float dm_m, float dv, float fM, int act) {
-    if (act != BCNN_HIP_ACT_NONE) g *= act_bwd_factor(yv, act, 0.f);
+    if (act != BCNN_HIP_ACT_NONE) g *= act_bwd_cheap(yv, act, 0.f);
     if (sc == 0.0f) g = 0.f;
     else if (sc != 1.0f) g = __fmul_rn(g, sc);
     // grad*1.0f/sqrtf(var+1e-5) + dvar*2*(x-mean)/M + dmean/M     (bcnn_batchnorm_layer.c:292-296)
@@ -227,6 +227,8 @@ void bcnn_hip_batchnorm_forward(const float* x, float* y, float* run_mean, float
                                 int mode, int act) {
     const long long M = (long long)n * hw, total = M * c;
     if (!total) return;
+    const int want_act = act;
+    if (!act_is_cheap(act)) act = BCNN_HIP_ACT_NONE;  // tanh/softplus/logistic: separate pass below
     BnApplyArgs a;
     a.x = x; a.y = y; a.ws = workspace; a.xn = x_norm; a.scale = scales; a.bias = bias;
     a.C = c; a.HW = hw; a.act = act; a.total = total;
@@ -245,6 +247,7 @@ void bcnn_hip_batchnorm_forward(const float* x, float* y, float* run_mean, float
     }
     auto al16 = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     launch_chan_map(BnApplyBody{a, al16(x) && al16(y) && al16(a.ws) && al16(a.xn)}, n, c, hw);
+    if (want_act != act) bcnn_hip_activation_forward(y, (size_t)total, want_act, nullptr, hw, c);
 }
 
 void bcnn_hip_batchnorm_backward(float* dy, float* dx, const float* y, int act, const float* scales,
@@ -254,6 +257,10 @@ void bcnn_hip_batchnorm_backward(float* dy, float* dx, const float* y, int act, 
     (void)x_norm;  // recomputed from workspace/mean/var: saves a full-tensor read (and its write in forward)
     const long long M = (long long)n * hw, total = M * c;
     if (!total) return;
+    if (!act_bwd_is_cheap(act)) {  // softplus: its derivative needs exp() -> separate in-place pass first
+        bcnn_hip_activation_backward(y, dy, (size_t)total, act, nullptr, nullptr, hw, c);
+        act = BCNN_HIP_ACT_NONE;
+    }
     const int splits = chan_splits(c, M);
     float* part = reduce_scratch((size_t)c * splits * 2);
     BwdSumsF f;

@@ -91,6 +91,38 @@ __device__ __forceinline__ float act_fwd(float x, int act, float slope) {
     }
 }
 
+// Activations cheap enough to fuse into a producer's epilogue (no double-precision exp/log). The
+// other three (tanh, softplus, logistic) run as a separate in-place pass (activation.hip) so that
+// the MFMA kernels keep their register budget.
+__host__ __device__ __forceinline__ bool act_is_cheap(int act) {
+    return act != BCNN_HIP_ACT_TANH && act != BCNN_HIP_ACT_SOFTPLUS && act != BCNN_HIP_ACT_LOGISTIC;
+}
+__device__ __forceinline__ float act_fwd_cheap(float x, int act, float slope) {
+    switch (act) {
+        case BCNN_HIP_ACT_RELU: return x * (float)(x > 0);
+        case BCNN_HIP_ACT_LRELU: return x > 0 ? x : 0.1f * x;
+        case BCNN_HIP_ACT_RAMP: return x * (float)(x > 0) + 0.1f * x;
+        case BCNN_HIP_ACT_ABS: return fabsf(x);
+        case BCNN_HIP_ACT_CLAMP: return (x < 0) ? 0.f : ((x > 1) ? 1.f : x);
+        case BCNN_HIP_ACT_PRELU: return x > 0 ? x : slope * x;
+        default: return x;
+    }
+}
+__device__ __forceinline__ float act_bwd_cheap(float y, int act, float slope) {
+    switch (act) {
+        case BCNN_HIP_ACT_TANH: return 1 - y * y;
+        case BCNN_HIP_ACT_RELU: return (float)(y > 0);
+        case BCNN_HIP_ACT_LRELU: return y > 0 ? 1.0f : 0.1f;
+        case BCNN_HIP_ACT_RAMP: return (float)(y > 0) + 0.1f;
+        case BCNN_HIP_ACT_ABS: return y >= 0 ? 1.0f : -1.0f;
+        case BCNN_HIP_ACT_CLAMP: return (float)(y > 0.0f && y < 1.0f);
+        case BCNN_HIP_ACT_LOGISTIC: return (1 - y) * y;
+        case BCNN_HIP_ACT_PRELU: return y > 0 ? 1.0f : slope;
+        default: return 1.0f;
+    }
+}
+__host__ __device__ __forceinline__ bool act_bwd_is_cheap(int act) { return act != BCNN_HIP_ACT_SOFTPLUS; }
+
 // derivative factor from the POST-activation value, bcnn_activation_layer.c:165-226
 __device__ __forceinline__ float act_bwd_factor(float y, int act, float slope) {
     switch (act) {

@@ -10,6 +10,18 @@ size_t conv_dw_workspace_floats(const ConvShape& s);
 bool conv_backward_weights(const float* x, const float* dy, float* dw, float* dbias, const ConvShape& s,
                            float* workspace, size_t workspace_floats, bool want_bias);
 void conv_backward_data(const float* w, const float* dy, float* dx, const ConvShape& s);
+// conv_direct.hip: LDS-free kernels for small reduction lengths (K <= 32)
+bool conv_forward_direct(const float* x, const float* w, const float* bias, const float* slopes, float* y,
+                         const ConvShape& s, int act, int raw);
+size_t conv_dw_direct_workspace_floats(const ConvShape& s);
+bool conv_backward_weights_direct(const float* x, const float* dy, float* dw, float* dbias, const ConvShape& s,
+                                  float* workspace, size_t workspace_floats);
+
+static void conv_fwd_any(const float* x, const float* w, const float* bias, const float* slopes, float* y,
+                         const ConvShape& s, int act, int raw) {
+    if (!conv_forward_direct(x, w, bias, slopes, y, s, act, raw))
+        conv_forward_dispatch(x, w, bias, slopes, y, s, act, raw);
+}
 }  // namespace bcnn_hip
 
 using namespace bcnn_hip;
@@ -17,7 +29,9 @@ using namespace bcnn_hip;
 extern "C" {
 
 size_t bcnn_hip_conv_workspace_size(int n, int c, int h, int w, int f, int k, int stride, int pad, int groups) {
-    return conv_dw_workspace_floats(make_conv_shape(n, c, h, w, f, k, stride, pad, groups));
+    const ConvShape s = make_conv_shape(n, c, h, w, f, k, stride, pad, groups);
+    const size_t a = conv_dw_workspace_floats(s), b = conv_dw_direct_workspace_floats(s);
+    return a > b ? a : b;
 }
 
 void bcnn_hip_conv_forward(const float* x, const float* w, const float* bias, float* y, int n, int c, int h,
@@ -26,12 +40,17 @@ void bcnn_hip_conv_forward(const float* x, const float* w, const float* bias, fl
                            float* saved_mean, float* saved_var, float* x_norm, float* bn_workspace, int mode) {
     const ConvShape s = make_conv_shape(n, c, h, wd, f, k, stride, pad, groups);
     if (!batch_norm) {
-        conv_forward_dispatch(x, w, bias, slopes, y, s, act, /*raw=*/0);
+        if (act_is_cheap(act)) {
+            conv_fwd_any(x, w, bias, slopes, y, s, act, /*raw=*/0);
+        } else {  // tanh / softplus / logistic: bias in the epilogue, activation as a second in-place pass
+            conv_fwd_any(x, w, bias, slopes, y, s, BCNN_HIP_ACT_NONE, /*raw=*/0);
+            bcnn_hip_activation_forward(y, (size_t)n * f * s.OHOW, act, slopes, s.OHOW, f);
+        }
         return;
     }
     // conv -> (pre-normalisation values, kept for backward) -> statistics -> normalise+scale+bias+act
     float* raw = (bn_workspace && mode != BCNN_HIP_MODE_PREDICT) ? bn_workspace : y;
-    conv_forward_dispatch(x, w, nullptr, nullptr, raw, s, BCNN_HIP_ACT_NONE, /*raw=*/1);
+    conv_fwd_any(x, w, nullptr, nullptr, raw, s, BCNN_HIP_ACT_NONE, /*raw=*/1);
     const int fused_act = (act == BCNN_HIP_ACT_PRELU) ? BCNN_HIP_ACT_NONE : act;
     bcnn_hip_batchnorm_forward(raw, y, run_mean, run_var, scales, bias, saved_mean, saved_var, x_norm, raw, n, f,
                                s.OHOW, mode, fused_act);
@@ -58,8 +77,12 @@ void bcnn_hip_conv_backward(const float* x, const float* w, const float* y, floa
     } else {
         bcnn_hip_activation_backward(y, dy, ysize, act, slopes, dslopes, s.OHOW, f);
     }
-    const bool bias_done = conv_backward_weights(x, dy, dw, dbias, s, workspace, workspace_elems,
-                                                 /*want_bias=*/!batch_norm);
+    bool bias_done;
+    if (conv_backward_weights_direct(x, dy, dw, batch_norm ? nullptr : dbias, s, workspace, workspace_elems))
+        bias_done = true;
+    else
+        bias_done = conv_backward_weights(x, dy, dw, dbias, s, workspace, workspace_elems,
+                                          /*want_bias=*/!batch_norm);
     if (!batch_norm && !bias_done) bcnn_hip_grad_bias(dbias, dy, n, f, s.OHOW);
     if (dx) conv_backward_data(w, dy, dx, s);
 }

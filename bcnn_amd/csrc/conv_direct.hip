@@ -1,0 +1,442 @@
+// conv_direct.hip -- LDS-free implicit-GEMM kernels for convolutions with a SMALL reduction length
+// (K = C/g*k*k <= 32, e.g. the 3x3 stem of BASELINE configs[1]: 3 -> 64 channels at 224x224).
+//
+// For such layers the GEMM is HBM-bound (arithmetic intensity 12.9 FLOP/B at configs[1]), so the
+// kernels are built to touch every activation byte exactly once and to spend as few issue slots as
+// possible next to the MFMAs:
+//   forward : the weight matrix lives in MFMA A-operand REGISTERS for the lifetime of a (persistent)
+//             wave; each B operand (one im2col element per lane: lane&31 = output pixel, lane>>5 picks
+//             the k of the pair) is loaded straight from global memory in fragment order -- a wave
+//             load instruction reads two 128-byte runs of consecutive pixels; the input (77 MB) is
+//             served by L1/L2/MALL. No LDS staging, no barriers, no materialised im2col.
+//   dW      : the reduction runs over output pixels q. The MFMA reduction index is free to be
+//             permuted, so step s pairs q0+s (lanes 0-31) with q0+8+s (lanes 32-63): every lane's
+//             eight A values (dy, lane&31 = output channel) and eight B values (x taps, lane&31 = k)
+//             are then 32 CONTIGUOUS bytes => two 16-byte loads per operand per 16 output pixels.
+//             A 29th all-ones im2col column yields the bias gradient in the same pass.
+// Reference semantics as in conv_fwd.hip / conv_bwd.hip (bcnn_conv_layer.c:367-587).
+#include "conv_common.h"
+
+namespace bcnn_hip {
+
+struct f4u { float x, y, z, w; } __attribute__((packed, aligned(4)));  // 16-byte load, 4-byte aligned
+
+// ================================================================================================
+// forward
+// ================================================================================================
+struct ConvDirectFwdArgs {
+    const float* x;
+    const float* w;
+    const float* bias;
+    const float* slopes;
+    float* y;
+    ConvShape s;
+    int act, add_bias;
+    int ntiles;        // ceil(total_q / 32)
+    int tiles_per_block;
+};
+
+template <int TM, int KS>  // TM 32-row tiles of output channels, KS = ceil(K/2) MFMA steps
+__global__ __launch_bounds__(256) void conv_fwd_direct_kernel(const ConvDirectFwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float sbias[TM * 32];
+    const ConvShape& s = a.s;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int g = blockIdx.y;
+    const float* wg = a.w + (long long)g * s.Mg * s.K;
+
+    // stage the (quirk-adjusted) bias of this group's channels once
+    if (tid < TM * 32) {
+        float b = 0.f;
+        if (a.add_bias && tid < s.Mg) {
+            b = a.bias[g * s.Mg + tid];
+            if (b == 1.0f) b = 0.f;  // bcnn_add_scalar (AVX build) adds nothing for exactly 1.0f
+        }
+        sbias[tid] = b;
+    }
+
+    // A operand: W[f = tm*32 + l31][k = 2*st + hi], resident in registers for the whole kernel.
+    // Per step the lane also keeps the byte offset of its tap (c*HW + kr*W + kc) and the tap's bit
+    // index kr*ksz + kc in the per-pixel validity mask (4 indices packed per register).
+    float areg[TM][KS];
+    int koffb[KS];
+    unsigned tapbits[(KS + 3) / 4];
+#pragma unroll
+    for (int i = 0; i < (KS + 3) / 4; ++i) tapbits[i] = 0;
+    const int kk2 = s.ksz * s.ksz;
+#pragma unroll
+    for (int st = 0; st < KS; ++st) {
+        const int k = 2 * st + hi;
+        const bool kv = k < s.K;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const int f = tm * 32 + l31;
+            areg[tm][st] = (kv && f < s.Mg) ? wg[(long long)f * s.K + k] : 0.f;
+        }
+        int tap = 31;  // bit 31 of the mask is never set => zero operand
+        koffb[st] = 0;
+        if (kv) {
+            const int c = k / kk2, r = k - c * kk2;
+            const int kr = r / s.ksz, kc = r - kr * s.ksz;
+            koffb[st] = (c * s.HW + kr * s.W + kc) * 4;
+            tap = r;
+        }
+        tapbits[st >> 2] |= (unsigned)tap << (8 * (st & 3));
+    }
+    __syncthreads();
+
+    const char* xbytes = reinterpret_cast<const char*>(a.x);  // wave-uniform base: loads use base + 32-bit offset
+    char* ybytes = reinterpret_cast<char*>(a.y);
+    const unsigned xg_off = (unsigned)(g * s.Cg) * (unsigned)s.HW;
+    const int t_begin = blockIdx.x * a.tiles_per_block;
+    int t_end = t_begin + a.tiles_per_block;
+    if (t_end > a.ntiles) t_end = a.ntiles;
+    const bool full_m = (s.Mg == TM * 32);
+    const unsigned fstride = (unsigned)s.OHOW * 4u;
+
+    // B fragments of one 32-pixel tile, loaded straight into MFMA operand order (unconditional loads
+    // from an always-legal address + select: no exec-mask branches around the loads)
+    float bnext[KS];
+    unsigned ynext = 0;   // byte offset of y[n][g*Mg][pix] for this lane's pixel
+    bool qvnext = false;
+    auto prefetch = [&](int t) {
+        const unsigned q = (unsigned)t * 32u + (unsigned)l31;
+        const bool qv = q < (unsigned)s.total_q;
+        const unsigned qq = qv ? q : 0u;
+        const unsigned n = qq / (unsigned)s.OHOW, pix = qq - n * (unsigned)s.OHOW;
+        const unsigned oh = pix / (unsigned)s.OW, ow = pix - oh * (unsigned)s.OW;
+        const int ih0 = (int)oh * s.stride - s.pad, iw0 = (int)ow * s.stride - s.pad;
+        unsigned colm = 0, mask = 0;  // validity of the ksz*ksz taps of this pixel (bit kr*ksz + kc)
+#pragma unroll
+        for (int kc = 0; kc < 5; ++kc)
+            if (kc < s.ksz && (unsigned)(iw0 + kc) < (unsigned)s.W) colm |= 1u << kc;
+#pragma unroll
+        for (int kr = 0; kr < 5; ++kr)
+            if (kr < s.ksz && (unsigned)(ih0 + kr) < (unsigned)s.H) mask |= colm << (kr * s.ksz);
+        if (!qv) mask = 0;
+        const unsigned pixb = ((n * (unsigned)s.C) * (unsigned)s.HW + xg_off + (unsigned)(ih0 * s.W + iw0)) * 4u;
+#pragma unroll
+        for (int st = 0; st < KS; ++st) {
+            const unsigned tap = (tapbits[st >> 2] >> (8 * (st & 3))) & 0xffu;
+            const bool ok = (mask >> tap) & 1u;
+            const unsigned off = ok ? pixb + (unsigned)koffb[st] : 0u;
+            const float v = *reinterpret_cast<const float*>(xbytes + off);
+            bnext[st] = ok ? v : 0.f;
+        }
+        ynext = ((n * (unsigned)s.F + (unsigned)(g * s.Mg)) * (unsigned)s.OHOW + pix) * 4u;
+        qvnext = qv;
+    };
+
+    int t = t_begin + wid;
+    if (t < t_end) prefetch(t);
+    for (; t < t_end; t += 4) {
+        float bfrag[KS];
+#pragma unroll
+        for (int st = 0; st < KS; ++st) bfrag[st] = bnext[st];
+        const unsigned ybase = ynext;
+        const bool qv = qvnext;
+        if (t + 4 < t_end) prefetch(t + 4);  // next tile's loads fly under this tile's MFMAs and stores
+
+        f32x16 acc[TM];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][r] = 0.f;
+#pragma unroll
+        for (int st = 0; st < KS; ++st)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) acc[tm] = mfma32(areg[tm][st], bfrag[st], acc[tm]);
+
+        // epilogue on the accumulators: + bias, activation, one store per element.
+        // y[n][g*Mg + f][pix], f = tm*32 + (r&3) + 8*(r>>2) + 4*hi: registers r..r+3 are 4 consecutive channels
+        float v[TM][16];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const float4 b4 = *reinterpret_cast<const float4*>(&sbias[tm * 32 + 8 * rq + 4 * hi]);
+                v[tm][rq * 4 + 0] = acc[tm][rq * 4 + 0] + b4.x;
+                v[tm][rq * 4 + 1] = acc[tm][rq * 4 + 1] + b4.y;
+                v[tm][rq * 4 + 2] = acc[tm][rq * 4 + 2] + b4.z;
+                v[tm][rq * 4 + 3] = acc[tm][rq * 4 + 3] + b4.w;
+            }
+        if (a.act != BCNN_HIP_ACT_NONE) {
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int f = tm * 32 + mfma_row(r, lane);
+                    const float sl = (a.act == BCNN_HIP_ACT_PRELU && f < s.Mg) ? a.slopes[g * s.Mg + f] : 0.f;
+                    v[tm][r] = act_fwd_cheap(v[tm][r], a.act, sl);
+                }
+        }
+        if (qv) {
+            if (full_m) {
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const unsigned f = (unsigned)(tm * 32 + (r & 3) + 8 * (r >> 2)) + 4u * (unsigned)hi;
+                        *reinterpret_cast<float*>(ybytes + (ybase + f * fstride)) = v[tm][r];
+                    }
+            } else {
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const unsigned f = (unsigned)(tm * 32 + (r & 3) + 8 * (r >> 2)) + 4u * (unsigned)hi;
+                        if (f < (unsigned)s.Mg) *reinterpret_cast<float*>(ybytes + (ybase + f * fstride)) = v[tm][r];
+                    }
+            }
+        }
+    }
+}
+
+bool conv_forward_direct(const float* x, const float* w, const float* bias, const float* slopes, float* y,
+                         const ConvShape& s, int act, int raw) {
+    if (s.pointwise || s.K > 32 || s.Mg > 64 || s.total_q == 0) return false;
+    if ((long long)s.N * s.F * s.OHOW >= (1LL << 30) || (long long)s.N * s.C * s.HW >= (1LL << 30) || s.ksz > 5) return false;
+    ConvDirectFwdArgs a;
+    a.x = x; a.w = w; a.bias = bias; a.slopes = slopes; a.y = y; a.s = s;
+    a.act = raw ? BCNN_HIP_ACT_NONE : act;
+    a.add_bias = raw ? 0 : 1;
+    a.ntiles = ceil_div(s.total_q, 32);
+    // persistent-ish: ~8 workgroups per CU, each walking a contiguous run of tiles (its 4 waves share rows)
+    int blocks = kCUs * 8;
+    a.tiles_per_block = ceil_div(a.ntiles, blocks);
+    if (a.tiles_per_block < 4) a.tiles_per_block = 4;
+    blocks = ceil_div(a.ntiles, a.tiles_per_block);
+    dim3 grid((unsigned)blocks, (unsigned)s.groups);
+    const int ks = (s.K + 1) / 2;
+    const int tm = (s.Mg <= 32) ? 1 : 2;
+#define LAUNCH(TMv, KSv) conv_fwd_direct_kernel<TMv, KSv><<<grid, 256, 0, current_stream()>>>(a)
+    if (tm == 1) {
+        if (ks <= 5) LAUNCH(1, 5); else if (ks <= 9) LAUNCH(1, 9); else if (ks <= 14) LAUNCH(1, 14); else LAUNCH(1, 16);
+    } else {
+        if (ks <= 5) LAUNCH(2, 5); else if (ks <= 9) LAUNCH(2, 9); else if (ks <= 14) LAUNCH(2, 14); else LAUNCH(2, 16);
+    }
+#undef LAUNCH
+    KERNEL_CHECK();
+    return true;
+}
+
+// ================================================================================================
+// dW (+ bias gradient)
+// ================================================================================================
+struct ConvDirectDwArgs {
+    const float* x;
+    const float* dy;
+    float* partials;  // [nblocks][groups][TM*32][32]
+    ConvShape s;
+    int nwin;         // N*OH*(OW/16) windows of 16 consecutive output pixels
+    int win_per_block;
+    int bias_col;
+};
+
+template <int TM>
+struct DwFrag {
+    float4 a[TM][2];  // dy[f][q0 + 8*hi .. +7]
+    float4 b[2];      // im2col column k at the same 8 output pixels
+};
+
+// Loads one 16-pixel window's MFMA fragments. Every load is unconditional from an always-legal
+// address; padding / out-of-range lanes are zeroed with selects (no exec-mask branches, no scratch).
+template <int TM>
+__device__ __forceinline__ DwFrag<TM> dw_load_window(const ConvDirectDwArgs& a, int wdx, int wpr, int g, int l31,
+                                                     int hi, int koff, int kr, int kc, bool ones, bool kvalid) {
+    const ConvShape& s = a.s;
+    DwFrag<TM> fr;
+    const unsigned row = (unsigned)wdx / (unsigned)wpr;  // n*OH + oh
+    const int ow_base = (int)((unsigned)wdx - row * (unsigned)wpr) * 16;
+    const int ow0 = ow_base + 8 * hi;
+    const unsigned n = row / (unsigned)s.OH, oh = row - n * (unsigned)s.OH;
+    const float* gp = a.dy + ((long long)(n * (unsigned)s.F + (unsigned)(g * s.Mg)) * s.OHOW + (long long)(oh * s.OW + ow0));
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const int f = tm * 32 + l31;
+        const bool fv = f < s.Mg;
+        const float4* p = reinterpret_cast<const float4*>(gp + (long long)(fv ? f : 0) * s.OHOW);
+        float4 v0 = p[0], v1 = p[1];
+        if (!fv) { v0 = make_float4(0.f, 0.f, 0.f, 0.f); v1 = v0; }
+        fr.a[tm][0] = v0;
+        fr.a[tm][1] = v1;
+    }
+    const int ih = (int)oh - s.pad + kr;
+    const bool rowok = kvalid && (unsigned)ih < (unsigned)s.H;
+    const int iw = ow0 - s.pad + kc;
+    const float* xrow = a.x + ((long long)(n * (unsigned)s.C + (unsigned)(g * s.Cg)) * s.HW +
+                               (long long)(koff + ((int)oh - s.pad) * s.W + (ow0 - s.pad)));
+    const bool edge = (ow_base == 0) || (ow_base + 16 >= s.OW);  // wave-uniform
+    float t0, t1, t2, t3, t4, t5, t6, t7;
+    if (!edge) {
+        const float* p = rowok ? xrow : a.x;
+        const f4u v0 = *reinterpret_cast<const f4u*>(p);
+        const f4u v1 = *reinterpret_cast<const f4u*>(p + 4);
+        t0 = v0.x; t1 = v0.y; t2 = v0.z; t3 = v0.w; t4 = v1.x; t5 = v1.y; t6 = v1.z; t7 = v1.w;
+        if (!rowok) { t0 = t1 = t2 = t3 = t4 = t5 = t6 = t7 = 0.f; }
+    } else {
+#define DW_EDGE_LOAD(E, T)                                                     \
+        {                                                                      \
+            const bool ok = rowok && (unsigned)(iw + E) < (unsigned)s.W;       \
+            const float v = *(ok ? xrow + E : a.x);                            \
+            T = ok ? v : 0.f;                                                  \
+        }
+        DW_EDGE_LOAD(0, t0) DW_EDGE_LOAD(1, t1) DW_EDGE_LOAD(2, t2) DW_EDGE_LOAD(3, t3)
+        DW_EDGE_LOAD(4, t4) DW_EDGE_LOAD(5, t5) DW_EDGE_LOAD(6, t6) DW_EDGE_LOAD(7, t7)
+#undef DW_EDGE_LOAD
+    }
+    if (ones) { t0 = t1 = t2 = t3 = t4 = t5 = t6 = t7 = 1.0f; }
+    fr.b[0] = make_float4(t0, t1, t2, t3);
+    fr.b[1] = make_float4(t4, t5, t6, t7);
+    return fr;
+}
+
+template <int TM>
+__global__ __launch_bounds__(256) void conv_dw_direct_kernel(const ConvDirectDwArgs a) {
+    __shared__ float red[3][TM * 32][33];
+    const ConvShape& s = a.s;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int g = blockIdx.y;
+    const int wpr = s.OW >> 4;  // windows per output row
+
+    // this lane's im2col column k = l31
+    int koff = 0, kr = 0, kc = 0;
+    bool ones = false, kvalid = false;
+    if (l31 < s.K) {
+        const int kk2 = s.ksz * s.ksz;
+        const int c = l31 / kk2, r = l31 - c * kk2;
+        kr = r / s.ksz; kc = r - kr * s.ksz;
+        koff = c * s.HW + kr * s.W + kc;
+        kvalid = true;
+    } else if (l31 == s.K && a.bias_col) {
+        ones = true;
+    }
+
+    f32x16 acc[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tm][r] = 0.f;
+
+    const int w_begin = blockIdx.x * a.win_per_block;
+    int w_end = w_begin + a.win_per_block;
+    if (w_end > a.nwin) w_end = a.nwin;
+
+    int wdx = w_begin + wid;
+    DwFrag<TM> nxt;
+    if (wdx < w_end) nxt = dw_load_window<TM>(a, wdx, wpr, g, l31, hi, koff, kr, kc, ones, kvalid);
+    for (; wdx < w_end; wdx += 4) {
+        const DwFrag<TM> cur = nxt;
+        if (wdx + 4 < w_end)  // next window's loads fly under the 8*TM MFMAs below
+            nxt = dw_load_window<TM>(a, wdx + 4, wpr, g, l31, hi, koff, kr, kc, ones, kvalid);
+#define DW_STEP(AV, BV)                                                        \
+        _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) acc[tm] = mfma32(cur.a[tm]AV, cur.b BV, acc[tm]);
+        DW_STEP([0].x, [0].x) DW_STEP([0].y, [0].y) DW_STEP([0].z, [0].z) DW_STEP([0].w, [0].w)
+        DW_STEP([1].x, [1].x) DW_STEP([1].y, [1].y) DW_STEP([1].z, [1].z) DW_STEP([1].w, [1].w)
+#undef DW_STEP
+    }
+
+    // cross-wave reduction (waves 1..3 -> LDS -> wave 0), then one partial tile per workgroup
+    if (wid > 0) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[wid - 1][tm * 32 + mfma_row(r, lane)][l31] = acc[tm][r];
+    }
+    __syncthreads();
+    if (wid == 0) {
+        float* out = a.partials + ((size_t)blockIdx.x * s.groups + g) * (TM * 32) * 32;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int f = tm * 32 + mfma_row(r, lane);
+                out[f * 32 + l31] = ((acc[tm][r] + red[0][f][l31]) + red[1][f][l31]) + red[2][f][l31];
+            }
+    }
+}
+
+// dW[g][f][k] += sum_p partials[p][g][f][k] (k < K), dbias[g*Mg + f] += column K. One workgroup per 16
+// output elements, 16 partial-lanes each, fixed summation order.
+__global__ __launch_bounds__(256) void conv_dw_direct_finalize_kernel(const float* __restrict__ partials,
+                                                                      int nparts, int groups, int Mg, int K,
+                                                                      int MP, int bias_col,
+                                                                      float* __restrict__ dw,
+                                                                      float* __restrict__ dbias) {
+    __shared__ float red[16][17];
+    const int kcols = K + (bias_col ? 1 : 0);
+    const int total = groups * Mg * kcols;
+    const int e = blockIdx.x * 16 + (threadIdx.x & 15), pl = threadIdx.x >> 4;
+    float sum = 0.f;
+    int g = 0, f = 0, k = 0;
+    if (e < total) {
+        k = e % kcols;
+        const int t = e / kcols;
+        f = t % Mg; g = t / Mg;
+        for (int p = pl; p < nparts; p += 16) sum += partials[(((size_t)p * groups + g) * MP + f) * 32 + k];
+    }
+    red[pl][threadIdx.x & 15] = sum;
+    __syncthreads();
+    if (pl == 0 && e < total) {
+        float tot = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tot += red[i][threadIdx.x & 15];
+        if (k < K) dw[((size_t)g * Mg + f) * K + k] += tot;
+        else dbias[g * Mg + f] += tot;
+    }
+}
+
+static bool dw_direct_ok(const ConvShape& s) {
+    return !s.pointwise && s.K < 32 && s.Mg <= 64 && s.stride == 1 && (s.OW % 16) == 0 && s.total_q > 0 &&
+           (long long)s.N * s.F * s.OHOW < (1LL << 32) && (long long)s.N * s.C * s.HW < (1LL << 32) &&
+           s.H < 0x4000;
+}
+
+static void dw_direct_plan(const ConvShape& s, int* nwin, int* wpb, int* blocks) {
+    *nwin = s.N * s.OH * (s.OW / 16);
+    int b = kCUs * 4;
+    int per = ceil_div(*nwin, b);
+    if (per < 16) per = 16;
+    *wpb = per;
+    *blocks = ceil_div(*nwin, per);
+}
+
+size_t conv_dw_direct_workspace_floats(const ConvShape& s) {
+    if (!dw_direct_ok(s)) return 0;
+    int nwin, wpb, blocks;
+    dw_direct_plan(s, &nwin, &wpb, &blocks);
+    const int tm = (s.Mg <= 32) ? 1 : 2;
+    return (size_t)blocks * s.groups * tm * 32 * 32;
+}
+
+// returns false when the shape is not covered (caller falls back to the LDS-tiled kernel);
+// when it returns true the bias gradient has been accumulated too (if dbias != NULL).
+bool conv_backward_weights_direct(const float* x, const float* dy, float* dw, float* dbias, const ConvShape& s,
+                                  float* workspace, size_t workspace_floats) {
+    if (!dw_direct_ok(s)) return false;
+    if ((reinterpret_cast<uintptr_t>(dy) & 15) != 0) return false;
+    int nwin, wpb, blocks;
+    dw_direct_plan(s, &nwin, &wpb, &blocks);
+    const int tm = (s.Mg <= 32) ? 1 : 2;
+    const size_t need = (size_t)blocks * s.groups * tm * 32 * 32;
+    if (workspace == nullptr || workspace_floats < need) {
+        fprintf(stderr, "[bcnn_hip] conv backward: workspace too small (%zu floats given, %zu needed)\n",
+                workspace_floats, need);
+        exit(1);
+    }
+    ConvDirectDwArgs a;
+    a.x = x; a.dy = dy; a.partials = workspace; a.s = s; a.nwin = nwin; a.win_per_block = wpb;
+    a.bias_col = dbias ? 1 : 0;
+    dim3 grid((unsigned)blocks, (unsigned)s.groups);
+    if (tm == 1) conv_dw_direct_kernel<1><<<grid, 256, 0, current_stream()>>>(a);
+    else conv_dw_direct_kernel<2><<<grid, 256, 0, current_stream()>>>(a);
+    KERNEL_CHECK();
+    const int total = s.groups * s.Mg * (s.K + a.bias_col);
+    conv_dw_direct_finalize_kernel<<<ceil_div(total, 16), 256, 0, current_stream()>>>(
+        workspace, blocks, s.groups, s.Mg, s.K, tm * 32, a.bias_col, dw, dbias);
+    KERNEL_CHECK();
+    return true;
+}
+
+}  // namespace bcnn_hip

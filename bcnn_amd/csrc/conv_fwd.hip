@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void conv_fwd_igemm(const ConvFwdArgs a) {
                     if (b != 0.0f && b != 1.0f) v += b;
                 }
                 if (a.act != BCNN_HIP_ACT_NONE)
-                    v = act_fwd(v, a.act, a.act == BCNN_HIP_ACT_PRELU ? a.slopes[fc] : 0.f);
+                    v = act_fwd_cheap(v, a.act, a.act == BCNN_HIP_ACT_PRELU ? a.slopes[fc] : 0.f);
                 yb[(long long)f * s.OHOW] = v;
             }
         }

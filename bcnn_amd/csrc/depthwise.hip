@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ x
         }
         const float b = bias[c];
         if (b != 0.0f && b != 1.0f) val += b;
-        y[o] = act_fwd(val, act, 0.f);
+        y[o] = act_fwd_cheap(val, act, 0.f);
     }
 }
 
@@ -159,9 +159,11 @@ void bcnn_hip_depthwise_forward(const float* x, const float* w, const float* bia
     DwShape s{n, c, h, wd, (h + 2 * pad - k) / stride + 1, (wd + 2 * pad - k) / stride + 1, k, stride, pad};
     const long long total = (long long)n * c * s.OH * s.OW;
     if (total <= 0) return;
-    dw_fwd_kernel<<<stream_grid((size_t)total, 256), 256, 0, current_stream()>>>(x, w, bias, y, s, act,
+    const int fused = act_is_cheap(act) ? act : BCNN_HIP_ACT_NONE;
+    dw_fwd_kernel<<<stream_grid((size_t)total, 256), 256, 0, current_stream()>>>(x, w, bias, y, s, fused,
                                                                                (unsigned)total);
     KERNEL_CHECK();
+    if (fused != act) bcnn_hip_activation_forward(y, (size_t)total, act, nullptr, s.OH * s.OW, c);
 }
 
 void bcnn_hip_depthwise_backward(const float* x, const float* w, const float* y, float* dy, float* dx,
