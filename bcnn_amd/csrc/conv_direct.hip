@@ -36,16 +36,23 @@ struct ConvDirectFwdArgs {
     int tiles_per_block;
 };
 
-template <int TM, int KS>  // TM 32-row tiles of output channels, KS = ceil(K/2) MFMA steps
+// TM: 32-row tiles of output channels; KS = ceil(K/2) MFMA steps; KSZ: kernel size (compile-time, so
+// that the tap of every (step, lane-half) is a constant and its offset is scalar arithmetic).
+// Loads and stores go through buffer descriptors: an out-of-range offset reads 0 / drops the store,
+// which implements zero padding and ragged edges without exec-mask branches or post-load selects.
+template <int TM, int KS, int KSZ>
 __global__ __launch_bounds__(256) void conv_fwd_direct_kernel(const ConvDirectFwdArgs a) {
     __shared__ __attribute__((aligned(16))) float sbias[TM * 32];
     const ConvShape& s = a.s;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform
     const int l31 = lane & 31, hi = lane >> 5;
     const int g = blockIdx.y;
     const float* wg = a.w + (long long)g * s.Mg * s.K;
+    constexpr int KK2 = KSZ * KSZ;
+    constexpr unsigned FULL = (1u << KK2) - 1u;
+    constexpr unsigned OOB = 0x80000000u;  // >= num_records of both descriptors (tensors < 2 GiB)
 
-    // stage the (quirk-adjusted) bias of this group's channels once
     if (tid < TM * 32) {
         float b = 0.f;
         if (a.add_bias && tid < s.Mg) {
@@ -54,39 +61,23 @@ __global__ __launch_bounds__(256) void conv_fwd_direct_kernel(const ConvDirectFw
         }
         sbias[tid] = b;
     }
-
-    // A operand: W[f = tm*32 + l31][k = 2*st + hi], resident in registers for the whole kernel.
-    // Per step the lane also keeps the byte offset of its tap (c*HW + kr*W + kc) and the tap's bit
-    // index kr*ksz + kc in the per-pixel validity mask (4 indices packed per register).
+    // A operand: W[f = tm*32 + l31][k = 2*st + hi], resident in registers for the whole kernel
     float areg[TM][KS];
-    int koffb[KS];
-    unsigned tapbits[(KS + 3) / 4];
-#pragma unroll
-    for (int i = 0; i < (KS + 3) / 4; ++i) tapbits[i] = 0;
-    const int kk2 = s.ksz * s.ksz;
 #pragma unroll
     for (int st = 0; st < KS; ++st) {
         const int k = 2 * st + hi;
-        const bool kv = k < s.K;
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
             const int f = tm * 32 + l31;
-            areg[tm][st] = (kv && f < s.Mg) ? wg[(long long)f * s.K + k] : 0.f;
+            const bool ok = (k < s.K) && (f < s.Mg);
+            const float v = wg[ok ? (long long)f * s.K + k : 0];
+            areg[tm][st] = ok ? v : 0.f;
         }
-        int tap = 31;  // bit 31 of the mask is never set => zero operand
-        koffb[st] = 0;
-        if (kv) {
-            const int c = k / kk2, r = k - c * kk2;
-            const int kr = r / s.ksz, kc = r - kr * s.ksz;
-            koffb[st] = (c * s.HW + kr * s.W + kc) * 4;
-            tap = r;
-        }
-        tapbits[st >> 2] |= (unsigned)tap << (8 * (st & 3));
     }
     __syncthreads();
 
-    const char* xbytes = reinterpret_cast<const char*>(a.x);  // wave-uniform base: loads use base + 32-bit offset
-    char* ybytes = reinterpret_cast<char*>(a.y);
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)((long long)s.N * s.C * s.HW * 4), 0x00020000);
+    const auto ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)((long long)s.N * s.F * s.OHOW * 4), 0x00020000);
     const unsigned xg_off = (unsigned)(g * s.Cg) * (unsigned)s.HW;
     const int t_begin = blockIdx.x * a.tiles_per_block;
     int t_end = t_begin + a.tiles_per_block;
@@ -94,99 +85,124 @@ __global__ __launch_bounds__(256) void conv_fwd_direct_kernel(const ConvDirectFw
     const bool full_m = (s.Mg == TM * 32);
     const unsigned fstride = (unsigned)s.OHOW * 4u;
 
-    // B fragments of one 32-pixel tile, loaded straight into MFMA operand order (unconditional loads
-    // from an always-legal address + select: no exec-mask branches around the loads)
-    float bnext[KS];
-    unsigned ynext = 0;   // byte offset of y[n][g*Mg][pix] for this lane's pixel
-    bool qvnext = false;
-    auto prefetch = [&](int t) {
+    // per-tile lane state
+    unsigned pixb = 0, mask = 0, ybyte = OOB;
+    auto locate = [&](int t) {
         const unsigned q = (unsigned)t * 32u + (unsigned)l31;
         const bool qv = q < (unsigned)s.total_q;
         const unsigned qq = qv ? q : 0u;
         const unsigned n = qq / (unsigned)s.OHOW, pix = qq - n * (unsigned)s.OHOW;
         const unsigned oh = pix / (unsigned)s.OW, ow = pix - oh * (unsigned)s.OW;
         const int ih0 = (int)oh * s.stride - s.pad, iw0 = (int)ow * s.stride - s.pad;
-        unsigned colm = 0, mask = 0;  // validity of the ksz*ksz taps of this pixel (bit kr*ksz + kc)
+        unsigned colm = 0, m = 0;  // bit kr*KSZ + kc set <=> tap inside the image
 #pragma unroll
-        for (int kc = 0; kc < 5; ++kc)
-            if (kc < s.ksz && (unsigned)(iw0 + kc) < (unsigned)s.W) colm |= 1u << kc;
+        for (int kc = 0; kc < KSZ; ++kc) colm |= ((unsigned)(iw0 + kc) < (unsigned)s.W ? 1u : 0u) << kc;
 #pragma unroll
-        for (int kr = 0; kr < 5; ++kr)
-            if (kr < s.ksz && (unsigned)(ih0 + kr) < (unsigned)s.H) mask |= colm << (kr * s.ksz);
-        if (!qv) mask = 0;
-        const unsigned pixb = ((n * (unsigned)s.C) * (unsigned)s.HW + xg_off + (unsigned)(ih0 * s.W + iw0)) * 4u;
-#pragma unroll
-        for (int st = 0; st < KS; ++st) {
-            const unsigned tap = (tapbits[st >> 2] >> (8 * (st & 3))) & 0xffu;
-            const bool ok = (mask >> tap) & 1u;
-            const unsigned off = ok ? pixb + (unsigned)koffb[st] : 0u;
-            const float v = *reinterpret_cast<const float*>(xbytes + off);
-            bnext[st] = ok ? v : 0.f;
-        }
-        ynext = ((n * (unsigned)s.F + (unsigned)(g * s.Mg)) * (unsigned)s.OHOW + pix) * 4u;
-        qvnext = qv;
+        for (int kr = 0; kr < KSZ; ++kr) m |= ((unsigned)(ih0 + kr) < (unsigned)s.H ? colm : 0u) << (kr * KSZ);
+        mask = qv ? m : 0u;
+        pixb = ((n * (unsigned)s.C) * (unsigned)s.HW + xg_off + (unsigned)(ih0 * s.W + iw0)) * 4u;
+        ybyte = qv ? ((n * (unsigned)s.F + (unsigned)(g * s.Mg)) * (unsigned)s.OHOW + pix) * 4u +
+                         4u * (unsigned)hi * fstride
+                   : OOB;
+    };
+    // byte offset of the im2col element of step st for this lane (k = 2*st + hi); OOB if k >= K
+    auto tap_off = [&](int st) -> unsigned {
+        const int k0 = 2 * st, k1 = 2 * st + 1;  // compile-time after unrolling
+        const int o0 = (k0 / KK2) * s.HW + ((k0 % KK2) / KSZ) * s.W + ((k0 % KK2) % KSZ);  // scalar
+        const int o1 = (k1 / KK2) * s.HW + ((k1 % KK2) / KSZ) * s.W + ((k1 % KK2) % KSZ);
+        const unsigned b0 = (k0 < s.K) ? 4u * (unsigned)o0 : OOB;
+        const unsigned b1 = (k1 < s.K) ? 4u * (unsigned)o1 : OOB;
+        return hi ? b1 : b0;
+    };
+    auto load_fast = [&](int st) -> float {  // every tap of every lane is inside the image
+        const unsigned to = tap_off(st);
+        const unsigned off = (to == OOB) ? OOB : pixb + to;
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off, 0, 0));
+    };
+    auto load_slow = [&](int st) -> float {  // zero padding: invalid taps get an out-of-range offset
+        const int k0 = 2 * st, k1 = 2 * st + 1;
+        const unsigned tap = hi ? (unsigned)(k1 % KK2) : (unsigned)(k0 % KK2);
+        const unsigned to = tap_off(st);
+        const bool ok = ((mask >> tap) & 1u) && (to != OOB);
+        const unsigned off = ok ? pixb + to : OOB;
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off, 0, 0));
     };
 
     int t = t_begin + wid;
-    if (t < t_end) prefetch(t);
-    for (; t < t_end; t += 4) {
-        float bfrag[KS];
+    float bfrag[KS];
+    if (t < t_end) {
+        locate(t);
 #pragma unroll
-        for (int st = 0; st < KS; ++st) bfrag[st] = bnext[st];
-        const unsigned ybase = ynext;
-        const bool qv = qvnext;
-        if (t + 4 < t_end) prefetch(t + 4);  // next tile's loads fly under this tile's MFMAs and stores
-
+        for (int st = 0; st < KS; ++st) bfrag[st] = load_slow(st);
+    }
+    for (; t < t_end; t += 4) {
+        const unsigned ycur = ybyte;
+        const int tn = (t + 4 < t_end) ? t + 4 : t;  // last iteration re-fetches its own tile (harmless)
+        locate(tn);
+        const bool fast = __all(mask == FULL);
         f32x16 acc[TM];
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tm][r] = 0.f;
+        // MFMA step st consumes bfrag[st]; the same register is then refilled with the NEXT tile's
+        // operand, so the loads of the next tile fly under the MFMAs and stores of this one.
+        if (fast) {
 #pragma unroll
-        for (int st = 0; st < KS; ++st)
+            for (int st = 0; st < KS; ++st) {
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) acc[tm] = mfma32(areg[tm][st], bfrag[st], acc[tm]);
+                for (int tm = 0; tm < TM; ++tm) acc[tm] = mfma32(areg[tm][st], bfrag[st], acc[tm]);
+                bfrag[st] = load_fast(st);
+            }
+        } else {
+#pragma unroll
+            for (int st = 0; st < KS; ++st) {
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) acc[tm] = mfma32(areg[tm][st], bfrag[st], acc[tm]);
+                bfrag[st] = load_slow(st);
+            }
+        }
 
         // epilogue on the accumulators: + bias, activation, one store per element.
         // y[n][g*Mg + f][pix], f = tm*32 + (r&3) + 8*(r>>2) + 4*hi: registers r..r+3 are 4 consecutive channels
-        float v[TM][16];
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
+        for (int tm = 0; tm < TM; ++tm) {
+            float v[16];
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) {
                 const float4 b4 = *reinterpret_cast<const float4*>(&sbias[tm * 32 + 8 * rq + 4 * hi]);
-                v[tm][rq * 4 + 0] = acc[tm][rq * 4 + 0] + b4.x;
-                v[tm][rq * 4 + 1] = acc[tm][rq * 4 + 1] + b4.y;
-                v[tm][rq * 4 + 2] = acc[tm][rq * 4 + 2] + b4.z;
-                v[tm][rq * 4 + 3] = acc[tm][rq * 4 + 3] + b4.w;
+                v[rq * 4 + 0] = acc[tm][rq * 4 + 0] + b4.x;
+                v[rq * 4 + 1] = acc[tm][rq * 4 + 1] + b4.y;
+                v[rq * 4 + 2] = acc[tm][rq * 4 + 2] + b4.z;
+                v[rq * 4 + 3] = acc[tm][rq * 4 + 3] + b4.w;
             }
-        if (a.act != BCNN_HIP_ACT_NONE) {
+            if (a.act == BCNN_HIP_ACT_RELU) {  // the common case without a per-element switch
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
+                for (int r = 0; r < 16; ++r) v[r] = v[r] * (float)(v[r] > 0);
+            } else if (a.act != BCNN_HIP_ACT_NONE) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int f = tm * 32 + mfma_row(r, lane);
                     const float sl = (a.act == BCNN_HIP_ACT_PRELU && f < s.Mg) ? a.slopes[g * s.Mg + f] : 0.f;
-                    v[tm][r] = act_fwd_cheap(v[tm][r], a.act, sl);
+                    v[r] = act_fwd_cheap(v[r], a.act, sl);
                 }
-        }
-        if (qv) {
+            }
+            // one VGPR offset per tile (ycur); the channel stride rides in the scalar offset operand
             if (full_m) {
 #pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const unsigned f = (unsigned)(tm * 32 + (r & 3) + 8 * (r >> 2)) + 4u * (unsigned)hi;
-                        *reinterpret_cast<float*>(ybytes + (ybase + f * fstride)) = v[tm][r];
-                    }
+                for (int r = 0; r < 16; ++r) {
+                    const int fr = tm * 32 + (r & 3) + 8 * (r >> 2);  // + 4*hi is folded into ycur
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), ry, ycur,
+                                                          (unsigned)fr * fstride, 0);
+                }
             } else {
 #pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const unsigned f = (unsigned)(tm * 32 + (r & 3) + 8 * (r >> 2)) + 4u * (unsigned)hi;
-                        if (f < (unsigned)s.Mg) *reinterpret_cast<float*>(ybytes + (ybase + f * fstride)) = v[tm][r];
-                    }
+                for (int r = 0; r < 16; ++r) {
+                    const int fr = tm * 32 + (r & 3) + 8 * (r >> 2);
+                    const unsigned off = (fr + 4 * hi < s.Mg) ? ycur : OOB;  // rows beyond F/groups are dropped
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), ry, off,
+                                                          (unsigned)fr * fstride, 0);
+                }
             }
         }
     }
@@ -195,7 +211,7 @@ __global__ __launch_bounds__(256) void conv_fwd_direct_kernel(const ConvDirectFw
 bool conv_forward_direct(const float* x, const float* w, const float* bias, const float* slopes, float* y,
                          const ConvShape& s, int act, int raw) {
     if (s.pointwise || s.K > 32 || s.Mg > 64 || s.total_q == 0) return false;
-    if ((long long)s.N * s.F * s.OHOW >= (1LL << 30) || (long long)s.N * s.C * s.HW >= (1LL << 30) || s.ksz > 5) return false;
+    if ((long long)s.N * s.F * s.OHOW >= (1LL << 29) || (long long)s.N * s.C * s.HW >= (1LL << 29) || s.ksz > 5 || s.ksz < 2) return false;
     ConvDirectFwdArgs a;
     a.x = x; a.w = w; a.bias = bias; a.slopes = slopes; a.y = y; a.s = s;
     a.act = raw ? BCNN_HIP_ACT_NONE : act;
@@ -209,12 +225,17 @@ bool conv_forward_direct(const float* x, const float* w, const float* bias, cons
     dim3 grid((unsigned)blocks, (unsigned)s.groups);
     const int ks = (s.K + 1) / 2;
     const int tm = (s.Mg <= 32) ? 1 : 2;
-#define LAUNCH(TMv, KSv) conv_fwd_direct_kernel<TMv, KSv><<<grid, 256, 0, current_stream()>>>(a)
-    if (tm == 1) {
-        if (ks <= 5) LAUNCH(1, 5); else if (ks <= 9) LAUNCH(1, 9); else if (ks <= 14) LAUNCH(1, 14); else LAUNCH(1, 16);
-    } else {
-        if (ks <= 5) LAUNCH(2, 5); else if (ks <= 9) LAUNCH(2, 9); else if (ks <= 14) LAUNCH(2, 14); else LAUNCH(2, 16);
-    }
+#define LAUNCH(TMv, KSv, KZ) conv_fwd_direct_kernel<TMv, KSv, KZ><<<grid, 256, 0, current_stream()>>>(a)
+#define LAUNCH_KS(TMv, KZ)                                                              \
+    do {                                                                                \
+        if (ks <= 5) LAUNCH(TMv, 5, KZ); else if (ks <= 9) LAUNCH(TMv, 9, KZ);          \
+        else if (ks <= 14) LAUNCH(TMv, 14, KZ); else LAUNCH(TMv, 16, KZ);               \
+    } while (0)
+    if (s.ksz == 3) { if (tm == 1) LAUNCH_KS(1, 3); else LAUNCH_KS(2, 3); }
+    else if (s.ksz == 2) { if (tm == 1) LAUNCH_KS(1, 2); else LAUNCH_KS(2, 2); }
+    else if (s.ksz == 4) { if (tm == 1) LAUNCH_KS(1, 4); else LAUNCH_KS(2, 4); }
+    else { if (tm == 1) LAUNCH_KS(1, 5); else LAUNCH_KS(2, 5); }
+#undef LAUNCH_KS
 #undef LAUNCH
     KERNEL_CHECK();
     return true;
