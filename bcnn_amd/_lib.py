@@ -8,7 +8,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libbcnn_hip.so")
+LIB_PATH = os.environ.get("BCNN_HIP_LIB", os.path.join(_HERE, "lib", "libbcnn_hip.so"))  # override: kernel experiments
 CSRC = os.path.join(_HERE, "csrc")
 
 vp, i, f, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t

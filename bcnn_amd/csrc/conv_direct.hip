@@ -36,12 +36,13 @@ struct ConvDirectFwdArgs {
     int tiles_per_block;
 };
 
-// TM: 32-row tiles of output channels; KS = ceil(K/2) MFMA steps; KSZ: kernel size (compile-time, so
-// that the tap of every (step, lane-half) is a constant and its offset is scalar arithmetic).
-// Loads and stores go through buffer descriptors: an out-of-range offset reads 0 / drops the store,
-// which implements zero padding and ragged edges without exec-mask branches or post-load selects.
-template <int TM, int KS, int KSZ>
-__global__ __launch_bounds__(256) void conv_fwd_direct_kernel(const ConvDirectFwdArgs a) {
+// TM: 32-row tiles of output channels; KS >= ceil(K/2): unrolled MFMA steps (the runtime count skips
+// the unused tail); KSZ: kernel size (compile time). Loads and stores go through buffer descriptors:
+// an out-of-range offset reads 0 / drops the store, which implements zero padding and ragged edges
+// without exec-mask branches or post-load selects.
+// ACTM: 0 = no activation, 1 = ReLU, 2 = any other cheap activation (runtime switch)
+template <int TM, int KS, int KSZ, int ACTM>
+__global__ __launch_bounds__(256, 3) void conv_fwd_direct_kernel(const ConvDirectFwdArgs a) {
     __shared__ __attribute__((aligned(16))) float sbias[TM * 32];
     const ConvShape& s = a.s;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -50,7 +51,6 @@ __global__ __launch_bounds__(256) void conv_fwd_direct_kernel(const ConvDirectFw
     const int g = blockIdx.y;
     const float* wg = a.w + (long long)g * s.Mg * s.K;
     constexpr int KK2 = KSZ * KSZ;
-    constexpr unsigned FULL = (1u << KK2) - 1u;
     constexpr unsigned OOB = 0x80000000u;  // >= num_records of both descriptors (tensors < 2 GiB)
 
     if (tid < TM * 32) {
@@ -61,18 +61,29 @@ __global__ __launch_bounds__(256) void conv_fwd_direct_kernel(const ConvDirectFw
         }
         sbias[tid] = b;
     }
-    // A operand: W[f = tm*32 + l31][k = 2*st + hi], resident in registers for the whole kernel
+    // A operand W[f = tm*32 + l31][k = 2*st + hi] resident in registers for the whole kernel; per step
+    // the lane also keeps its tap's byte offset (OOB when k >= K) and, packed 4 per register, the tap's
+    // bit index kr*KSZ + kc in the per-pixel validity mask (used on border tiles only).
     float areg[TM][KS];
+    unsigned koffb[KS];
+    unsigned tapbits[(KS + 3) / 4];
+#pragma unroll
+    for (int i = 0; i < (KS + 3) / 4; ++i) tapbits[i] = 0;
 #pragma unroll
     for (int st = 0; st < KS; ++st) {
         const int k = 2 * st + hi;
+        const bool kv = k < s.K;
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
             const int f = tm * 32 + l31;
-            const bool ok = (k < s.K) && (f < s.Mg);
+            const bool ok = kv && (f < s.Mg);
             const float v = wg[ok ? (long long)f * s.K + k : 0];
             areg[tm][st] = ok ? v : 0.f;
         }
+        const int c = k / KK2, r = k - c * KK2;
+        const int kr = r / KSZ, kc = r - kr * KSZ;
+        koffb[st] = kv ? (unsigned)(c * s.HW + kr * s.W + kc) * 4u : OOB;
+        tapbits[st >> 2] |= (unsigned)(kv ? r : 31) << (8 * (st & 3));
     }
     __syncthreads();
 
@@ -85,46 +96,51 @@ __global__ __launch_bounds__(256) void conv_fwd_direct_kernel(const ConvDirectFw
     const bool full_m = (s.Mg == TM * 32);
     const unsigned fstride = (unsigned)s.OHOW * 4u;
 
-    // per-tile lane state
-    unsigned pixb = 0, mask = 0, ybyte = OOB;
-    auto locate = [&](int t) {
+    // per-tile lane state: pixel coordinates, byte offset of its top-left tap, output byte offset
+    unsigned pn = 0, poh = 0, pow_ = 0;
+    unsigned pixb = 0, ybyte = OOB;
+    bool interior = false, qvalid = false;
+    auto place = [&]() {  // derive offsets from (pn, poh, pow_)
+        const int ih0 = (int)poh * s.stride - s.pad, iw0 = (int)pow_ * s.stride - s.pad;
+        interior = qvalid && ih0 >= 0 && iw0 >= 0 && (ih0 + KSZ <= s.H) && (iw0 + KSZ <= s.W);
+        pixb = ((pn * (unsigned)s.C) * (unsigned)s.HW + xg_off + (unsigned)(ih0 * s.W + iw0)) * 4u;
+        ybyte = qvalid ? ((pn * (unsigned)s.F + (unsigned)(g * s.Mg)) * (unsigned)s.OHOW + poh * (unsigned)s.OW + pow_) * 4u +
+                             4u * (unsigned)hi * fstride
+                       : OOB;
+    };
+    auto locate = [&](int t) {  // full decode (two divisions)
         const unsigned q = (unsigned)t * 32u + (unsigned)l31;
-        const bool qv = q < (unsigned)s.total_q;
-        const unsigned qq = qv ? q : 0u;
-        const unsigned n = qq / (unsigned)s.OHOW, pix = qq - n * (unsigned)s.OHOW;
-        const unsigned oh = pix / (unsigned)s.OW, ow = pix - oh * (unsigned)s.OW;
-        const int ih0 = (int)oh * s.stride - s.pad, iw0 = (int)ow * s.stride - s.pad;
-        unsigned colm = 0, m = 0;  // bit kr*KSZ + kc set <=> tap inside the image
+        qvalid = q < (unsigned)s.total_q;
+        const unsigned qq = qvalid ? q : 0u;
+        pn = qq / (unsigned)s.OHOW;
+        const unsigned pix = qq - pn * (unsigned)s.OHOW;
+        poh = pix / (unsigned)s.OW;
+        pow_ = pix - poh * (unsigned)s.OW;
+        place();
+    };
+    const bool wide = s.OW >= 128;  // then +128 pixels wraps at most one row: no division per tile
+    auto advance = [&](int t) {      // move the lane from tile t-4 to tile t
+        if (wide) {
+            const unsigned q = (unsigned)t * 32u + (unsigned)l31;
+            qvalid = q < (unsigned)s.total_q;
+            pow_ += 128u;
+            if (pow_ >= (unsigned)s.OW) { pow_ -= (unsigned)s.OW; poh += 1u; }
+            if (poh >= (unsigned)s.OH) { poh -= (unsigned)s.OH; pn += 1u; }
+            place();
+        } else {
+            locate(t);
+        }
+    };
+    auto tap_mask = [&]() -> unsigned {  // bit kr*KSZ + kc set <=> tap inside the image (border tiles)
+        const int ih0 = (int)poh * s.stride - s.pad, iw0 = (int)pow_ * s.stride - s.pad;
+        unsigned colm = 0, m = 0;
 #pragma unroll
         for (int kc = 0; kc < KSZ; ++kc) colm |= ((unsigned)(iw0 + kc) < (unsigned)s.W ? 1u : 0u) << kc;
 #pragma unroll
         for (int kr = 0; kr < KSZ; ++kr) m |= ((unsigned)(ih0 + kr) < (unsigned)s.H ? colm : 0u) << (kr * KSZ);
-        mask = qv ? m : 0u;
-        pixb = ((n * (unsigned)s.C) * (unsigned)s.HW + xg_off + (unsigned)(ih0 * s.W + iw0)) * 4u;
-        ybyte = qv ? ((n * (unsigned)s.F + (unsigned)(g * s.Mg)) * (unsigned)s.OHOW + pix) * 4u +
-                         4u * (unsigned)hi * fstride
-                   : OOB;
+        return qvalid ? m : 0u;
     };
-    // byte offset of the im2col element of step st for this lane (k = 2*st + hi); OOB if k >= K
-    auto tap_off = [&](int st) -> unsigned {
-        const int k0 = 2 * st, k1 = 2 * st + 1;  // compile-time after unrolling
-        const int o0 = (k0 / KK2) * s.HW + ((k0 % KK2) / KSZ) * s.W + ((k0 % KK2) % KSZ);  // scalar
-        const int o1 = (k1 / KK2) * s.HW + ((k1 % KK2) / KSZ) * s.W + ((k1 % KK2) % KSZ);
-        const unsigned b0 = (k0 < s.K) ? 4u * (unsigned)o0 : OOB;
-        const unsigned b1 = (k1 < s.K) ? 4u * (unsigned)o1 : OOB;
-        return hi ? b1 : b0;
-    };
-    auto load_fast = [&](int st) -> float {  // every tap of every lane is inside the image
-        const unsigned to = tap_off(st);
-        const unsigned off = (to == OOB) ? OOB : pixb + to;
-        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off, 0, 0));
-    };
-    auto load_slow = [&](int st) -> float {  // zero padding: invalid taps get an out-of-range offset
-        const int k0 = 2 * st, k1 = 2 * st + 1;
-        const unsigned tap = hi ? (unsigned)(k1 % KK2) : (unsigned)(k0 % KK2);
-        const unsigned to = tap_off(st);
-        const bool ok = ((mask >> tap) & 1u) && (to != OOB);
-        const unsigned off = ok ? pixb + to : OOB;
+    auto ldx = [&](unsigned off) -> float {
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off, 0, 0));
     };
 
@@ -132,54 +148,71 @@ __global__ __launch_bounds__(256) void conv_fwd_direct_kernel(const ConvDirectFw
     float bfrag[KS];
     if (t < t_end) {
         locate(t);
+        const unsigned m = tap_mask();
 #pragma unroll
-        for (int st = 0; st < KS; ++st) bfrag[st] = load_slow(st);
+        for (int st = 0; st < KS; ++st) {
+            const unsigned tap = (tapbits[st >> 2] >> (8 * (st & 3))) & 0xffu;
+            bfrag[st] = ldx(((m >> tap) & 1u) ? pixb + koffb[st] : OOB);
+        }
     }
     for (; t < t_end; t += 4) {
         const unsigned ycur = ybyte;
-        const int tn = (t + 4 < t_end) ? t + 4 : t;  // last iteration re-fetches its own tile (harmless)
-        locate(tn);
-        const bool fast = __all(mask == FULL);
+        const bool more = (t + 4 < t_end);  // wave-uniform
+        if (more) advance(t + 4);
+        const bool fast = __all(interior);
+        // the accumulators start from the bias (4 consecutive channels per 16-byte LDS read), so the
+        // bias add costs no VALU: row(r) = (r&3) + 8*(r>>2) + 4*hi
         f32x16 acc[TM];
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[tm][r] = 0.f;
+            for (int rq = 0; rq < 4; ++rq) {
+                const float4 b4 = *reinterpret_cast<const float4*>(&sbias[tm * 32 + 8 * rq + 4 * hi]);
+                acc[tm][rq * 4 + 0] = b4.x;
+                acc[tm][rq * 4 + 1] = b4.y;
+                acc[tm][rq * 4 + 2] = b4.z;
+                acc[tm][rq * 4 + 3] = b4.w;
+            }
         // MFMA step st consumes bfrag[st]; the same register is then refilled with the NEXT tile's
         // operand, so the loads of the next tile fly under the MFMAs and stores of this one.
-        if (fast) {
+        if (fast) {  // every tap of every lane is inside the image: offset = pixel + tap, nothing else
+                     // (a tap with k >= K carries OOB = 2^31: pixel + 2^31 stays out of range for tensors < 1 GiB)
 #pragma unroll
             for (int st = 0; st < KS; ++st) {
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm) acc[tm] = mfma32(areg[tm][st], bfrag[st], acc[tm]);
-                bfrag[st] = load_fast(st);
+                bfrag[st] = ldx(pixb + koffb[st]);
             }
-        } else {
+        } else {     // border tile (or tail): invalid taps get an out-of-range offset => 0
+            const unsigned m = more ? tap_mask() : 0u;
+            unsigned tb[(KS + 3) / 4];
+#pragma unroll
+            for (int i = 0; i < (KS + 3) / 4; ++i) {
+                tb[i] = tapbits[i];
+                asm volatile("" : "+v"(tb[i]));  // keep the 4-per-register packing (no hoisted unpacked copies)
+            }
 #pragma unroll
             for (int st = 0; st < KS; ++st) {
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm) acc[tm] = mfma32(areg[tm][st], bfrag[st], acc[tm]);
-                bfrag[st] = load_slow(st);
+                const unsigned tap = (tb[st >> 2] >> (8 * (st & 3))) & 0xffu;
+                bfrag[st] = ldx(((m >> tap) & 1u) ? pixb + koffb[st] : OOB);
             }
         }
 
         // epilogue on the accumulators: + bias, activation, one store per element.
         // y[n][g*Mg + f][pix], f = tm*32 + (r&3) + 8*(r>>2) + 4*hi: registers r..r+3 are 4 consecutive channels
+        unsigned fs = fstride;
+        asm volatile("" : "+s"(fs));  // recompute the 32 scalar channel offsets per tile instead of pinning 32 SGPRs
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
             float v[16];
 #pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                const float4 b4 = *reinterpret_cast<const float4*>(&sbias[tm * 32 + 8 * rq + 4 * hi]);
-                v[rq * 4 + 0] = acc[tm][rq * 4 + 0] + b4.x;
-                v[rq * 4 + 1] = acc[tm][rq * 4 + 1] + b4.y;
-                v[rq * 4 + 2] = acc[tm][rq * 4 + 2] + b4.z;
-                v[rq * 4 + 3] = acc[tm][rq * 4 + 3] + b4.w;
-            }
-            if (a.act == BCNN_HIP_ACT_RELU) {  // the common case without a per-element switch
+            for (int r = 0; r < 16; ++r) v[r] = acc[tm][r];
+            if (ACTM == 1) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[r] = v[r] * (float)(v[r] > 0);
-            } else if (a.act != BCNN_HIP_ACT_NONE) {
+            } else if (ACTM == 2) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int f = tm * 32 + mfma_row(r, lane);
@@ -193,7 +226,7 @@ __global__ __launch_bounds__(256) void conv_fwd_direct_kernel(const ConvDirectFw
                 for (int r = 0; r < 16; ++r) {
                     const int fr = tm * 32 + (r & 3) + 8 * (r >> 2);  // + 4*hi is folded into ycur
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), ry, ycur,
-                                                          (unsigned)fr * fstride, 0);
+                                                          (unsigned)fr * fs, 0);
                 }
             } else {
 #pragma unroll
@@ -201,7 +234,7 @@ __global__ __launch_bounds__(256) void conv_fwd_direct_kernel(const ConvDirectFw
                     const int fr = tm * 32 + (r & 3) + 8 * (r >> 2);
                     const unsigned off = (fr + 4 * hi < s.Mg) ? ycur : OOB;  // rows beyond F/groups are dropped
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), ry, off,
-                                                          (unsigned)fr * fstride, 0);
+                                                          (unsigned)fr * fs, 0);
                 }
             }
         }
@@ -211,7 +244,8 @@ __global__ __launch_bounds__(256) void conv_fwd_direct_kernel(const ConvDirectFw
 bool conv_forward_direct(const float* x, const float* w, const float* bias, const float* slopes, float* y,
                          const ConvShape& s, int act, int raw) {
     if (s.pointwise || s.K > 32 || s.Mg > 64 || s.total_q == 0) return false;
-    if ((long long)s.N * s.F * s.OHOW >= (1LL << 29) || (long long)s.N * s.C * s.HW >= (1LL << 29) || s.ksz > 5 || s.ksz < 2) return false;
+    if ((long long)s.N * s.F * s.OHOW >= (1LL << 29) || (long long)s.N * s.C * s.HW >= (1LL << 28)) return false;
+    if (!((s.ksz == 3 && s.Cg <= 3) || (s.ksz == 5 && s.Cg == 1))) return false;
     ConvDirectFwdArgs a;
     a.x = x; a.w = w; a.bias = bias; a.slopes = slopes; a.y = y; a.s = s;
     a.act = raw ? BCNN_HIP_ACT_NONE : act;
@@ -225,17 +259,18 @@ bool conv_forward_direct(const float* x, const float* w, const float* bias, cons
     dim3 grid((unsigned)blocks, (unsigned)s.groups);
     const int ks = (s.K + 1) / 2;
     const int tm = (s.Mg <= 32) ? 1 : 2;
-#define LAUNCH(TMv, KSv, KZ) conv_fwd_direct_kernel<TMv, KSv, KZ><<<grid, 256, 0, current_stream()>>>(a)
-#define LAUNCH_KS(TMv, KZ)                                                              \
-    do {                                                                                \
-        if (ks <= 5) LAUNCH(TMv, 5, KZ); else if (ks <= 9) LAUNCH(TMv, 9, KZ);          \
-        else if (ks <= 14) LAUNCH(TMv, 14, KZ); else LAUNCH(TMv, 16, KZ);               \
+    const int actm = (a.act == BCNN_HIP_ACT_NONE) ? 0 : (a.act == BCNN_HIP_ACT_RELU ? 1 : 2);
+#define LAUNCH(TMv, KSv, KZ)                                                                            \
+    do {                                                                                                \
+        if (actm == 0) conv_fwd_direct_kernel<TMv, KSv, KZ, 0><<<grid, 256, 0, current_stream()>>>(a);      \
+        else if (actm == 1) conv_fwd_direct_kernel<TMv, KSv, KZ, 1><<<grid, 256, 0, current_stream()>>>(a); \
+        else conv_fwd_direct_kernel<TMv, KSv, KZ, 2><<<grid, 256, 0, current_stream()>>>(a);                \
     } while (0)
-    if (s.ksz == 3) { if (tm == 1) LAUNCH_KS(1, 3); else LAUNCH_KS(2, 3); }
-    else if (s.ksz == 2) { if (tm == 1) LAUNCH_KS(1, 2); else LAUNCH_KS(2, 2); }
-    else if (s.ksz == 4) { if (tm == 1) LAUNCH_KS(1, 4); else LAUNCH_KS(2, 4); }
-    else { if (tm == 1) LAUNCH_KS(1, 5); else LAUNCH_KS(2, 5); }
-#undef LAUNCH_KS
+    if (s.ksz == 3 && ks == 14) { if (tm == 1) LAUNCH(1, 14, 3); else LAUNCH(2, 14, 3); }
+    else if (s.ksz == 3 && ks == 9) { if (tm == 1) LAUNCH(1, 9, 3); else LAUNCH(2, 9, 3); }
+    else if (s.ksz == 3 && ks == 5) { if (tm == 1) LAUNCH(1, 5, 3); else LAUNCH(2, 5, 3); }
+    else if (s.ksz == 5 && ks == 13) { if (tm == 1) LAUNCH(1, 13, 5); else LAUNCH(2, 13, 5); }
+    else return false;
 #undef LAUNCH
     KERNEL_CHECK();
     return true;
