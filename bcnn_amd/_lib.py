@@ -60,6 +60,9 @@ SIGNATURES = {
     "bcnn_hip_depthwise_forward": (None, [vp, vp, vp, vp] + [i] * 8),
     "bcnn_hip_depthwise_backward": (None, [vp] * 7 + [i] * 8),
     "bcnn_hip_sgd_update": (None, [vp, vp, vp, vp, sz, sz, i, f, f, f]),
+    "bcnn_hip_axpy_strided": (None, [i, f, vp, vp] + [i] * 11),
+    "bcnn_hip_add_rowvec": (None, [vp, vp, i, i]),
+    "bcnn_hip_softmax_forward": (None, [vp, vp, i, i, i]),
 }
 
 _lib = None
@@ -76,6 +79,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    try:
+        # torch wheels bundle their own HIP runtime; importing torch first makes the process share ONE
+        # runtime (two runtimes in a process cannot both own the device). torch stays plumbing only.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             "bcnn_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "

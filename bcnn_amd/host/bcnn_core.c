@@ -1,0 +1,580 @@
+/*
+ * bcnn_core.c -- graph runtime of the MI355X build: net / node / tensor bookkeeping, the three
+ * executor loops, the learner, and the device-mirror sync points. C99; every device action goes
+ * through the C-ABI of include/bcnn_hip.h (no HIP types here).
+ *
+ * Behaviour follows the reference runtime (jnbraun/bcnn):
+ *   net life cycle   src/bcnn_net.c:61-157, 236-258, 280-285, 337-359
+ *   executor         src/bcnn_net.c:361-375 (dst-gradient reset), 410-429, 452-481
+ *   tensors          src/bcnn_tensor.c:40-145
+ *   learner          src/bcnn_learner.c:29-65, 167-217
+ * What is new: parameters and their gradients are re-packed into two contiguous device arenas at
+ * compile time (one all-reduce per step, one place to checkpoint), and the SGD step knows the
+ * data-parallel world size.
+ */
+#include <math.h>
+#include <stdarg.h>
+#include <string.h>
+
+#include "bcnn_internal.h"
+#include "../../include/bcnn_hip.h"
+
+#ifndef BCNN_USE_HIP
+#error "this runtime is the device build: compile with -DBCNN_USE_HIP"
+#endif
+
+/* ------------------------------------------------------------------------------------------------
+ * logging
+ * ---------------------------------------------------------------------------------------------- */
+void bcnn_log(bcnn_log_context ctx, bcnn_log_level level, const char *fmt, ...) {
+    if (level < ctx.lvl) return;
+    char msg[2048];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(msg, sizeof(msg), fmt, ap);
+    va_end(ap);
+    if (ctx.fct) {
+        ctx.fct("%s", msg);
+        return;
+    }
+    static const char *tag[] = {"[INFO] ", "[WARNING] ", "[ERROR] ", ""};
+    fprintf(stderr, "%s%s", tag[level > 3 ? 3 : level], msg);
+}
+
+void bcnn_set_log_context(bcnn_net *net, bcnn_log_callback fct, bcnn_log_level level) {
+    net->log_ctx.fct = fct;
+    net->log_ctx.lvl = level;
+}
+
+/* Box-Muller pair generator on rand(), as the MSRA filler of the reference uses (bcnn_utils.c:48-73) */
+float bcnn_rng_gaussian(bcnn_gauss_gen *g) {
+    if (g->state) {
+        g->state = 0;
+        return g->r;
+    }
+    float u, v, s;
+    do {
+        u = 2.0f * ((float)rand() / RAND_MAX) - 1.0f;
+        v = 2.0f * ((float)rand() / RAND_MAX) - 1.0f;
+        s = u * u + v * v;
+    } while (s >= 1.0f || s == 0.0f);
+    const float m = sqrtf(-2.0f * logf(s) / s);
+    g->r = v * m;
+    g->state = 1;
+    return u * m;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * tensors: 32-byte aligned zeroed host buffer + device mirror
+ * ---------------------------------------------------------------------------------------------- */
+static float *host_calloc_aligned(size_t count) {
+    void *p = NULL;
+    if (count == 0) return NULL;
+    if (posix_memalign(&p, 32, count * sizeof(float)) != 0) return NULL;
+    memset(p, 0, count * sizeof(float));
+    return (float *)p;
+}
+
+int bcnn_tensor_size(const bcnn_tensor *t) { return t->w * t->h * t->c * t->n; }
+int bcnn_tensor_size3d(const bcnn_tensor *t) { return t->w * t->h * t->c; }
+int bcnn_tensor_size2d(const bcnn_tensor *t) { return t->w * t->h; }
+
+void bcnn_tensor_set_shape(bcnn_tensor *t, int n, int c, int h, int w, int has_grad) {
+    t->n = n; t->c = c; t->h = h; t->w = w; t->has_grad = has_grad;
+}
+
+void bcnn_tensor_free(bcnn_tensor *t) {
+    free(t->data); t->data = NULL;
+    free(t->grad_data); t->grad_data = NULL;
+    bcnn_hip_free(t->data_gpu); t->data_gpu = NULL;
+    bcnn_hip_free(t->grad_data_gpu); t->grad_data_gpu = NULL;
+}
+
+bcnn_status bcnn_tensor_allocate_buffer(bcnn_tensor *t, int net_state, size_t size) {
+    bcnn_tensor_free(t);
+    if (size == 0) return BCNN_INVALID_PARAMETER;
+    t->data = host_calloc_aligned(size);
+    if (!t->data) return BCNN_FAILED_ALLOC;
+    t->data_gpu = bcnn_hip_malloc_f32(size); /* zero-filled, like the freshly calloc'ed host copy */
+    if (t->has_grad && net_state != BCNN_MODE_PREDICT) {
+        t->grad_data = host_calloc_aligned(size);
+        if (!t->grad_data) return BCNN_FAILED_ALLOC;
+        t->grad_data_gpu = bcnn_hip_malloc_f32(size);
+    }
+    return BCNN_SUCCESS;
+}
+
+bcnn_status bcnn_tensor_allocate(bcnn_tensor *t, int net_state) {
+    return bcnn_tensor_allocate_buffer(t, net_state, (size_t)t->n * t->c * t->h * t->w);
+}
+
+static char *dup_name(const char *s) {
+    size_t n = strlen(s) + 1;
+    char *d = (char *)malloc(n);
+    if (d) memcpy(d, s, n);
+    return d;
+}
+
+void bcnn_tensor_create(bcnn_tensor *t, int n, int c, int h, int w, int has_grad, const char *name,
+                        int net_state) {
+    bcnn_tensor_set_shape(t, n, c, h, w, has_grad);
+    bcnn_tensor_allocate(t, net_state);
+    free(t->name);
+    t->name = dup_name(name);
+}
+
+/* Xavier: sqrt(3/range)*U(-1,1) from rand(); MSRA: sqrt(2/range)*N(0,1); then host -> device */
+void bcnn_tensor_fill(bcnn_tensor *t, bcnn_tensor_filler filler) {
+    if (!t->data) return;
+    const int sz = bcnn_tensor_size(t);
+    if (filler.type == BCNN_FILLER_XAVIER) {
+        const float a = sqrtf(3.0f / filler.range);
+        for (int i = 0; i < sz; ++i) t->data[i] = a * (2 * ((float)rand() / RAND_MAX) - 1);
+    } else if (filler.type == BCNN_FILLER_MSRA) {
+        const float a = sqrtf(2.0f / filler.range);
+        bcnn_gauss_gen g = {0};
+        for (int i = 0; i < sz; ++i) t->data[i] = a * bcnn_rng_gaussian(&g);
+    } else {
+        for (int i = 0; i < sz; ++i) t->data[i] = filler.value;
+    }
+    if (t->data_gpu) bcnn_hip_memcpy_h2d(t->data_gpu, t->data, (size_t)sz * sizeof(float));
+}
+
+void bcnn_tensor_destroy(bcnn_tensor *t) {
+    bcnn_tensor_free(t);
+    bcnn_tensor_set_shape(t, 0, 0, 0, 0, 0);
+    free(t->name);
+    t->name = NULL;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * net / node containers (realloc-grown arrays: indices are stable, pointers are not)
+ * ---------------------------------------------------------------------------------------------- */
+static bcnn_hip_context *hctx(bcnn_net *net) { return (bcnn_hip_context *)net->hip_ctx; }
+
+bcnn_status bcnn_net_add_tensor(bcnn_net *net, bcnn_tensor tensor) {
+    bcnn_tensor *p = (bcnn_tensor *)realloc(net->tensors, (size_t)(net->num_tensors + 1) * sizeof(bcnn_tensor));
+    if (!p) return BCNN_FAILED_ALLOC;
+    net->tensors = p;
+    net->tensors[net->num_tensors++] = tensor;
+    return BCNN_SUCCESS;
+}
+
+bcnn_status bcnn_net_add_node(bcnn_net *net, bcnn_node node) {
+    bcnn_node *p = (bcnn_node *)realloc(net->nodes, (size_t)(net->num_nodes + 1) * sizeof(bcnn_node));
+    if (!p) return BCNN_FAILED_ALLOC;
+    net->nodes = p;
+    net->nodes[net->num_nodes++] = node;
+    return BCNN_SUCCESS;
+}
+
+static bcnn_status push_index(int **arr, int *count, int index) {
+    int *p = (int *)realloc(*arr, (size_t)(*count + 1) * sizeof(int));
+    if (!p) return BCNN_FAILED_ALLOC;
+    p[(*count)++] = index;
+    *arr = p;
+    return BCNN_SUCCESS;
+}
+
+bcnn_status bcnn_node_add_input(bcnn_net *net, bcnn_node *node, int index) {
+    (void)net;
+    return push_index(&node->src, &node->num_src, index);
+}
+
+bcnn_status bcnn_node_add_output(bcnn_net *net, bcnn_node *node, int index) {
+    (void)net;
+    return push_index(&node->dst, &node->num_dst, index);
+}
+
+int bcnn_net_find_tensor(bcnn_net *net, const char *name) {
+    for (int i = net->num_tensors - 1; i >= 0; --i)
+        if (net->tensors[i].name && strcmp(net->tensors[i].name, name) == 0) return i;
+    return -1;
+}
+
+void bcnn_net_register_param(bcnn_net *net, int index) {
+    bcnn_hip_context *hc = hctx(net);
+    push_index(&hc->param_ids, &hc->num_params, index);
+}
+
+bcnn_status bcnn_init_net(bcnn_net **net, bcnn_mode mode) {
+    bcnn_net *p = (bcnn_net *)calloc(1, sizeof(bcnn_net));
+    if (!p) return BCNN_FAILED_ALLOC;
+    p->mode = mode;
+    p->hip_ctx = calloc(1, sizeof(bcnn_hip_context));
+    if (!p->hip_ctx) { free(p); return BCNN_FAILED_ALLOC; }
+    hctx(p)->dp_world = 1;
+    /* tensor 0 = "input", tensor 1 = "label" (reference bcnn_net.c:66-76) */
+    bcnn_tensor in = {0}, lab = {0};
+    in.name = dup_name("input");
+    lab.name = dup_name("label");
+    bcnn_net_add_tensor(p, in);
+    bcnn_net_add_tensor(p, lab);
+    if (mode != BCNN_MODE_PREDICT) {
+        p->learner = (bcnn_learner *)calloc(1, sizeof(bcnn_learner));
+        p->data_aug = (bcnn_data_augmenter *)calloc(1, sizeof(bcnn_data_augmenter));
+    }
+    p->num_inputs = 1;
+    p->inputs = (int *)calloc(1, sizeof(int));
+    p->num_threads = 1;
+    *net = p;
+    return BCNN_SUCCESS;
+}
+
+void bcnn_end_net(bcnn_net **pnet) {
+    bcnn_net *net = *pnet;
+    if (!net) return;
+    bcnn_hip_sync();
+    bcnn_hip_context *hc = hctx(net);
+    /* arena members do not own their device buffers */
+    if (hc->compiled) {
+        for (int i = 0; i < hc->num_params; ++i) {
+            bcnn_tensor *t = &net->tensors[hc->param_ids[i]];
+            t->data_gpu = NULL;
+            t->grad_data_gpu = NULL;
+        }
+        bcnn_hip_free(hc->param_arena_gpu);
+        bcnn_hip_free(hc->grad_arena_gpu);
+    }
+    for (int i = 0; i < net->num_nodes; ++i) {
+        bcnn_node *nd = &net->nodes[i];
+        if (nd->release_param) nd->release_param(nd);
+        free(nd->src); free(nd->dst); free(nd->param);
+    }
+    free(net->nodes);
+    for (int i = 0; i < net->num_tensors; ++i) bcnn_tensor_destroy(&net->tensors[i]);
+    free(net->tensors);
+    bcnn_hip_free(hc->workspace_gpu);
+    free(hc->param_ids);
+    free(hc);
+    free(net->learner); free(net->data_aug); free(net->data_loader); free(net->inputs);
+    free(net);
+    *pnet = NULL;
+}
+
+bcnn_status bcnn_set_num_threads(bcnn_net *net, int num_threads, const int *cpu_ids) {
+    (void)cpu_ids;  /* host threads do no math in this build */
+    net->num_threads = num_threads > 0 ? num_threads : 1;
+    return BCNN_SUCCESS;
+}
+int bcnn_get_num_threads(bcnn_net *net) { return net->num_threads; }
+int bcnn_get_batch_size(bcnn_net *net) { return net->batch_size; }
+
+void bcnn_set_input_shape(bcnn_net *net, int width, int height, int channels, int batch_size) {
+    net->batch_size = batch_size;
+    bcnn_tensor_set_shape(&net->tensors[0], batch_size, channels, height, width, 0);
+}
+
+bcnn_status bcnn_add_input(bcnn_net *net, int width, int height, int channels, const char *name) {
+    bcnn_tensor t = {0};
+    bcnn_tensor_set_shape(&t, net->batch_size, channels, height, width, 0);
+    BCNN_CHECK_STATUS(bcnn_tensor_allocate(&t, net->mode));
+    t.name = dup_name(name);
+    BCNN_CHECK_STATUS(bcnn_net_add_tensor(net, t));
+    int *p = (int *)realloc(net->inputs, (size_t)(net->num_inputs + 1) * sizeof(int));
+    if (!p) return BCNN_FAILED_ALLOC;
+    net->inputs = p;
+    net->inputs[net->num_inputs++] = net->num_tensors - 1;
+    return BCNN_SUCCESS;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * compile: input tensor, shared conv workspace, parameter / gradient arenas
+ * ---------------------------------------------------------------------------------------------- */
+static void build_arenas(bcnn_net *net) {
+    bcnn_hip_context *hc = hctx(net);
+    size_t total = 0;
+    for (int i = 0; i < hc->num_params; ++i) {
+        /* keep every member 16-byte aligned for the vectorised kernels */
+        total += ((size_t)bcnn_tensor_size(&net->tensors[hc->param_ids[i]]) + 3) & ~(size_t)3;
+    }
+    hc->arena_size = total;
+    if (total == 0) return;
+    hc->param_arena_gpu = bcnn_hip_malloc_f32(total);
+    hc->grad_arena_gpu = (net->mode != BCNN_MODE_PREDICT) ? bcnn_hip_malloc_f32(total) : NULL;
+    size_t off = 0;
+    for (int i = 0; i < hc->num_params; ++i) {
+        bcnn_tensor *t = &net->tensors[hc->param_ids[i]];
+        const size_t sz = (size_t)bcnn_tensor_size(t);
+        bcnn_hip_memcpy_d2d(hc->param_arena_gpu + off, t->data_gpu, sz * sizeof(float));
+        bcnn_hip_sync();
+        bcnn_hip_free(t->data_gpu);
+        t->data_gpu = hc->param_arena_gpu + off;
+        if (hc->grad_arena_gpu && t->grad_data_gpu) {
+            bcnn_hip_memcpy_d2d(hc->grad_arena_gpu + off, t->grad_data_gpu, sz * sizeof(float));
+            bcnn_hip_sync();
+            bcnn_hip_free(t->grad_data_gpu);
+            t->grad_data_gpu = hc->grad_arena_gpu + off;
+        }
+        off += (sz + 3) & ~(size_t)3;
+    }
+}
+
+bcnn_status bcnn_compile_net(bcnn_net *net) {
+    bcnn_hip_context *hc = hctx(net);
+    /* (re)allocate the input tensor, as bcnn_init_workload does (reference bcnn_net.c:337-359) */
+    BCNN_CHECK_STATUS(bcnn_tensor_allocate(&net->tensors[0], net->mode));
+    /* one conv scratch for the whole net: the largest any conv node needs */
+    size_t need = 0;
+    for (int i = 0; i < net->num_nodes; ++i) {
+        if (net->nodes[i].type != BCNN_LAYER_CONV2D) continue;
+        bcnn_conv_param *p = (bcnn_conv_param *)net->nodes[i].param;
+        const bcnn_tensor *s = &net->tensors[net->nodes[i].src[0]];
+        const size_t ws = bcnn_hip_conv_workspace_size(s->n, s->c, s->h, s->w, p->num, p->size, p->stride, p->pad,
+                                                       p->num_groups);
+        if (ws > need) need = ws;
+    }
+    if (need > hc->workspace_size) {
+        bcnn_hip_free(hc->workspace_gpu);
+        hc->workspace_gpu = bcnn_hip_malloc_f32(need);
+        hc->workspace_size = need;
+    }
+    for (int i = 0; i < net->num_nodes; ++i)
+        if (net->nodes[i].type == BCNN_LAYER_CONV2D)
+            ((bcnn_conv_param *)net->nodes[i].param)->conv_workspace_gpu = hc->workspace_gpu;
+    if (!hc->compiled) {
+        build_arenas(net);
+        hc->compiled = 1;
+    }
+    bcnn_hip_sync();
+    return BCNN_SUCCESS;
+}
+
+bcnn_status bcnn_set_mode(bcnn_net *net, bcnn_mode mode) {
+    net->mode = mode;
+    return BCNN_SUCCESS;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * executor loops
+ * ---------------------------------------------------------------------------------------------- */
+void bcnn_forward(bcnn_net *net) {
+    for (int i = 0; i < net->num_nodes; ++i) {
+        bcnn_node *node = &net->nodes[i];
+        if (net->mode == BCNN_MODE_TRAIN) {
+            /* every dst gradient is zero-filled before the node runs (reference bcnn_net.c:361-375):
+             * pooling / eltwise / fc / softmax backward ACCUMULATE into it */
+            for (int d = 0; d < node->num_dst; ++d) {
+                bcnn_tensor *t = &net->tensors[node->dst[d]];
+                if (t->grad_data_gpu) bcnn_hip_fill_f32(t->grad_data_gpu, (size_t)bcnn_tensor_size(t), 0.0f);
+            }
+        }
+        node->forward(net, node);
+    }
+}
+
+void bcnn_backward(bcnn_net *net) {
+    for (int i = net->num_nodes - 1; i >= 0; --i) net->nodes[i].backward(net, &net->nodes[i]);
+}
+
+/* learning-rate schedules, reference bcnn_learner.c:29-65 */
+static void step_learning_rate(bcnn_net *net) {
+    bcnn_learner *ln = net->learner;
+    ln->seen += net->batch_size;
+    const int iter = ln->seen / net->batch_size;
+    switch (ln->decay_type) {
+        case BCNN_LR_DECAY_STEP:
+            ln->learning_rate = ln->base_learning_rate * (float)pow(ln->scale, iter / ln->step);
+            break;
+        case BCNN_LR_DECAY_INV:
+            ln->learning_rate = ln->base_learning_rate * (float)pow(1.0f + ln->gamma * iter, -ln->power);
+            break;
+        case BCNN_LR_DECAY_EXP:
+            ln->learning_rate = ln->base_learning_rate * (float)pow(ln->gamma, iter);
+            break;
+        case BCNN_LR_DECAY_POLY:
+            ln->learning_rate = ln->base_learning_rate * (float)pow(1 - (float)iter / ln->max_batches, ln->power);
+            break;
+        case BCNN_LR_DECAY_SIGMOID:
+            ln->learning_rate = ln->base_learning_rate * (1.0f / (1.0f + (float)exp(ln->gamma * (iter - ln->step))));
+            break;
+        default:
+            break;
+    }
+}
+
+void bcnn_update(bcnn_net *net) {
+    step_learning_rate(net);
+    for (int i = 0; i < net->num_nodes; ++i)
+        if (net->nodes[i].update) net->nodes[i].update(net, &net->nodes[i]);
+}
+
+/* One fused pass per buffer (reference: axpy/axpy/scal sequence, bcnn_learner.c:67-104). Under data
+ * parallelism the all-reduced gradient is a sum over `world` ranks of (fresh gradient + momentum
+ * carry): the step divides by the GLOBAL batch and leaves momentum*g/world in the buffer, so the next
+ * all-reduce reconstitutes exactly one carry ("momentum trap"). */
+void bcnn_node_sgd_step(bcnn_net *net, bcnn_tensor *weights, bcnn_tensor *biases) {
+    const bcnn_learner *ln = net->learner;
+    const int world = hctx(net)->dp_world;
+    bcnn_hip_sgd_update(weights ? weights->data_gpu : NULL, biases ? biases->data_gpu : NULL,
+                        weights ? weights->grad_data_gpu : NULL, biases ? biases->grad_data_gpu : NULL,
+                        weights ? (size_t)bcnn_tensor_size(weights) : 0, biases ? (size_t)bcnn_tensor_size(biases) : 0,
+                        net->batch_size * world, ln->learning_rate, ln->momentum / (float)world, ln->decay);
+}
+
+static float current_loss(bcnn_net *net) {
+    float loss = 0.f;
+    int n = 0;
+    for (int i = 0; i < net->num_nodes; ++i)
+        if (net->nodes[i].type == BCNN_LAYER_COST) {
+            loss += net->tensors[net->nodes[i].dst[0]].data[0];
+            ++n;
+        }
+    return n ? loss / n : 0.f;
+}
+
+/* data: only the host->device hook of the reference loader is on the path (bcnn_data.c:413-425) */
+bcnn_status bcnn_loader_next(bcnn_net *net) {
+    for (int i = 0; i < net->num_inputs; ++i) {
+        bcnn_tensor *t = &net->tensors[net->inputs[i]];
+        if (t->data && t->data_gpu)
+            bcnn_hip_memcpy_h2d(t->data_gpu, t->data, (size_t)bcnn_tensor_size(t) * sizeof(float));
+    }
+    bcnn_tensor *lab = &net->tensors[1];
+    if (net->mode != BCNN_MODE_PREDICT && lab->data && lab->data_gpu)
+        bcnn_hip_memcpy_h2d(lab->data_gpu, lab->data, (size_t)bcnn_tensor_size(lab) * sizeof(float));
+    return BCNN_SUCCESS;
+}
+
+float bcnn_train_on_batch(bcnn_net *net) {
+    bcnn_loader_next(net);
+    bcnn_forward(net);
+    bcnn_backward(net);
+    bcnn_update(net);
+    return current_loss(net);
+}
+
+float bcnn_predict_on_batch(bcnn_net *net, bcnn_tensor **out) {
+    bcnn_loader_next(net);
+    bcnn_forward(net);
+    const bcnn_node *last = &net->nodes[net->num_nodes - 1];
+    const int out_id = (last->type == BCNN_LAYER_COST) ? last->src[0] : last->dst[0];
+    bcnn_tensor *t = &net->tensors[out_id];
+    bcnn_hip_memcpy_d2h(t->data, t->data_gpu, (size_t)bcnn_tensor_size(t) * sizeof(float));
+    *out = t;
+    return current_loss(net);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * tensor access + sync points
+ * ---------------------------------------------------------------------------------------------- */
+int bcnn_get_tensor_index_by_name(bcnn_net *net, const char *name) { return bcnn_net_find_tensor(net, name); }
+
+bcnn_tensor *bcnn_get_tensor_by_index(bcnn_net *net, int index) {
+    if (index < 0 || index >= net->num_tensors) return NULL;
+    bcnn_download_tensor(net, index, 1); /* refresh host data + grad (reference bcnn_net.c:393-401) */
+    return &net->tensors[index];
+}
+
+bcnn_tensor *bcnn_get_tensor_by_name(bcnn_net *net, const char *name) {
+    return bcnn_get_tensor_by_index(net, bcnn_net_find_tensor(net, name));
+}
+
+bcnn_status bcnn_upload_tensor(bcnn_net *net, int index, int with_grad) {
+    if (index < 0 || index >= net->num_tensors) return BCNN_INVALID_PARAMETER;
+    bcnn_tensor *t = &net->tensors[index];
+    const size_t bytes = (size_t)bcnn_tensor_size(t) * sizeof(float);
+    if (t->data && t->data_gpu) bcnn_hip_memcpy_h2d(t->data_gpu, t->data, bytes);
+    if (with_grad && t->grad_data && t->grad_data_gpu) bcnn_hip_memcpy_h2d(t->grad_data_gpu, t->grad_data, bytes);
+    return BCNN_SUCCESS;
+}
+
+bcnn_status bcnn_download_tensor(bcnn_net *net, int index, int with_grad) {
+    if (index < 0 || index >= net->num_tensors) return BCNN_INVALID_PARAMETER;
+    bcnn_tensor *t = &net->tensors[index];
+    const size_t bytes = (size_t)bcnn_tensor_size(t) * sizeof(float);
+    if (t->data && t->data_gpu) bcnn_hip_memcpy_d2h(t->data, t->data_gpu, bytes);
+    if (with_grad && t->grad_data && t->grad_data_gpu) bcnn_hip_memcpy_d2h(t->grad_data, t->grad_data_gpu, bytes);
+    return BCNN_SUCCESS;
+}
+
+bcnn_tensor *bcnn_peek_tensor(bcnn_net *net, int index) {
+    return (index < 0 || index >= net->num_tensors) ? NULL : &net->tensors[index];
+}
+
+int bcnn_get_num_nodes(bcnn_net *net) { return net->num_nodes; }
+
+int bcnn_get_node_tensor(bcnn_net *net, int node, int is_dst, int slot) {
+    if (node < 0 || node >= net->num_nodes || slot < 0) return -1;
+    const bcnn_node *nd = &net->nodes[node];
+    if (is_dst) return slot < nd->num_dst ? nd->dst[slot] : -1;
+    return slot < nd->num_src ? nd->src[slot] : -1;
+}
+
+void *bcnn_get_node_state(bcnn_net *net, int node, int which) {
+    if (node < 0 || node >= net->num_nodes) return NULL;
+    const bcnn_node *nd = &net->nodes[node];
+    const bcnn_tensor *sm = NULL, *sv = NULL;
+    if (nd->type == BCNN_LAYER_MAXPOOL) return which == 0 ? (void *)((bcnn_maxpool_param *)nd->param)->indexes_gpu : NULL;
+    if (nd->type == BCNN_LAYER_CONV2D && ((bcnn_conv_param *)nd->param)->batch_norm) {
+        sm = &((bcnn_conv_param *)nd->param)->saved_mean;
+        sv = &((bcnn_conv_param *)nd->param)->saved_variance;
+    } else if (nd->type == BCNN_LAYER_BATCHNORM) {
+        sm = &((bcnn_batchnorm_param *)nd->param)->saved_mean;
+        sv = &((bcnn_batchnorm_param *)nd->param)->saved_variance;
+    }
+    if (!sm) return NULL;
+    switch (which) {
+        case 1: return sm->data_gpu;
+        case 2: return sv->data_gpu;
+        case 3: return sm->grad_data_gpu;
+        case 4: return sv->grad_data_gpu;
+    }
+    return NULL;
+}
+
+void bcnn_synchronize(bcnn_net *net) {
+    (void)net;
+    bcnn_hip_sync();
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * data parallel helpers
+ * ---------------------------------------------------------------------------------------------- */
+bcnn_status bcnn_set_data_parallel(bcnn_net *net, int rank, int world_size) {
+    if (world_size < 1 || rank < 0 || rank >= world_size) return BCNN_INVALID_PARAMETER;
+    hctx(net)->dp_rank = rank;
+    hctx(net)->dp_world = world_size;
+    return BCNN_SUCCESS;
+}
+
+float *bcnn_get_gradient_arena(bcnn_net *net, size_t *num_floats) {
+    if (num_floats) *num_floats = hctx(net)->arena_size;
+    return hctx(net)->grad_arena_gpu;
+}
+
+float *bcnn_get_parameter_arena(bcnn_net *net, size_t *num_floats) {
+    if (num_floats) *num_floats = hctx(net)->arena_size;
+    return hctx(net)->param_arena_gpu;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * learner set-up (reference bcnn_learner.c:177-225; neither setter touches learner->optimizer,
+ * so API users always train with SGD -- quirk 6 of SURVEY.md)
+ * ---------------------------------------------------------------------------------------------- */
+static bcnn_learner *learner_of(bcnn_net *net) {
+    if (!net->learner) net->learner = (bcnn_learner *)calloc(1, sizeof(bcnn_learner));
+    return net->learner;
+}
+
+void bcnn_set_learning_rate_policy(bcnn_net *net, bcnn_lr_decay decay_type, float gamma, float scale, float power,
+                                   int max_batches, int step) {
+    bcnn_learner *ln = learner_of(net);
+    ln->decay_type = decay_type; ln->gamma = gamma; ln->scale = scale; ln->power = power;
+    ln->max_batches = max_batches; ln->step = step;
+}
+
+void bcnn_set_adam_optimizer(bcnn_net *net, float learning_rate, float beta1, float beta2) {
+    bcnn_learner *ln = learner_of(net);
+    ln->base_learning_rate = ln->learning_rate = learning_rate;
+    ln->beta1 = beta1; ln->beta2 = beta2;
+    ln->momentum = 0.9f;
+}
+
+void bcnn_set_sgd_optimizer(bcnn_net *net, float learning_rate, float momentum) {
+    bcnn_learner *ln = learner_of(net);
+    ln->base_learning_rate = ln->learning_rate = learning_rate;
+    ln->momentum = momentum;
+}
+
+void bcnn_set_weight_regularizer(bcnn_net *net, float weight_decay) { learner_of(net)->decay = weight_decay; }

@@ -1,0 +1,442 @@
+/*
+ * bcnn_layers_hot.c -- builders and node workers of the hot-path operators (conv, depthwise conv,
+ * batch-norm, max/avg pooling, activation) of the MI355X build. Each worker has the reference's
+ * plug-in signature `void f(bcnn_net*, bcnn_node*)` and tensor-index conventions
+ * (conv: src = {x, W, b [, run_mean, run_var, scales] [, prelu slopes]}, bcnn_conv_layer.c:368-387;
+ *  batch-norm: src = {x, run_mean, run_var, scales, biases}, bcnn_batchnorm_layer.c:247-250)
+ * and makes ONE whole-batch call into the C-ABI (include/bcnn_hip.h) per direction.
+ *
+ * Builder behaviour follows: bcnn_conv_layer.c:45-365, bcnn_depthwise_conv_layer.c:42-163,
+ * bcnn_batchnorm_layer.c:36-145, bcnn_maxpool_layer.c:40-143, bcnn_avgpool_layer.c:33-80,
+ * bcnn_activation_layer.c:36-88 (tensor names "<src>_w", "<src>_b", "<src>_run_mean", ... included,
+ * because bcnn_get_tensor_by_name and the weight files rely on them).
+ */
+#include <math.h>
+#include <string.h>
+
+#include "bcnn_internal.h"
+#include "../../include/bcnn_hip.h"
+
+static bcnn_hip_context *hctx(bcnn_net *net) { return (bcnn_hip_context *)net->hip_ctx; }
+
+/* Resolve the source tensor of a new node: tensor 0 for the first node, else newest tensor of that name. */
+static bcnn_status attach_source(bcnn_net *net, bcnn_node *node, const char *src_id, const char *what) {
+    if (net->num_nodes == 0) return bcnn_node_add_input(net, node, 0);
+    const int idx = bcnn_net_find_tensor(net, src_id);
+    BCNN_CHECK_AND_LOG(net->log_ctx, idx >= 0, BCNN_INVALID_PARAMETER, "%s layer: invalid input node name %s\n",
+                       what, src_id);
+    return bcnn_node_add_input(net, node, idx);
+}
+
+/* creates a [1,1,1,count] parameter tensor, registers it with the node (and the arena if trainable) */
+static bcnn_status add_vector_param(bcnn_net *net, bcnn_node *node, int count, int has_grad, const char *src_id,
+                                    const char *suffix, float fill, int trainable) {
+    char name[256];
+    snprintf(name, sizeof(name), "%s_%s", src_id, suffix);
+    bcnn_tensor t = {0};
+    bcnn_tensor_create(&t, 1, 1, 1, count, has_grad, name, net->mode);
+    if (fill != 0.0f) {
+        bcnn_tensor_filler f = {.value = fill, .type = BCNN_FILLER_FIXED};
+        bcnn_tensor_fill(&t, f);
+    }
+    BCNN_CHECK_STATUS(bcnn_net_add_tensor(net, t));
+    BCNN_CHECK_STATUS(bcnn_node_add_input(net, node, net->num_tensors - 1));
+    if (trainable) bcnn_net_register_param(net, net->num_tensors - 1);
+    return BCNN_SUCCESS;
+}
+
+static bcnn_status add_output(bcnn_net *net, bcnn_node *node, int n, int c, int h, int w, const char *dst_id) {
+    bcnn_tensor t = {0};
+    bcnn_tensor_set_shape(&t, n, c, h, w, 1);
+    BCNN_CHECK_STATUS(bcnn_tensor_allocate(&t, net->mode));
+    t.name = (char *)malloc(strlen(dst_id) + 1);
+    strcpy(t.name, dst_id);
+    BCNN_CHECK_STATUS(bcnn_net_add_tensor(net, t));
+    return bcnn_node_add_output(net, node, net->num_tensors - 1);
+}
+
+/* ================================================================================================
+ * convolution (+ fused batch-norm, + fused activation)
+ * ============================================================================================== */
+bcnn_status bcnn_add_convolutional_layer(bcnn_net *net, int num_filters, int size, int stride, int pad,
+                                         int num_groups, int batch_norm, bcnn_filler_type init,
+                                         bcnn_activation activation, int quantize, const char *src_id,
+                                         const char *dst_id) {
+    (void)quantize;
+    bcnn_node node = {0};
+    if (net->num_nodes == 0)
+        BCNN_CHECK_AND_LOG(net->log_ctx, bcnn_tensor_size(&net->tensors[0]) > 0, BCNN_INVALID_PARAMETER,
+                           "Invalid input size of the network. Hint: use 'bcnn_set_input_shape'\n");
+    BCNN_CHECK_STATUS(attach_source(net, &node, src_id, "Convolution"));
+    const int sn = net->tensors[node.src[0]].n, sc = net->tensors[node.src[0]].c;
+    const int sh = net->tensors[node.src[0]].h, sw = net->tensors[node.src[0]].w;
+    BCNN_CHECK_AND_LOG(net->log_ctx, num_groups > 0 && sc % num_groups == 0, BCNN_INVALID_PARAMETER,
+                       "Number of input channels has to be a multiple of the number of groups\n");
+    BCNN_CHECK_AND_LOG(net->log_ctx, num_filters % num_groups == 0, BCNN_INVALID_PARAMETER,
+                       "Number of output channels has to be a multiple of the number of groups\n");
+    const int cg = sc / num_groups;
+
+    char name[256];
+    snprintf(name, sizeof(name), "%s_w", src_id);
+    bcnn_tensor weights = {0};
+    bcnn_tensor_create(&weights, num_filters, cg, size, size, 1, name, net->mode);
+    bcnn_tensor_filler wf = {.range = size * size * cg, .type = init};
+    bcnn_tensor_fill(&weights, wf);
+    BCNN_CHECK_STATUS(bcnn_net_add_tensor(net, weights));
+    BCNN_CHECK_STATUS(bcnn_node_add_input(net, &node, net->num_tensors - 1));
+    bcnn_net_register_param(net, net->num_tensors - 1);
+    BCNN_CHECK_STATUS(add_vector_param(net, &node, num_filters, 1, src_id, "b", 0.0f, 1));
+
+    node.type = BCNN_LAYER_CONV2D;
+    node.param_size = sizeof(bcnn_conv_param);
+    bcnn_conv_param *param = (bcnn_conv_param *)calloc(1, node.param_size);
+    node.param = param;
+    param->activation = activation;
+    param->pad = pad; param->num = num_filters; param->size = size; param->stride = stride;
+    param->num_groups = num_groups;
+    node.forward = bcnn_forward_conv_layer;
+    node.backward = bcnn_backward_conv_layer;
+    node.update = bcnn_update_conv_layer;
+    node.release_param = bcnn_release_param_conv_layer;
+
+    const int oh = (sh + 2 * pad - size) / stride + 1, ow = (sw + 2 * pad - size) / stride + 1;
+    BCNN_CHECK_STATUS(add_output(net, &node, sn, num_filters, oh, ow, dst_id));
+    if (batch_norm) {
+        param->batch_norm = 1;
+        snprintf(name, sizeof(name), "%s_sav_mean", src_id);
+        bcnn_tensor_create(&param->saved_mean, 1, 1, 1, num_filters, 1, name, net->mode);
+        snprintf(name, sizeof(name), "%s_sav_var", src_id);
+        bcnn_tensor_create(&param->saved_variance, 1, 1, 1, num_filters, 1, name, net->mode);
+        BCNN_CHECK_STATUS(add_vector_param(net, &node, num_filters, 0, src_id, "run_mean", 0.0f, 0));
+        BCNN_CHECK_STATUS(add_vector_param(net, &node, num_filters, 0, src_id, "run_var", 0.0f, 0));
+        /* scales accumulate a gradient but no update function ever applies it (reference
+         * bcnn_conv_layer.c:810-855 updates weights and biases only) -- kept out of the arena */
+        BCNN_CHECK_STATUS(add_vector_param(net, &node, num_filters, 1, src_id, "scales", 1.0f, 0));
+        if (net->mode != BCNN_MODE_PREDICT)
+            param->bn_workspace_gpu = bcnn_hip_malloc_f32((size_t)sn * num_filters * oh * ow);
+    }
+    if (activation == BCNN_ACT_PRELU)
+        BCNN_CHECK_STATUS(add_vector_param(net, &node, num_filters, 0, src_id, "prelu_slopes", 0.0f, 0));
+    BCNN_CHECK_STATUS(bcnn_net_add_node(net, node));
+    BCNN_INFO(net->log_ctx, "[Conv2D%s%s] %-8s (%4d x%4d x%4d) -> %-8s (%4d x%4d x%4d) %d x %d / %d pad %d groups %d\n",
+              batch_norm ? "+BN" : "", activation != BCNN_ACT_NONE ? "+act" : "", src_id, sw, sh, sc, dst_id, ow, oh,
+              num_filters, size, size, stride, pad, num_groups);
+    return BCNN_SUCCESS;
+}
+
+typedef struct {
+    bcnn_tensor *x, *w, *b, *y, *run_mean, *run_var, *scales, *slopes;
+} conv_io;
+
+static conv_io conv_tensors(bcnn_net *net, bcnn_node *node) {
+    conv_io io = {0};
+    bcnn_conv_param *p = (bcnn_conv_param *)node->param;
+    io.x = &net->tensors[node->src[0]];
+    io.w = &net->tensors[node->src[1]];
+    io.b = &net->tensors[node->src[2]];
+    io.y = &net->tensors[node->dst[0]];
+    if (p->batch_norm) {
+        io.run_mean = &net->tensors[node->src[3]];
+        io.run_var = &net->tensors[node->src[4]];
+        io.scales = &net->tensors[node->src[5]];
+    }
+    if (p->activation == BCNN_ACT_PRELU) io.slopes = &net->tensors[node->src[3 + 3 * p->batch_norm]];
+    return io;
+}
+
+void bcnn_forward_conv_layer(bcnn_net *net, bcnn_node *node) {
+    bcnn_conv_param *p = (bcnn_conv_param *)node->param;
+    conv_io io = conv_tensors(net, node);
+    bcnn_hip_conv_forward(io.x->data_gpu, io.w->data_gpu, io.b->data_gpu, io.y->data_gpu, io.x->n, io.x->c, io.x->h,
+                          io.x->w, p->num, p->size, p->stride, p->pad, p->num_groups, (int)p->activation,
+                          io.slopes ? io.slopes->data_gpu : NULL, p->batch_norm,
+                          io.run_mean ? io.run_mean->data_gpu : NULL, io.run_var ? io.run_var->data_gpu : NULL,
+                          io.scales ? io.scales->data_gpu : NULL, p->saved_mean.data_gpu,
+                          p->saved_variance.data_gpu, p->x_norm_gpu, p->bn_workspace_gpu, (int)net->mode);
+}
+
+void bcnn_backward_conv_layer(bcnn_net *net, bcnn_node *node) {
+    bcnn_conv_param *p = (bcnn_conv_param *)node->param;
+    conv_io io = conv_tensors(net, node);
+    bcnn_hip_conv_backward(io.x->data_gpu, io.w->data_gpu, io.y->data_gpu, io.y->grad_data_gpu,
+                           io.x->grad_data_gpu /* NULL for the net input: no dX */, io.w->grad_data_gpu,
+                           io.b->grad_data_gpu, io.x->n, io.x->c, io.x->h, io.x->w, p->num, p->size, p->stride,
+                           p->pad, p->num_groups, (int)p->activation, io.slopes ? io.slopes->data_gpu : NULL,
+                           io.slopes ? io.slopes->grad_data_gpu : NULL, p->batch_norm,
+                           io.scales ? io.scales->data_gpu : NULL, io.scales ? io.scales->grad_data_gpu : NULL,
+                           p->saved_mean.data_gpu, p->saved_variance.data_gpu, p->saved_mean.grad_data_gpu,
+                           p->saved_variance.grad_data_gpu, p->x_norm_gpu, p->bn_workspace_gpu,
+                           p->conv_workspace_gpu, hctx(net)->workspace_size);
+}
+
+void bcnn_update_conv_layer(bcnn_net *net, bcnn_node *node) {
+    if (net->learner->optimizer != BCNN_OPTIM_SGD) return; /* Adam: out of scope (only reachable via INI) */
+    bcnn_node_sgd_step(net, &net->tensors[node->src[1]], &net->tensors[node->src[2]]);
+}
+
+void bcnn_release_param_conv_layer(bcnn_node *node) {
+    bcnn_conv_param *p = (bcnn_conv_param *)node->param;
+    bcnn_tensor_destroy(&p->saved_mean);
+    bcnn_tensor_destroy(&p->saved_variance);
+    bcnn_hip_free(p->bn_workspace_gpu);
+    bcnn_hip_free(p->x_norm_gpu);
+}
+
+/* ================================================================================================
+ * depthwise convolution
+ * ============================================================================================== */
+bcnn_status bcnn_add_depthwise_conv_layer(bcnn_net *net, int size, int stride, int pad, int batch_norm,
+                                          bcnn_filler_type init, bcnn_activation activation, const char *src_id,
+                                          const char *dst_id) {
+    (void)batch_norm; /* ignored by the reference as well (bcnn_depthwise_conv_layer.c:42-163) */
+    bcnn_node node = {0};
+    BCNN_CHECK_STATUS(attach_source(net, &node, src_id, "Depthwise convolution"));
+    const bcnn_tensor s = net->tensors[node.src[0]];
+    char name[256];
+    snprintf(name, sizeof(name), "%s_w", src_id);
+    bcnn_tensor weights = {0};
+    bcnn_tensor_create(&weights, 1, 1, 1, s.c * size * size, 1, name, net->mode); /* laid out [C][k][k] */
+    bcnn_tensor_filler wf = {.range = size * size * s.c, .type = init};
+    bcnn_tensor_fill(&weights, wf);
+    BCNN_CHECK_STATUS(bcnn_net_add_tensor(net, weights));
+    BCNN_CHECK_STATUS(bcnn_node_add_input(net, &node, net->num_tensors - 1));
+    bcnn_net_register_param(net, net->num_tensors - 1);
+    BCNN_CHECK_STATUS(add_vector_param(net, &node, s.c, 1, src_id, "b", 0.0f, 1));
+    node.type = BCNN_LAYER_DEPTHWISE_CONV2D;
+    node.param_size = sizeof(bcnn_depthwise_conv_param);
+    bcnn_depthwise_conv_param *param = (bcnn_depthwise_conv_param *)calloc(1, node.param_size);
+    node.param = param;
+    param->activation = activation; param->size = size; param->stride = stride; param->pad = pad;
+    node.forward = bcnn_forward_depthwise_conv_layer;
+    node.backward = bcnn_backward_depthwise_conv_layer;
+    node.update = bcnn_update_depthwise_conv_layer;
+    const int oh = (s.h + 2 * pad - size) / stride + 1, ow = (s.w + 2 * pad - size) / stride + 1;
+    BCNN_CHECK_STATUS(add_output(net, &node, s.n, s.c, oh, ow, dst_id));
+    BCNN_CHECK_STATUS(bcnn_net_add_node(net, node));
+    BCNN_INFO(net->log_ctx, "[DepthwiseConv2D] %-8s (%4d x%4d x%4d) -> %-8s (%4d x%4d x%4d) %d x %d / %d\n", src_id,
+              s.w, s.h, s.c, dst_id, ow, oh, s.c, size, size, stride);
+    return BCNN_SUCCESS;
+}
+
+void bcnn_forward_depthwise_conv_layer(bcnn_net *net, bcnn_node *node) {
+    bcnn_depthwise_conv_param *p = (bcnn_depthwise_conv_param *)node->param;
+    bcnn_tensor *x = &net->tensors[node->src[0]], *w = &net->tensors[node->src[1]];
+    bcnn_tensor *b = &net->tensors[node->src[2]], *y = &net->tensors[node->dst[0]];
+    bcnn_hip_depthwise_forward(x->data_gpu, w->data_gpu, b->data_gpu, y->data_gpu, x->n, x->c, x->h, x->w, p->size,
+                               p->stride, p->pad, (int)p->activation);
+}
+
+void bcnn_backward_depthwise_conv_layer(bcnn_net *net, bcnn_node *node) {
+    bcnn_depthwise_conv_param *p = (bcnn_depthwise_conv_param *)node->param;
+    bcnn_tensor *x = &net->tensors[node->src[0]], *w = &net->tensors[node->src[1]];
+    bcnn_tensor *b = &net->tensors[node->src[2]], *y = &net->tensors[node->dst[0]];
+    bcnn_hip_depthwise_backward(x->data_gpu, w->data_gpu, y->data_gpu, y->grad_data_gpu, x->grad_data_gpu,
+                                w->grad_data_gpu, b->grad_data_gpu, x->n, x->c, x->h, x->w, p->size, p->stride,
+                                p->pad, (int)p->activation);
+}
+
+void bcnn_update_depthwise_conv_layer(bcnn_net *net, bcnn_node *node) {
+    if (net->learner->optimizer != BCNN_OPTIM_SGD) return;
+    bcnn_node_sgd_step(net, &net->tensors[node->src[1]], &net->tensors[node->src[2]]);
+}
+
+/* ================================================================================================
+ * stand-alone batch normalisation
+ * ============================================================================================== */
+bcnn_status bcnn_add_batchnorm_layer(bcnn_net *net, const char *src_id, const char *dst_id) {
+    bcnn_node node = {0};
+    BCNN_CHECK_AND_LOG(net->log_ctx, net->num_nodes >= 1, BCNN_INVALID_PARAMETER,
+                       "Batchnorm layer can't be the first layer of the network\n");
+    BCNN_CHECK_STATUS(attach_source(net, &node, src_id, "Batchnorm"));
+    const bcnn_tensor s = net->tensors[node.src[0]];
+    BCNN_CHECK_STATUS(add_output(net, &node, s.n, s.c, s.h, s.w, dst_id));
+    node.type = BCNN_LAYER_BATCHNORM;
+    node.param_size = sizeof(bcnn_batchnorm_param);
+    bcnn_batchnorm_param *param = (bcnn_batchnorm_param *)calloc(1, node.param_size);
+    node.param = param;
+    node.forward = bcnn_forward_batchnorm_layer;
+    node.backward = bcnn_backward_batchnorm_layer;
+    node.release_param = bcnn_release_param_batchnorm_layer;
+    char name[256];
+    snprintf(name, sizeof(name), "%s_sav_mean", src_id);
+    bcnn_tensor_create(&param->saved_mean, 1, 1, 1, s.c, 1, name, net->mode);
+    snprintf(name, sizeof(name), "%s_sav_var", src_id);
+    bcnn_tensor_create(&param->saved_variance, 1, 1, 1, s.c, 1, name, net->mode);
+    BCNN_CHECK_STATUS(add_vector_param(net, &node, s.c, 0, src_id, "run_mean", 0.0f, 0));
+    BCNN_CHECK_STATUS(add_vector_param(net, &node, s.c, 0, src_id, "run_var", 0.0f, 0));
+    BCNN_CHECK_STATUS(add_vector_param(net, &node, s.c, 1, src_id, "scales", 1.0f, 0));
+    BCNN_CHECK_STATUS(add_vector_param(net, &node, s.c, 1, src_id, "b", 0.0f, 0));
+    if (net->mode != BCNN_MODE_PREDICT) param->workspace_gpu = bcnn_hip_malloc_f32((size_t)bcnn_tensor_size(&s));
+    BCNN_CHECK_STATUS(bcnn_net_add_node(net, node));
+    BCNN_INFO(net->log_ctx, "[Batchnorm] %-8s (%4d x%4d x%4d) -> %-8s\n", src_id, s.w, s.h, s.c, dst_id);
+    return BCNN_SUCCESS;
+}
+
+void bcnn_forward_batchnorm_layer(bcnn_net *net, bcnn_node *node) {
+    bcnn_batchnorm_param *p = (bcnn_batchnorm_param *)node->param;
+    bcnn_tensor *x = &net->tensors[node->src[0]], *y = &net->tensors[node->dst[0]];
+    bcnn_hip_batchnorm_forward(x->data_gpu, y->data_gpu, net->tensors[node->src[1]].data_gpu,
+                               net->tensors[node->src[2]].data_gpu, net->tensors[node->src[3]].data_gpu,
+                               net->tensors[node->src[4]].data_gpu, p->saved_mean.data_gpu,
+                               p->saved_variance.data_gpu, p->x_norm_gpu, p->workspace_gpu, x->n, x->c, x->h * x->w,
+                               (int)net->mode, BCNN_HIP_ACT_NONE);
+}
+
+void bcnn_backward_batchnorm_layer(bcnn_net *net, bcnn_node *node) {
+    bcnn_batchnorm_param *p = (bcnn_batchnorm_param *)node->param;
+    bcnn_tensor *x = &net->tensors[node->src[0]], *y = &net->tensors[node->dst[0]];
+    bcnn_tensor *scales = &net->tensors[node->src[3]], *biases = &net->tensors[node->src[4]];
+    /* VALID-mode backward would use the running statistics (reference :306-309); only TRAIN is meaningful */
+    bcnn_hip_batchnorm_backward(y->grad_data_gpu, x->grad_data_gpu, NULL, BCNN_HIP_ACT_NONE, scales->data_gpu,
+                                scales->grad_data_gpu, biases->grad_data_gpu, p->saved_mean.data_gpu,
+                                p->saved_variance.data_gpu, p->saved_mean.grad_data_gpu,
+                                p->saved_variance.grad_data_gpu, p->x_norm_gpu, p->workspace_gpu, x->n, x->c,
+                                x->h * x->w);
+}
+
+void bcnn_release_param_batchnorm_layer(bcnn_node *node) {
+    bcnn_batchnorm_param *p = (bcnn_batchnorm_param *)node->param;
+    bcnn_tensor_destroy(&p->saved_mean);
+    bcnn_tensor_destroy(&p->saved_variance);
+    bcnn_hip_free(p->workspace_gpu);
+    bcnn_hip_free(p->x_norm_gpu);
+}
+
+/* ================================================================================================
+ * pooling
+ * ============================================================================================== */
+static int pooled_extent(int in, int size, int stride, bcnn_padding padding) {
+    switch (padding) { /* reference bcnn_maxpool_layer.c:62-83 */
+        case BCNN_PADDING_SAME: return (in + stride - 1) / stride;
+        case BCNN_PADDING_VALID: return (in - size + stride) / stride;
+        case BCNN_PADDING_CAFFE: return (int)(ceil((float)(in - size) / stride)) + 1;
+    }
+    return 0;
+}
+
+bcnn_status bcnn_add_maxpool_layer(bcnn_net *net, int size, int stride, bcnn_padding padding, const char *src_id,
+                                   const char *dst_id) {
+    bcnn_node node = {0};
+    BCNN_CHECK_STATUS(attach_source(net, &node, src_id, "Maxpool"));
+    const bcnn_tensor s = net->tensors[node.src[0]];
+    const int oh = pooled_extent(s.h, size, stride, padding), ow = pooled_extent(s.w, size, stride, padding);
+    BCNN_CHECK_STATUS(add_output(net, &node, s.n, s.c, oh, ow, dst_id));
+    node.type = BCNN_LAYER_MAXPOOL;
+    node.param_size = sizeof(bcnn_maxpool_param);
+    bcnn_maxpool_param *param = (bcnn_maxpool_param *)calloc(1, node.param_size);
+    node.param = param;
+    param->size = size; param->stride = stride; param->padding = padding;
+    const size_t sz = (size_t)s.n * s.c * oh * ow;
+    param->indexes = (int *)calloc(sz, sizeof(int));
+    param->indexes_gpu = bcnn_hip_malloc_i32(sz);
+    node.forward = bcnn_forward_maxpool_layer;
+    node.backward = bcnn_backward_maxpool_layer;
+    node.release_param = bcnn_release_param_maxpool_layer;
+    BCNN_CHECK_STATUS(bcnn_net_add_node(net, node));
+    BCNN_INFO(net->log_ctx, "[Maxpool] %-8s (%4d x%4d x%4d) -> %-8s (%4d x%4d x%4d) %d x %d / %d\n", src_id, s.w, s.h,
+              s.c, dst_id, ow, oh, s.c, size, size, stride);
+    return BCNN_SUCCESS;
+}
+
+void bcnn_forward_maxpool_layer(bcnn_net *net, bcnn_node *node) {
+    bcnn_maxpool_param *p = (bcnn_maxpool_param *)node->param;
+    bcnn_tensor *x = &net->tensors[node->src[0]], *y = &net->tensors[node->dst[0]];
+    bcnn_hip_maxpool_forward(x->data_gpu, y->data_gpu, p->indexes_gpu, x->n, x->c, x->h, x->w, y->h, y->w, p->size,
+                             p->stride);
+}
+
+void bcnn_backward_maxpool_layer(bcnn_net *net, bcnn_node *node) {
+    bcnn_maxpool_param *p = (bcnn_maxpool_param *)node->param;
+    bcnn_tensor *x = &net->tensors[node->src[0]], *y = &net->tensors[node->dst[0]];
+    if (!x->grad_data_gpu) return;
+    bcnn_hip_maxpool_backward(y->grad_data_gpu, p->indexes_gpu, x->grad_data_gpu, x->n, x->c, x->h, x->w, y->h, y->w,
+                              p->size, p->stride);
+}
+
+void bcnn_release_param_maxpool_layer(bcnn_node *node) {
+    bcnn_maxpool_param *p = (bcnn_maxpool_param *)node->param;
+    free(p->indexes);
+    bcnn_hip_free(p->indexes_gpu);
+}
+
+bcnn_status bcnn_add_avgpool_layer(bcnn_net *net, const char *src_id, const char *dst_id) {
+    bcnn_node node = {0};
+    BCNN_CHECK_STATUS(attach_source(net, &node, src_id, "Avgpool"));
+    const bcnn_tensor s = net->tensors[node.src[0]];
+    BCNN_CHECK_STATUS(add_output(net, &node, s.n, s.c, 1, 1, dst_id));
+    node.type = BCNN_LAYER_AVGPOOL;
+    node.forward = bcnn_forward_avgpool_layer;
+    node.backward = bcnn_backward_avgpool_layer;
+    BCNN_CHECK_STATUS(bcnn_net_add_node(net, node));
+    BCNN_INFO(net->log_ctx, "[Avgpool] %-8s (%4d x%4d x%4d) -> %-8s (1 x 1 x %d)\n", src_id, s.w, s.h, s.c, dst_id, s.c);
+    return BCNN_SUCCESS;
+}
+
+void bcnn_forward_avgpool_layer(bcnn_net *net, bcnn_node *node) {
+    bcnn_tensor *x = &net->tensors[node->src[0]], *y = &net->tensors[node->dst[0]];
+    bcnn_hip_avgpool_forward(x->data_gpu, y->data_gpu, x->n, x->c, x->h, x->w);
+}
+
+void bcnn_backward_avgpool_layer(bcnn_net *net, bcnn_node *node) {
+    bcnn_tensor *x = &net->tensors[node->src[0]], *y = &net->tensors[node->dst[0]];
+    if (!x->grad_data_gpu) return;
+    bcnn_hip_avgpool_backward(y->grad_data_gpu, x->grad_data_gpu, x->n, x->c, x->h, x->w);
+}
+
+/* ================================================================================================
+ * stand-alone activation node (in place: src index == dst index, bcnn_activation_layer.c:46-47).
+ * The reference's CPU worker dereferences a NULL weights tensor for every non-PReLU activation
+ * (:152-160); here the node simply works for all of them.
+ * ============================================================================================== */
+bcnn_status bcnn_add_activation_layer(bcnn_net *net, bcnn_activation type, const char *src_id) {
+    bcnn_node node = {0};
+    BCNN_CHECK_AND_LOG(net->log_ctx, net->num_nodes >= 1, BCNN_INVALID_PARAMETER,
+                       "Activation layer can't be the first layer of the network\n");
+    const int idx = bcnn_net_find_tensor(net, src_id);
+    BCNN_CHECK_AND_LOG(net->log_ctx, idx >= 0, BCNN_INVALID_PARAMETER,
+                       "Activation layer: invalid input node name %s\n", src_id);
+    BCNN_CHECK_STATUS(bcnn_node_add_input(net, &node, idx));
+    BCNN_CHECK_STATUS(bcnn_node_add_output(net, &node, idx));
+    node.type = BCNN_LAYER_ACTIVATION;
+    node.param_size = sizeof(bcnn_activation_param);
+    bcnn_activation_param *param = (bcnn_activation_param *)calloc(1, node.param_size);
+    node.param = param;
+    param->activation = type;
+    node.forward = bcnn_forward_activation_layer;
+    node.backward = bcnn_backward_activation_layer;
+    node.update = bcnn_update_activation_layer;
+    if (type == BCNN_ACT_PRELU) {
+        char name[256];
+        snprintf(name, sizeof(name), "%s_w_prelu", src_id);
+        bcnn_tensor slopes = {0};
+        bcnn_tensor_create(&slopes, 1, 1, 1, net->tensors[idx].c, 1, name, net->mode);
+        BCNN_CHECK_STATUS(bcnn_net_add_tensor(net, slopes));
+        BCNN_CHECK_STATUS(bcnn_node_add_input(net, &node, net->num_tensors - 1));
+        bcnn_net_register_param(net, net->num_tensors - 1);
+    }
+    BCNN_CHECK_STATUS(bcnn_net_add_node(net, node));
+    BCNN_INFO(net->log_ctx, "[%s] %-8s (in place)\n", bcnn_act2str(type), src_id);
+    return BCNN_SUCCESS;
+}
+
+void bcnn_forward_activation_layer(bcnn_net *net, bcnn_node *node) {
+    bcnn_activation_param *p = (bcnn_activation_param *)node->param;
+    bcnn_tensor *t = &net->tensors[node->dst[0]];
+    const float *slopes = (p->activation == BCNN_ACT_PRELU) ? net->tensors[node->src[1]].data_gpu : NULL;
+    bcnn_hip_activation_forward(t->data_gpu, (size_t)bcnn_tensor_size(t), (int)p->activation, slopes, t->w * t->h, t->c);
+}
+
+void bcnn_backward_activation_layer(bcnn_net *net, bcnn_node *node) {
+    bcnn_activation_param *p = (bcnn_activation_param *)node->param;
+    bcnn_tensor *t = &net->tensors[node->dst[0]];
+    if (!t->grad_data_gpu) return;
+    bcnn_tensor *sl = (p->activation == BCNN_ACT_PRELU) ? &net->tensors[node->src[1]] : NULL;
+    bcnn_hip_activation_backward(t->data_gpu, t->grad_data_gpu, (size_t)bcnn_tensor_size(t), (int)p->activation,
+                                 sl ? sl->data_gpu : NULL, sl ? sl->grad_data_gpu : NULL, t->w * t->h, t->c);
+}
+
+void bcnn_update_activation_layer(bcnn_net *net, bcnn_node *node) {
+    bcnn_activation_param *p = (bcnn_activation_param *)node->param;
+    if (p->activation != BCNN_ACT_PRELU) return;
+    bcnn_node_sgd_step(net, &net->tensors[node->src[1]], NULL);
+}

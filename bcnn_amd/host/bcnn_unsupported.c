@@ -1,0 +1,101 @@
+/*
+ * bcnn_unsupported.c -- entry points of the public API that lie outside the hot path (SURVEY.md
+ * section 8: control plane, storage, data loaders, detection head, rarely used layers). They exist so
+ * that every consumer of the reference links; each returns BCNN_INVALID_PARAMETER (or does nothing)
+ * and says so in the log. INTEGRATION.md lists them.
+ */
+#include <string.h>
+
+#include "bcnn_internal.h"
+
+#define NOT_BUILT(net, what)                                                                                  \
+    do {                                                                                                      \
+        bcnn_log((net)->log_ctx, BCNN_LOG_ERROR, "%s is outside the MI355X hot-path build (see INTEGRATION.md)\n", \
+                 (what));                                                                                     \
+        return BCNN_INVALID_PARAMETER;                                                                        \
+    } while (0)
+
+bcnn_status bcnn_resize_net(bcnn_net *net, int w, int h, int c, int need_realloc) {
+    (void)w; (void)h; (void)c; (void)need_realloc;
+    NOT_BUILT(net, "bcnn_resize_net");
+}
+bcnn_status bcnn_load_weights(bcnn_net *net, const char *model_path) { (void)model_path; NOT_BUILT(net, "bcnn_load_weights"); }
+bcnn_status bcnn_load_net(bcnn_net *net, const char *config_path, const char *model_path) {
+    (void)config_path; (void)model_path;
+    NOT_BUILT(net, "bcnn_load_net (INI graph loader)");
+}
+bcnn_status bcnn_save_weights(bcnn_net *net, const char *filename) { (void)filename; NOT_BUILT(net, "bcnn_save_weights"); }
+bcnn_status bcnn_set_data_loader(bcnn_net *net, bcnn_loader_type type, const char *a, const char *b, const char *c,
+                                 const char *d) {
+    (void)type; (void)a; (void)b; (void)c; (void)d;
+    NOT_BUILT(net, "bcnn_set_data_loader (dataset readers; feed tensors with bcnn_upload_tensor)");
+}
+void bcnn_augment_data_with_shift(bcnn_net *net, int x, int y) { (void)net; (void)x; (void)y; }
+void bcnn_augment_data_with_scale(bcnn_net *net, float a, float b) { (void)net; (void)a; (void)b; }
+void bcnn_augment_data_with_rotation(bcnn_net *net, float r) { (void)net; (void)r; }
+void bcnn_augment_data_with_flip(bcnn_net *net, int h, int v) { (void)net; (void)h; (void)v; }
+void bcnn_augment_data_with_color_adjustment(bcnn_net *net, int a, int b, float c, float d) {
+    (void)net; (void)a; (void)b; (void)c; (void)d;
+}
+void bcnn_augment_data_with_blobs(bcnn_net *net, int m) { (void)net; (void)m; }
+void bcnn_augment_data_with_distortion(bcnn_net *net, float d) { (void)net; (void)d; }
+
+/* uint8 HWC image -> float CHW, reference bcnn_data.c:70-100 */
+void bcnn_convert_img_to_float(const uint8_t *src, int w, int h, int c, float norm_coeff, int swap_to_bgr,
+                               float mean_r, float mean_g, float mean_b, float *dst) {
+    const float m[3] = {mean_r, mean_g, mean_b};
+    for (int k = 0; k < c; ++k) {
+        const int ks = (swap_to_bgr && c == 3) ? 2 - k : k;
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < w; ++x)
+                dst[(size_t)k * w * h + (size_t)y * w + x] =
+                    ((float)src[((size_t)y * w + x) * c + ks] - (c == 3 ? m[ks] : m[0])) * norm_coeff;
+    }
+}
+
+bcnn_status bcnn_fill_tensor_with_image(bcnn_net *net, const uint8_t *src, int w, int h, int c, float norm_coeff,
+                                        int swap_to_bgr, float mean_r, float mean_g, float mean_b, int tensor_index,
+                                        int batch_index) {
+    if (tensor_index < 0 || tensor_index >= net->num_tensors) return BCNN_INVALID_PARAMETER;
+    bcnn_tensor *t = &net->tensors[tensor_index];
+    if (t->w != w || t->h != h || t->c != c || batch_index < 0 || batch_index >= t->n) return BCNN_INVALID_PARAMETER;
+    bcnn_convert_img_to_float(src, w, h, c, norm_coeff, swap_to_bgr, mean_r, mean_g, mean_b,
+                              t->data + (size_t)batch_index * w * h * c);
+    return bcnn_upload_tensor(net, tensor_index, 0);
+}
+
+void bcnn_draw_color_box(unsigned char *img, int w_img, int h_img, float cx, float cy, float w, float h,
+                         unsigned char color[3]) {
+    (void)img; (void)w_img; (void)h_img; (void)cx; (void)cy; (void)w; (void)h; (void)color;
+}
+
+bcnn_output_detection *bcnn_yolo_get_detections(bcnn_net *net, int batch, int width, int height, int netw, int neth,
+                                                float thresh, int relative, int *num_dets) {
+    (void)net; (void)batch; (void)width; (void)height; (void)netw; (void)neth; (void)thresh; (void)relative;
+    if (num_dets) *num_dets = 0;
+    return NULL;
+}
+
+bcnn_status bcnn_add_deconvolutional_layer(bcnn_net *net, int n, int size, int stride, int pad, bcnn_filler_type init,
+                                           bcnn_activation act, const char *s, const char *d) {
+    (void)n; (void)size; (void)stride; (void)pad; (void)init; (void)act; (void)s; (void)d;
+    NOT_BUILT(net, "deconvolution layer");
+}
+bcnn_status bcnn_add_lrn_layer(bcnn_net *net, int ls, float a, float b, float k, const char *s, const char *d) {
+    (void)ls; (void)a; (void)b; (void)k; (void)s; (void)d;
+    NOT_BUILT(net, "LRN layer");
+}
+bcnn_status bcnn_add_concat_layer(bcnn_net *net, int n, char *const *ids, const char *d) {
+    (void)n; (void)ids; (void)d;
+    NOT_BUILT(net, "concat layer");
+}
+bcnn_status bcnn_add_dropout_layer(bcnn_net *net, float rate, const char *id) { (void)rate; (void)id; NOT_BUILT(net, "dropout layer"); }
+bcnn_status bcnn_add_upsample_layer(bcnn_net *net, int size, const char *s, const char *d) {
+    (void)size; (void)s; (void)d;
+    NOT_BUILT(net, "upsample layer");
+}
+bcnn_status bcnn_add_yolo_layer(bcnn_net *net, int nb, int nc, int coords, int total, int *mask, float *anchors,
+                                const char *s, const char *d) {
+    (void)nb; (void)nc; (void)coords; (void)total; (void)mask; (void)anchors; (void)s; (void)d;
+    NOT_BUILT(net, "YOLOv3 head");
+}

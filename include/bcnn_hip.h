@@ -199,6 +199,23 @@ void bcnn_hip_sgd_update(float *w_d, float *b_d, float *dw_d, float *db_d, size_
                          size_t b_size, int batch_size, float learning_rate, float momentum,
                          float decay);
 
+/* ---------------------------------------------------------------------------------------------
+ * "Next" rows: the nodes either side of the hot path that a ResNet-style
+ * graph needs, kept on the device so that a training step has no host round trip.
+ *   axpy_strided : bcnn_axpy_strided (bcnn_mat.c:159-177), the residual add of the eltwise node for
+ *                  operands of different spatial size / depth (bcnn_eltwise_layer.c:119-150);
+ *                  y[n][k][j*sy][i*sy] += a * x[n][k][j*sx][i*sx] over min_dim = {c,h,w}.
+ *   add_rowvec   : y[r][:] += v[:] for r < rows (bias add of the full-connected node,
+ *                  bcnn_fc_layer.c:170-172; plain axpy, no 0/1 quirk).
+ *   softmax      : bcnn_forward_softmax_layer_cpu (bcnn_softmax_layer.c:88-155), log-sum-exp form,
+ *                  over c for every (n, spatial position).
+ * ------------------------------------------------------------------------------------------- */
+void bcnn_hip_axpy_strided(int num_batches, float a, const float *x_d, float *y_d, int stride_y,
+                           int stride_x, int x_c, int x_h, int x_w, int y_c, int y_h, int y_w, int min_c,
+                           int min_h, int min_w);
+void bcnn_hip_add_rowvec(float *y_d, const float *v_d, int rows, int cols);
+void bcnn_hip_softmax_forward(const float *x_d, float *y_d, int n, int c, int hw);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,172 @@
+"""GPU parity at the bcnn_net / bcnn_node level: the same graph is built through the PUBLIC C API on
+ (1) the unmodified reference (oracle/_ref/libbcnn_ref.so, CPU, driven by oracle/ref_bind.py) and
+ (2) this repo's libbcnn.so (C99 host + HIP back-end, driven by bcnn_amd/capi.py),
+with identical parameters and inputs; every tensor's data and gradient is compared after
+forward / backward / SGD update. This is the drop-in check of SURVEY.md section 8b."""
+import numpy as np
+import pytest
+import torch  # noqa: F401  (first, so that one HIP runtime serves torch and libbcnn_hip.so)
+
+from oracle import ref_bind as rb
+from tests import _golden as G
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-4
+
+
+def _need_ref():
+    if not rb.available():
+        pytest.skip("oracle/_ref/libbcnn_ref.so not present (built from /root/reference by oracle/Makefile)")
+
+
+def stack_graph(net):
+    """conv(3->16, relu) -> BN -> maxpool 3/2 SAME -> avgpool (the SURVEY.md section 8c agreement stack)"""
+    net.conv(16, 3, 1, 1, 1, 0, rb.ACT_RELU, "input", "c1")
+    net.batchnorm("c1", "bn1")
+    net.maxpool(3, 2, rb.PADDING_SAME, "bn1", "p1")
+    net.avgpool("p1", "avg")
+
+
+def resnet_block_graph(net):
+    """stem conv+BN+relu, a residual block with identity shortcut, a down-sampling block with the 1x1/s2
+    projection (quirk 1) -- the topology of examples/cifar10/cifar10_example.c:65-143 in miniature --
+    then avgpool, fc, softmax, cost."""
+    net.conv(8, 3, 1, 1, 1, 1, rb.ACT_RELU, "input", "stem")
+    net.conv(8, 3, 1, 1, 1, 1, rb.ACT_RELU, "stem", "b1c1")
+    net.conv(8, 3, 1, 1, 1, 1, rb.ACT_NONE, "b1c1", "b1c2")
+    net.eltwise(rb.ACT_RELU, "stem", "b1c2", "b1")
+    net.conv(16, 3, 2, 1, 1, 1, rb.ACT_RELU, "b1", "b2c1")
+    net.conv(16, 3, 1, 1, 1, 1, rb.ACT_NONE, "b2c1", "b2c2")
+    net.conv(16, 1, 2, 0, 1, 1, rb.ACT_NONE, "b1", "b2p")
+    net.eltwise(rb.ACT_RELU, "b2p", "b2c2", "b2")
+    net.avgpool("b2", "avg")
+    net.fullc(10, rb.ACT_NONE, "avg", "fc")
+    net.softmax("fc", "sm")
+    net.cost("sm", "label", "cost", 1.0)
+
+
+def lenet_graph(net):
+    """examples/mnist/mnist_example.c:30-55"""
+    net.conv(8, 3, 1, 1, 1, 0, rb.ACT_RELU, "input", "conv1")
+    net.batchnorm("conv1", "bn1")
+    net.maxpool(2, 2, rb.PADDING_SAME, "bn1", "pool1")
+    net.conv(8, 3, 1, 1, 1, 0, rb.ACT_RELU, "pool1", "conv2")
+    net.batchnorm("conv2", "bn2")
+    net.maxpool(2, 2, rb.PADDING_SAME, "bn2", "pool2")
+    net.fullc(32, rb.ACT_RELU, "pool2", "fc1")
+    net.batchnorm("fc1", "bn3")
+    net.fullc(10, rb.ACT_RELU, "bn3", "fc2")
+    net.softmax("fc2", "softmax")
+    net.cost("softmax", "label", "cost", 1.0)
+
+
+def depthwise_graph(net):
+    """MobileNet-v1 unit (BASELINE configs[4]): depthwise 3x3 (fused relu) -> BN -> pointwise 1x1 conv (+BN+relu)"""
+    net.conv(8, 3, 2, 1, 1, 1, rb.ACT_RELU, "input", "stem")
+    net.depthwise(3, 1, 1, rb.ACT_RELU, "stem", "dw1")
+    net.batchnorm("dw1", "dwbn1")
+    net.conv(16, 1, 1, 0, 1, 1, rb.ACT_RELU, "dwbn1", "pw1")
+    net.depthwise(3, 2, 1, rb.ACT_RELU, "pw1", "dw2")
+    net.conv(16, 1, 1, 0, 1, 1, rb.ACT_RELU, "dw2", "pw2")
+    net.avgpool("pw2", "avg")
+
+
+GRAPHS = {
+    "stack": (stack_graph, dict(w=16, h=12, c=3, n=3), False),
+    "resnet_block": (resnet_block_graph, dict(w=16, h=16, c=3, n=4), True),
+    "lenet": (lenet_graph, dict(w=12, h=12, c=1, n=4), True),
+    "mobilenet_unit": (depthwise_graph, dict(w=16, h=16, c=3, n=2), False),
+}
+
+
+def _compare(tag, a, b, tol=REL_TOL):
+    assert a.shape == b.shape, (tag, a.shape, b.shape)
+    # |a-b| <= tol*max|b| + 1e-7: gradients that are analytically zero (e.g. the bias of a BN feeding
+    # another BN) are ~1e-9 noise on both sides and carry no relative information
+    a64, b64 = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    diff = float(np.max(np.abs(a64 - b64))) if a64.size else 0.0
+    bound = tol * float(np.max(np.abs(b64))) + 1e-7 if b64.size else 0.0
+    assert diff <= bound, "%s: max abs diff %.3g > %.3g (rel %.3g)" % (tag, diff, bound, G.rel_err(a, b))
+
+
+@pytest.mark.parametrize("gname", sorted(GRAPHS))
+def test_net_matches_reference(gname):
+    _need_ref()
+    from bcnn_amd import capi
+    build, shp, has_cost = GRAPHS[gname]
+    rs = np.random.RandomState(7)
+    ref = rb.RefNet(mode=rb.MODE_TRAIN, **shp)
+    ref.L.ref_set_threads(ref.net, 4)  # the reference oversubscribes badly with one OpenMP thread per core
+    hip = capi.Net(mode=capi.MODE_TRAIN, **shp)
+    build(ref)
+    build(hip)
+    ref.compile()
+    hip.compile()
+    ref.L.bcnn_set_sgd_optimizer(ref.net, 0.01, 0.9)
+    ref.L.bcnn_set_weight_regularizer(ref.net, 5e-4)
+    hip.set_sgd(0.01, 0.9, 5e-4)
+    nt = ref.L.ref_num_tensors(ref.net)
+    names = [ref.L.ref_tensor_name(ref.net, i).decode() for i in range(nt)]
+    # identical parameters: take the reference's (rand()-initialised) values; perturb BN params so they matter
+    for i in range(2, nt):
+        d = ref.data(i)
+        nm = names[i]
+        if nm.endswith("_scales"):
+            d[...] = rs.uniform(0.5, 1.5, d.shape)
+        elif nm.endswith("_b"):
+            d[...] = rs.uniform(-0.2, 0.2, d.shape)
+        elif nm.endswith("_run_var"):
+            d[...] = rs.uniform(0.5, 1.5, d.shape)
+        assert hip.shape(i) == ref.shape(i), (nm, hip.shape(i), ref.shape(i))
+        hip.data(i)[...] = d
+        hip.upload(i)
+    x = rs.uniform(-1, 1, ref.shape(0)).astype(np.float32)
+    ref.data(0)[...] = x
+    hip.data(0)[...] = x
+    hip.upload(0)
+    if has_cost:
+        lab = np.zeros(ref.shape(1), np.float32)
+        for b in range(lab.shape[0]):
+            lab[b, rs.randint(lab.shape[1])] = 1.0
+        ref.data(1)[...] = lab
+        hip.data(1)[...] = lab
+        hip.upload(1)
+    last = nt - 1
+    for it in range(2):  # two steps: the second one runs on updated weights and the momentum carry
+        ref.forward()
+        hip.forward()
+        if not has_cost:
+            dy = (rs.uniform(-1, 1, ref.shape(last)) * 0.1).astype(np.float32)
+            ref.grad(last)[...] = dy
+            hip.download(last)
+            hip.grad(last)[...] = dy
+            hip.upload(last, with_grad=True)
+        ref.backward()
+        hip.backward()
+        for i in range(nt):
+            if not ref.tensor(i).data:
+                continue  # the label tensor has no storage in graphs without a cost node
+            hip.download(i)
+            _compare("%s it%d %s data" % (gname, it, names[i]), hip.data(i), ref.data(i))
+            if ref.grad(i) is not None and i != 1:
+                _compare("%s it%d %s grad" % (gname, it, names[i]), hip.grad(i), ref.grad(i))
+        ref.L.bcnn_update(ref.net)
+        hip.update()
+        for i in range(2, nt):
+            hip.download(i)
+            _compare("%s it%d %s data after update" % (gname, it, names[i]), hip.data(i), ref.data(i))
+    # bit-exact pooling indices
+    nn = ref.L.ref_num_nodes(ref.net)
+    import torch
+    for node in range(nn):
+        if ref.L.ref_node_type(ref.net, node) == 5:  # BCNN_LAYER_MAXPOOL
+            want = ref.maxpool_indexes(node)
+            ptr = hip.node_state(node, 0)
+            got = torch.empty(want.shape, dtype=torch.int32, device="cuda:0")
+            from bcnn_amd import _lib
+            _lib.load().bcnn_hip_memcpy_d2d(got.data_ptr(), ptr, got.numel() * 4)
+            torch.cuda.synchronize()
+            assert np.array_equal(got.cpu().numpy(), want), "maxpool indexes differ in node %d" % node
+    ref.close()
+    hip.close()
