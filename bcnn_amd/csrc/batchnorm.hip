@@ -227,6 +227,7 @@ void bcnn_hip_batchnorm_forward(const float* x, float* y, float* run_mean, float
                                 int mode, int act) {
     const long long M = (long long)n * hw, total = M * c;
     if (!total) return;
+    KTimer kt(K_BN_FWD, 0.0, 4.0 * 3.0 * (double)total);  // read x twice (statistics, apply) + write y
     const int want_act = act;
     if (!act_is_cheap(act)) act = BCNN_HIP_ACT_NONE;  // tanh/softplus/logistic: separate pass below
     BnApplyArgs a;
@@ -257,6 +258,7 @@ void bcnn_hip_batchnorm_backward(float* dy, float* dx, const float* y, int act, 
     (void)x_norm;  // recomputed from workspace/mean/var: saves a full-tensor read (and its write in forward)
     const long long M = (long long)n * hw, total = M * c;
     if (!total) return;
+    KTimer kt(K_BN_BWD, 0.0, 4.0 * 6.0 * (double)total);  // 2 passes x (dy, x[, y]) + write dy
     if (!act_bwd_is_cheap(act)) {  // softplus: its derivative needs exp() -> separate in-place pass first
         bcnn_hip_activation_backward(y, dy, (size_t)total, act, nullptr, nullptr, hw, c);
         act = BCNN_HIP_ACT_NONE;

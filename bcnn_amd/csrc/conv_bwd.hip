@@ -218,6 +218,8 @@ bool conv_backward_weights(const float* x, const float* dy, float* dw, float* db
                 workspace_floats, p.partial_floats);
         exit(1);
     }
+    KTimer kt(K_CONV_DW, 2.0 * (double)s.total_q * s.Mg * s.K * s.groups,
+              4.0 * ((double)s.N * s.C * s.HW + (double)s.F * s.K + (double)s.N * s.F * s.OHOW));
     ConvDwArgs a;
     a.x = x; a.dy = dy; a.partials = workspace; a.s = s;
     a.mtiles = p.mtiles; a.ntiles = p.ntiles; a.qsplits = p.qsplits; a.q_per_split = p.q_per_split;
@@ -409,6 +411,8 @@ static void launch_dx(ConvDxArgs& a) {
 
 void conv_backward_data(const float* w, const float* dy, float* dx, const ConvShape& s) {
     if (s.total_p == 0 || s.Cg == 0) return;
+    KTimer kt(K_CONV_DX, 2.0 * (double)s.total_q * s.Mg * s.K * s.groups,
+              4.0 * ((double)s.N * s.C * s.HW + (double)s.F * s.K + (double)s.N * s.F * s.OHOW));
     ConvDxArgs a;
     a.w = w; a.dy = dy; a.dx = dx; a.s = s; a.KR = s.Mg * s.ksz * s.ksz;
     const long long cols = s.pointwise ? s.total_q : s.total_p;

@@ -259,6 +259,8 @@ bool conv_forward_direct(const float* x, const float* w, const float* bias, cons
     dim3 grid((unsigned)blocks, (unsigned)s.groups);
     const int ks = (s.K + 1) / 2;
     const int tm = (s.Mg <= 32) ? 1 : 2;
+    KTimer kt(K_CONV_FWD, 2.0 * (double)s.total_q * s.Mg * s.K * s.groups,
+              4.0 * ((double)s.N * s.C * s.HW + (double)s.F * s.K + (double)s.N * s.F * s.OHOW));
     const int actm = (a.act == BCNN_HIP_ACT_NONE) ? 0 : (a.act == BCNN_HIP_ACT_RELU ? 1 : 2);
 #define LAUNCH(TMv, KSv, KZ)                                                                            \
     do {                                                                                                \
@@ -481,6 +483,8 @@ bool conv_backward_weights_direct(const float* x, const float* dy, float* dw, fl
                 workspace_floats, need);
         exit(1);
     }
+    KTimer kt(K_CONV_DW, 2.0 * (double)s.total_q * s.Mg * s.K * s.groups,
+              4.0 * ((double)s.N * s.C * s.HW + (double)s.F * s.K + (double)s.N * s.F * s.OHOW));
     ConvDirectDwArgs a;
     a.x = x; a.dy = dy; a.partials = workspace; a.s = s; a.nwin = nwin; a.win_per_block = wpb;
     a.bias_col = dbias ? 1 : 0;

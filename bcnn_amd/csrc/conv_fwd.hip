@@ -209,6 +209,8 @@ void conv_forward_dispatch(const float* x, const float* w, const float* bias, co
     a.act = raw ? BCNN_HIP_ACT_NONE : act;
     a.add_bias = raw ? 0 : 1;
     if (s.total_q == 0 || s.Mg == 0) return;
+    KTimer kt(K_CONV_FWD, 2.0 * (double)s.total_q * s.Mg * s.K * s.groups,
+              4.0 * ((double)s.N * s.C * s.HW + (double)s.F * s.K + (double)s.N * s.F * s.OHOW));
     if (s.Mg <= 32) {
         launch_fwd<1, 4, 1, 1, 16>(a);       // 32 x 128
     } else if (s.Mg <= 64 || (long long)ceil_div(s.Mg, 128) * ceil_div(s.total_q, 128) * s.groups < 2 * kCUs) {

@@ -4,10 +4,35 @@
 #include "common.h"
 
 #include <cstring>
+#include <vector>
 
 namespace bcnn_hip {
 static thread_local hipStream_t g_stream = nullptr;  // nullptr = null stream (PyTorch-ROCm default)
 hipStream_t current_stream() { return g_stream; }
+
+// ---- per-kernel-class event timing ---------------------------------------------------------------
+struct KRecord { int cls; hipEvent_t a, b; double flops, bytes; };
+static thread_local bool g_prof_on = false;
+static thread_local std::vector<KRecord>* g_records = nullptr;
+static thread_local std::vector<hipEvent_t>* g_event_pool = nullptr;
+static hipEvent_t pool_event() {
+    if (!g_event_pool) g_event_pool = new std::vector<hipEvent_t>();
+    if (!g_event_pool->empty()) { hipEvent_t e = g_event_pool->back(); g_event_pool->pop_back(); return e; }
+    hipEvent_t e;
+    HIP_CHECK(hipEventCreate(&e));
+    return e;
+}
+KTimer::KTimer(int cls, double flops, double bytes) : idx(-1) {
+    if (!g_prof_on) return;
+    if (!g_records) g_records = new std::vector<KRecord>();
+    KRecord r{cls, pool_event(), pool_event(), flops, bytes};
+    HIP_CHECK(hipEventRecord(r.a, g_stream));
+    idx = (int)g_records->size();
+    g_records->push_back(r);
+}
+KTimer::~KTimer() {
+    if (idx >= 0) HIP_CHECK(hipEventRecord((*g_records)[idx].b, g_stream));
+}
 
 __global__ void fill_f32_kernel(float* __restrict__ x, size_t n, float v) {
     // scalar head up to 16-byte alignment, 16-byte stores on the body, scalar tail
@@ -127,6 +152,41 @@ float bcnn_hip_event_elapsed_ms(void* start, void* stop) {
     float ms = 0.f;
     HIP_CHECK(hipEventElapsedTime(&ms, (hipEvent_t)start, (hipEvent_t)stop));
     return ms;
+}
+
+void bcnn_hip_profile_enable(int on) { g_prof_on = (on != 0); }
+
+void bcnn_hip_profile_reset(void) {
+    if (!g_records) return;
+    HIP_CHECK(hipStreamSynchronize(current_stream()));
+    for (auto& r : *g_records) { g_event_pool->push_back(r.a); g_event_pool->push_back(r.b); }
+    g_records->clear();
+}
+
+int bcnn_hip_profile_num_classes(void) { return K_NUM; }
+
+const char* bcnn_hip_profile_class_name(int cls) {
+    static const char* names[K_NUM] = {"conv_fwd", "conv_dw", "conv_dx", "bn_fwd", "bn_bwd", "pool",
+                                       "eltwise_act", "gemm", "sgd"};
+    return (cls >= 0 && cls < K_NUM) ? names[cls] : "?";
+}
+
+void bcnn_hip_profile_read(int cls, double* ms, long long* launches, double* flops, double* bytes) {
+    double t = 0, f = 0, b = 0;
+    long long n = 0;
+    if (g_records) {
+        HIP_CHECK(hipStreamSynchronize(current_stream()));
+        for (auto& r : *g_records) {
+            if (r.cls != cls) continue;
+            float e = 0.f;
+            HIP_CHECK(hipEventElapsedTime(&e, r.a, r.b));
+            t += e; f += r.flops; b += r.bytes; ++n;
+        }
+    }
+    if (ms) *ms = t;
+    if (launches) *launches = n;
+    if (flops) *flops = f;
+    if (bytes) *bytes = b;
 }
 
 }  // extern "C"

@@ -2,16 +2,23 @@
 """bench.py -- images/s forward+backward of bcnn's conv hot path on MI355X, one process per GPU.
 
 Contract: `python bench.py --gpus N --steps K --warmup W` (for N > 1 launched under
-torch.distributed.run, one rank per GPU, RCCL all-reduce of the weight gradients after backward).
-Rank 0 prints ONE JSON line with the whole-job throughput, the roofline of the dominant kernel
-(duration measured live with HIP events on the launch stream) and a CPU baseline.
+torch.distributed.run, one rank per GPU, RCCL all-reduce of the weight-gradient arena after backward).
+Rank 0 prints ONE JSON line: whole-job throughput, the roofline of the dominant kernel class (durations
+measured live with HIP events on the launch stream, inside the timed region) and a CPU baseline
+(the unmodified reference, oracle/_ref, timed on this host on a bounded sample).
 
 Workloads (BASELINE.json configs):
-  conv3x3   configs[1]: one 3x3 s1 p1 conv, N=128 x 3 x 224 x 224 -> 64 channels (default)
-A step = forward (conv + bias) and backward (bias gradient + dW; the layer is the net's first node so
-its source carries no gradient and the reference computes no dX, bcnn_net.c:283 / bcnn_conv_layer.c:560).
+  resnet18  configs[2]/[3] (the configuration the metric is quoted on): ResNet-18, 224x224, N=128 per GPU,
+            built through the bcnn_net C API (libbcnn.so): topology of the reference's
+            examples/cifar10/cifar10_example.c:65-143 (fused-BN convs, eltwise-ReLU shortcuts, 1x1/s2
+            projections) behind an ImageNet stem (7x7 s2 p3 + maxpool 3/2 SAME; the reference ships only
+            the CIFAR stem), avgpool, fc-1000, softmax, cost. A step = bcnn_forward + bcnn_backward
+            (+ all-reduce) + bcnn_update (SGD), i.e. one full training step on synthetic data.
+  conv3x3   configs[1]: one 3x3 s1 p1 conv, N=128 x 3 x 224 x 224 -> 64; step = forward + backward(dW, dbias)
+            straight through the C-ABI (the layer is the net input: no dX, bcnn_net.c:283).
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -22,58 +29,95 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-MFMA_F32_PEAK_TF = 157.3   # fp32-input MFMA dense peak
+MFMA_F32_PEAK_TF = 157.3   # fp32-input MFMA dense peak (v_mfma_f32_32x32x2_f32)
 
 
-def cpu_baseline_conv(c, h, w, f, k, s, p, sample_n, iters):
-    """Reference (oracle/_ref, the unmodified bcnn built by oracle/Makefile) or, if that library did
-    not travel, the repo's C restatement; bounded sample of the same layer. Checker code: only this
-    baseline leg may touch oracle/."""
+# ---------------------------------------------------------------------------------------------------
+# graph
+# ---------------------------------------------------------------------------------------------------
+def build_resnet18(net, A, classes=1000):
+    """A = module with ACT_* / PADDING_* constants (capi for the device net, ref_bind for the reference)."""
+    net.conv(64, 7, 2, 3, 1, 1, A.ACT_RELU, "input", "conv0")
+    net.maxpool(3, 2, A.PADDING_SAME, "conv0", "pool0")
+    src = "pool0"
+    for stage, width in enumerate((64, 128, 256, 512), start=1):
+        for blk in (1, 2):
+            down = stage > 1 and blk == 1
+            a, b, out = "s%db%d_c1" % (stage, blk), "s%db%d_c2" % (stage, blk), "s%db%d" % (stage, blk)
+            net.conv(width, 3, 2 if down else 1, 1, 1, 1, A.ACT_RELU, src, a)
+            net.conv(width, 3, 1, 1, 1, 1, A.ACT_NONE, a, b)
+            if down:  # 1x1 / s2 projection shortcut (raw-view addressing quirk of the reference included)
+                proj = "s%db%d_proj" % (stage, blk)
+                net.conv(width, 1, 2, 0, 1, 1, A.ACT_NONE, src, proj)
+                net.eltwise(A.ACT_RELU, proj, b, out)
+            else:
+                net.eltwise(A.ACT_RELU, src, b, out)
+            src = out
+    net.avgpool(src, "gap")
+    net.fullc(classes, A.ACT_NONE, "gap", "fc")
+    net.softmax("fc", "prob")
+    net.cost("prob", "label", "cost", 1.0)
+
+
+# ---------------------------------------------------------------------------------------------------
+# CPU baseline: the unmodified reference on a bounded sample of the same workload
+# ---------------------------------------------------------------------------------------------------
+def cpu_baseline(workload, sample_n):
     import numpy as np
-    from oracle import ref_bind
+    from oracle import ref_bind as rb
+    if not rb.available():
+        return {"value": None, "unit": "images/s", "cores": 0, "kind": "reference",
+                "sample": "oracle/_ref/libbcnn_ref.so not present on this host"}
     rs = np.random.RandomState(0)
-    if ref_bind.available():
-        net = ref_bind.RefNet(mode=ref_bind.MODE_TRAIN, w=w, h=h, c=c, n=sample_n)
-        node = net.conv(f, k, s, p, 1, 0, ref_bind.ACT_NONE, "input", "conv1")
+    best = None
+    # the reference sizes its OpenMP team from the core count and oversubscribes badly on big hosts
+    # (nested parallel-for in its gemm): try a few team sizes on one iteration each, time the best.
+    ncpu = os.cpu_count() or 8
+    for threads in sorted({8, 16, min(32, ncpu)}):
+        if workload == "conv3x3":
+            net = rb.RefNet(mode=rb.MODE_TRAIN, w=224, h=224, c=3, n=sample_n)
+            net.conv(64, 3, 1, 1, 1, 0, rb.ACT_NONE, "input", "conv1")
+        else:
+            net = rb.RefNet(mode=rb.MODE_TRAIN, w=224, h=224, c=3, n=sample_n)
+            build_resnet18(net, rb)
         net.compile()
-        net.data(net.node_src(node, 0))[...] = rs.uniform(-1, 1, (sample_n, c, h, w)).astype(np.float32)
-        t, tf, tb = net.time_fwd_bwd(1, iters)
-        cores = net.threads()
+        net.L.ref_set_threads(net.net, threads)
+        net.data(0)[...] = rs.uniform(-1, 1, net.shape(0)).astype(np.float32)
+        t, _, _ = net.time_fwd_bwd(1, 2)
         net.close()
-        kind = "reference"
-    else:
-        from oracle import orc_bind
-        oh, ow = orc_bind.conv_out_hw(h, w, k, s, p)
-        case = dict(op="conv", n=sample_n, c=c, h=h, w=w, f=f, k=k, s=s, p=p, g=1, bn=0, act=0,
-                    input_grad=0, mode=1,
-                    x=rs.uniform(-1, 1, (sample_n, c, h, w)).astype(np.float32),
-                    wt=rs.uniform(-0.3, 0.3, (f, c, k, k)).astype(np.float32),
-                    bias=np.zeros(f, np.float32),
-                    dy=rs.uniform(-0.01, 0.01, (sample_n, f, oh, ow)).astype(np.float32))
-        orc_bind.run_oracle(case)
-        best = 1e30
-        for _ in range(max(1, iters // 4)):
-            t0 = time.perf_counter()
-            orc_bind.run_oracle(case)
-            best = min(best, time.perf_counter() - t0)
-        t, cores, kind = best, os.cpu_count(), "port"
-    return {"value": round(sample_n / t, 2), "unit": "images/s", "cores": int(cores), "kind": kind,
-            "sample": "same conv layer, N=%d, fwd+bwd(dW+bias), best of %d iterations" % (sample_n, iters)}
+        if best is None or t < best[0]:
+            best = (t, threads)
+    t, threads = best
+    return {"value": round(sample_n / t, 2), "unit": "images/s", "cores": int(threads), "kind": "reference",
+            "sample": "unmodified reference (oracle/_ref, AVX2+OpenMP, in-tree gemm), same %s graph at N=%d, "
+                      "bcnn_forward+bcnn_backward, best of 2 after 1 warm-up, best OpenMP team of {8,16,32}"
+                      % (workload, sample_n)}
+
+
+def read_profile(L):
+    out = {}
+    for cls in range(L.bcnn_hip_profile_num_classes()):
+        ms, n, fl, by = C.c_double(), C.c_longlong(), C.c_double(), C.c_double()
+        L.bcnn_hip_profile_read(cls, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by))
+        if n.value:
+            out[L.bcnn_hip_profile_class_name(cls).decode()] = dict(ms=ms.value, launches=n.value, flops=fl.value,
+                                                                    bytes=by.value)
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="conv3x3")
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="resnet18", choices=["resnet18", "conv3x3"])
     ap.add_argument("--batch", type=int, default=128, help="images per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from bcnn_amd import _lib, ops
+    from bcnn_amd import _lib, capi, ops
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -86,104 +130,137 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)  # "nccl" IS RCCL on ROCm
     dev = torch.device("cuda", local_rank)
-
-    assert args.workload == "conv3x3", "only the conv3x3 microbench is wired up in this round"
-    n, c, h, w, f, k, s, p = args.batch, 3, 224, 224, 64, 3, 1, 1
-    oh, ow = ops.conv_out_hw(h, w, k, s, p)
+    n = args.batch
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)   # every rank owns different images
-    x = torch.rand((n, c, h, w), device=dev, generator=gen) * 2 - 1
-    wgen = torch.Generator(device=dev).manual_seed(7)            # identical weights on every rank
-    a = (3.0 / (c * k * k)) ** 0.5
-    # one flat arena for parameters and one for their gradients => a single all-reduce per step
-    params = torch.empty(f * c * k * k + f, device=dev)
-    grads = torch.zeros_like(params)
-    wt = params[: f * c * k * k].view(f, c, k, k)
-    bias = params[f * c * k * k:]
-    wt.copy_((torch.rand(wt.shape, device=dev, generator=wgen) * 2 - 1) * a)
-    bias.copy_((torch.rand(f, device=dev, generator=wgen) - 0.5) * 0.2)
-    dw = grads[: f * c * k * k].view(f, c, k, k)
-    db = grads[f * c * k * k:]
-    y = torch.empty((n, f, oh, ow), device=dev)
-    dy = (torch.rand((n, f, oh, ow), device=dev, generator=gen) * 2 - 1) * 1e-2
-    ws = torch.zeros(max(1, ops.conv_workspace_size(n, c, h, w, f, k, s, p, 1)), device=dev)
 
-    # launch on an explicit stream of our own and time with HIP events recorded on that same stream
+    # launch on an explicit stream of our own; HIP events are recorded on that same stream
     stream = L.bcnn_hip_stream_create()
     L.bcnn_hip_set_stream(stream)
-    torch.cuda.synchronize()
-    ev = [[L.bcnn_hip_event_create() for _ in range(3)] for _ in range(args.steps)]
 
-    def step(i=None):
-        if i is not None:
-            L.bcnn_hip_event_record(ev[i][0])
-        ops.conv_forward(x, wt, bias, y, k, s, p, 1, 0)
-        if i is not None:
-            L.bcnn_hip_event_record(ev[i][1])
-        ops.conv_backward(x, wt, y, dy, None, dw, db, k, s, p, 1, 0, ws)
-        if i is not None:
-            L.bcnn_hip_event_record(ev[i][2])
-        if world > 1:
-            L.bcnn_hip_sync()                 # gradients complete on our stream before RCCL reads them
-            dist.all_reduce(grads)            # sum over ranks of the flat gradient arena (xGMI)
-            torch.cuda.synchronize()          # the next backward accumulates into `grads`
+    if args.workload == "resnet18":
+        import numpy as np
+        net = capi.Net(mode=capi.MODE_TRAIN, w=224, h=224, c=3, n=n)
+        import random
+        # identical parameters on every rank: the builders draw from libc rand()
+        C.CDLL(None).srand(7)
+        build_resnet18(net, capi)
+        net.compile()
+        net.set_sgd(0.01, 0.9, 5e-4)
+        net.set_data_parallel(rank, world)
+        x = torch.rand((n, 3, 224, 224), device=dev, generator=gen) * 2 - 1
+        lab = torch.zeros((n, 1000), device=dev)
+        lab[torch.arange(n, device=dev), torch.randint(0, 1000, (n,), device=dev, generator=gen)] = 1.0
+        torch.cuda.synchronize()
+        t_in, t_lab = net.tensor(0), net.tensor(1)
+        L.bcnn_hip_memcpy_d2d(t_in.data_gpu, x.data_ptr(), x.numel() * 4)
+        L.bcnn_hip_memcpy_d2d(t_lab.data_gpu, lab.data_ptr(), lab.numel() * 4)
+        L.bcnn_hip_sync()
+        gptr, gsize = net.gradient_arena()
+        grads = torch.as_tensor(capi.DeviceArray(gptr, gsize), device=dev) if world > 1 else None
+
+        def step():
+            net.forward()
+            net.backward()
+            if world > 1:
+                L.bcnn_hip_sync()           # gradients complete on our stream before RCCL reads them
+                dist.all_reduce(grads)      # ONE all-reduce of the flat weight/bias-gradient arena (xGMI)
+                torch.cuda.synchronize()
+            net.update()
+        desc = ("ResNet-18 224x224 (BASELINE configs[2]), N=%d per GPU, fwd+bwd+SGD through bcnn_net C API; "
+                "CIFAR-example topology + ImageNet stem, fc-1000" % n)
+        sample_n = 2
+    else:
+        c, h, w, f, k, s, p = 3, 224, 224, 64, 3, 1, 1
+        oh, ow = ops.conv_out_hw(h, w, k, s, p)
+        x = torch.rand((n, c, h, w), device=dev, generator=gen) * 2 - 1
+        wgen = torch.Generator(device=dev).manual_seed(7)            # identical weights on every rank
+        a = (3.0 / (c * k * k)) ** 0.5
+        params = torch.empty(f * c * k * k + f, device=dev)
+        grads = torch.zeros_like(params)
+        wt = params[: f * c * k * k].view(f, c, k, k)
+        bias = params[f * c * k * k:]
+        wt.copy_((torch.rand(wt.shape, device=dev, generator=wgen) * 2 - 1) * a)
+        bias.copy_((torch.rand(f, device=dev, generator=wgen) - 0.5) * 0.2)
+        dw = grads[: f * c * k * k].view(f, c, k, k)
+        db = grads[f * c * k * k:]
+        y = torch.empty((n, f, oh, ow), device=dev)
+        dy = (torch.rand((n, f, oh, ow), device=dev, generator=gen) * 2 - 1) * 1e-2
+        ws = torch.zeros(max(1, ops.conv_workspace_size(n, c, h, w, f, k, s, p, 1)), device=dev)
+        torch.cuda.synchronize()
+
+        def step():
+            ops.conv_forward(x, wt, bias, y, k, s, p, 1, 0)
+            ops.conv_backward(x, wt, y, dy, None, dw, db, k, s, p, 1, 0, ws)
+            if world > 1:
+                L.bcnn_hip_sync()
+                dist.all_reduce(grads)
+                torch.cuda.synchronize()
+        desc = ("conv3x3 s1 p1, N=%d x 3 x 224 x 224 -> 64 (BASELINE configs[1]), fwd + bwd(dW, dbias); "
+                "no dX: the layer's source is the net input" % n)
+        sample_n = 16
 
     for _ in range(args.warmup):
         step()
     L.bcnn_hip_sync()
     torch.cuda.synchronize()
+    L.bcnn_hip_profile_reset()
+    L.bcnn_hip_profile_enable(1)
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
+    for _ in range(args.steps):
+        step()
     L.bcnn_hip_sync()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    L.bcnn_hip_profile_enable(0)
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    fwd_ms = sum(L.bcnn_hip_event_elapsed_ms(e[0], e[1]) for e in ev) / args.steps
-    bwd_ms = sum(L.bcnn_hip_event_elapsed_ms(e[1], e[2]) for e in ev) / args.steps
-    # algorithmic traffic per launch: forward reads x and W once, writes y once;
-    # backward-dW reads x and dy once.
-    fwd_bytes = 4.0 * (n * c * h * w + f * c * k * k + n * f * oh * ow)
-    bwd_bytes = 4.0 * (n * c * h * w + n * f * oh * ow + f * c * k * k)
-    flops = 2.0 * n * f * oh * ow * c * k * k  # per direction
-    fwd_gbs = fwd_bytes / (fwd_ms * 1e-3) / 1e9
-    bwd_gbs = bwd_bytes / (bwd_ms * 1e-3) / 1e9
-
     if rank == 0:
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_conv3x3_pmc.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("conv_fwd_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        prof = read_profile(L)
+        # dominant kernel class by time inside the timed region
+        dom = max(prof.items(), key=lambda kv: kv[1]["ms"]) if prof else None
+        roof = None
+        if dom:
+            name, d = dom
+            avg_ms = d["ms"] / d["launches"]
+            tf = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["flops"] else 0.0
+            gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+            ai = d["flops"] / d["bytes"] if d["bytes"] else 0.0
+            ridge = MFMA_F32_PEAK_TF * 1e12 / (HBM_PEAK_GBS * 1e9)
+            if ai >= ridge:   # MFMA-bound class
+                roof = {"kernel": name, "bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF,
+                        "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4)}
+            else:
+                roof = {"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
+            traffic = None
+            if args.workload == "conv3x3" and name == "conv_fwd":
+                pmc = os.path.join(ROOT, "profiles", "r01_conv3x3_pmc.json")
+                if os.path.exists(pmc):
+                    traffic = json.load(open(pmc)).get("conv_fwd_hbm_bytes_per_launch")
+            roof.update({"traffic": traffic, "launches": d["launches"], "avg_ms": round(avg_ms, 4),
+                         "algorithmic_flops_per_launch": d["flops"] / d["launches"],
+                         "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
+                         "tflops": round(tf, 2), "gbs": round(gbs, 1)})
         out = {
             "metric": "images/sec fwd+bwd", "value": round(args.steps * n * world / dt, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "conv3x3 s1 p1, N=%d x 3 x 224 x 224 -> 64 (BASELINE configs[1]), "
-                                   "fwd + bwd(dW, dbias); no dX: the layer's source is the net input" % n,
-                       "batch_per_gpu": n, "global_batch": n * world, "parallelism": "dp%d" % world},
-            "roofline": {"kernel": "conv_fwd_igemm", "bound": "hbm", "achieved": round(fwd_gbs, 1),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fwd_gbs / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "algorithmic_bytes": fwd_bytes, "avg_ms": round(fwd_ms, 4),
-                         "mfma_tflops": round(flops / (fwd_ms * 1e-3) / 1e12, 2),
-                         "mfma_frac": round(flops / (fwd_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4)},
-            "roofline_bwd": {"kernel": "conv_dw_kernel+finalize", "bound": "hbm", "achieved": round(bwd_gbs, 1),
-                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(bwd_gbs / HBM_PEAK_GBS, 4),
-                             "algorithmic_bytes": bwd_bytes, "avg_ms": round(bwd_ms, 4),
-                             "mfma_tflops": round(flops / (bwd_ms * 1e-3) / 1e12, 2)},
+            "config": {"workload": desc, "batch_per_gpu": n, "global_batch": n * world, "parallelism": "dp%d" % world},
+            "roofline": roof,
+            "kernel_classes": {k: {"ms_per_step": round(v["ms"] / args.steps, 4), "launches_per_step": v["launches"] // args.steps,
+                                   "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None,
+                                   "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} for k, v in prof.items()},
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_conv(c, h, w, f, k, s, p, sample_n=16, iters=12)
+            out["cpu_baseline"] = cpu_baseline(args.workload, sample_n)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

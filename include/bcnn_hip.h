@@ -62,6 +62,15 @@ void bcnn_hip_event_record(void *ev);
 void bcnn_hip_event_sync(void *ev);
 float bcnn_hip_event_elapsed_ms(void *start, void *stop);
 
+/* Per-kernel-class timing (measurement aid, off by default): while enabled every launch of a classified
+ * kernel is bracketed by HIP events on the launch stream together with its ALGORITHMIC flops / bytes;
+ * read() sums them per class since the last reset(). Classes: bcnn_hip_profile_class_name(i). */
+void bcnn_hip_profile_enable(int on);
+void bcnn_hip_profile_reset(void);
+int bcnn_hip_profile_num_classes(void);
+const char *bcnn_hip_profile_class_name(int cls);
+void bcnn_hip_profile_read(int cls, double *ms, long long *launches, double *flops, double *bytes);
+
 /* ---------------------------------------------------------------------------------------------
  * BLAS-1 / per-channel helpers.  Replaces bcnn_cuda_axpy/scal/copy (bcnn_mat.cu:44-100),
  * bcnn_cuda_add_bias / bcnn_cuda_grad_bias (bcnn_mat.cu:348-391), bcnn_scales_gpu /
