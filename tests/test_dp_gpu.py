@@ -1,0 +1,79 @@
+"""GPU check of the data-parallel path of the C host: two bcnn_net replicas (virtual ranks on one GPU),
+each with half of the batch, gradient arenas summed (what RCCL all-reduce does across GPUs), then
+bcnn_update with bcnn_set_data_parallel(rank, 2). Weights after several steps must equal the UNMODIFIED
+reference trained on the whole batch (a BN-free graph, where shard-local == global semantics)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_bind as rb
+
+pytestmark = pytest.mark.gpu
+
+
+def graph(net):
+    net.conv(8, 3, 1, 1, 1, 0, rb.ACT_RELU, "input", "c1")
+    net.conv(8, 3, 2, 1, 1, 0, rb.ACT_RELU, "c1", "c2")
+    net.maxpool(2, 2, rb.PADDING_SAME, "c2", "p1")
+    net.fullc(5, rb.ACT_NONE, "p1", "fc")
+    net.softmax("fc", "sm")
+    net.cost("sm", "label", "cost", 1.0)
+
+
+def test_two_replicas_with_summed_arena_match_reference_on_global_batch():
+    if not rb.available():
+        pytest.skip("oracle/_ref not present")
+    from bcnn_amd import capi
+    shp = dict(w=12, h=12, c=3)
+    ref = rb.RefNet(mode=rb.MODE_TRAIN, n=4, **shp)
+    ref.L.ref_set_threads(ref.net, 4)
+    graph(ref)
+    ref.compile()
+    ref.L.bcnn_set_sgd_optimizer(ref.net, 0.05, 0.9)
+    ref.L.bcnn_set_weight_regularizer(ref.net, 5e-4)
+    reps = []
+    for r in range(2):
+        net = capi.Net(mode=capi.MODE_TRAIN, n=2, **shp)
+        graph(net)
+        net.compile()
+        net.set_sgd(0.05, 0.9, 5e-4)
+        net.set_data_parallel(r, 2)
+        reps.append(net)
+    nt = ref.L.ref_num_tensors(ref.net)
+    names = [ref.L.ref_tensor_name(ref.net, i).decode() for i in range(nt)]
+    params = [i for i in range(2, nt) if names[i].endswith("_w") or names[i].endswith("_b")]
+    for i in params:
+        for net in reps:
+            net.data(i)[...] = ref.data(i)
+            net.upload(i)
+    arenas = []
+    for net in reps:
+        p, n = net.gradient_arena()
+        arenas.append(torch.as_tensor(capi.DeviceArray(p, n), device="cuda:0"))
+    rs = np.random.RandomState(11)
+    for step in range(3):
+        x = rs.uniform(-1, 1, (4, 3, 12, 12)).astype(np.float32)
+        lab = np.zeros((4, 5, 1, 1), np.float32)
+        for b in range(4):
+            lab[b, rs.randint(5)] = 1.0
+        ref.data(0)[...] = x
+        ref.data(1)[...] = lab
+        ref.forward(); ref.backward(); ref.L.bcnn_update(ref.net)
+        for r, net in enumerate(reps):
+            net.data(0)[...] = x[2 * r:2 * r + 2]; net.upload(0)
+            net.data(1)[...] = lab[2 * r:2 * r + 2]; net.upload(1)
+            net.forward(); net.backward(); net.sync()
+        total = arenas[0] + arenas[1]          # the all-reduce(sum)
+        arenas[0].copy_(total); arenas[1].copy_(total)
+        torch.cuda.synchronize()
+        for net in reps:
+            net.update(); net.sync()
+        for i in params:
+            for net in reps:
+                net.download(i, with_grad=False)
+                a, b = net.data(i), ref.data(i)
+                err = np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+                assert err < 1e-4, (step, names[i], err)
+    for net in reps:
+        net.close()
+    ref.close()
