@@ -12,8 +12,7 @@
 //       the workspace and a second kernel adds the partials to dW in a fixed order (deterministic;
 //       keeps the `+=` onto the momentum carry). One extra all-ones im2col column yields the bias
 //       gradient for free when the padded K tile has room (saves a full re-read of dy).
-//   dX: gather form, GEMM-M = C/g, GEMM-N = N*H*W input pixels, reduction over (f, kr, kc); every
-//       output element is produced by exactly one thread => plain store, no zero-fill pass, no atomics.
+//   dX lives in conv_igemm.hip (it is the same gather-GEMM as the forward pass).
 #include "conv_common.h"
 
 namespace bcnn_hip {
@@ -236,190 +235,6 @@ bool conv_backward_weights(const float* x, const float* dy, float* dw, float* db
         dw, dbias);
     KERNEL_CHECK();
     return p.bias_col != 0;
-}
-
-// ================================================================================================
-// dX
-// ================================================================================================
-struct ConvDxArgs {
-    const float* w;
-    const float* dy;
-    float* dx;
-    ConvShape s;
-    int mtiles, ptiles;
-    int KR;  // reduction length Mg*ksz*ksz
-};
-
-template <int WM, int WN, int TM, int TN, int BK>
-__global__ __launch_bounds__(256) void conv_dx_kernel(const ConvDxArgs a) {
-    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int LDA = BM + 1;
-    constexpr int B_ROWS = 256 / BN, B_IT = BK / B_ROWS, A_IT = BM * BK / 256;
-    static_assert(WM * WN == 4 && BN <= 256 && 256 % BN == 0, "tile");
-    __shared__ float As[2][BK][LDA];   // As[kred][c]
-    __shared__ float Bs[2][BK][BN];    // Bs[kred][pixel]
-    __shared__ int4 ktab[2][BK];       // {f*OHOW, kr | kc<<16, f*Cg*k2 + tap, valid}
-
-    const ConvShape& s = a.s;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid / WN, wn = wid % WN;
-    const int g = blockIdx.y;
-    const int lb = xcd_remap(blockIdx.x, gridDim.x);
-    const int mt = lb % a.mtiles, pt = lb / a.mtiles;
-    const int c0 = mt * BM;
-    const long long p0 = (long long)pt * BN;
-    const long long total_cols = s.pointwise ? s.total_q : s.total_p;
-    const int col_per_img = s.pointwise ? s.OHOW : s.HW;
-    const int kk2 = s.ksz * s.ksz;
-    const int nk = (a.KR + BK - 1) / BK;
-
-    // this thread's B column = one input pixel (or one output pixel in the 1x1 raw-view case)
-    const int bj = tid % BN, bk0 = tid / BN;
-    const long long bp = p0 + bj;
-    const bool bvalid = bp < total_cols;
-    int b_ih = 0, b_iw = 0, b_pix = 0;
-    const float* gyb = a.dy;
-    {
-        const long long pp = bvalid ? bp : 0;
-        const int n = (int)(pp / col_per_img), pix = (int)(pp - (long long)n * col_per_img);
-        gyb = a.dy + ((long long)n * s.F + (long long)g * s.Mg) * s.OHOW;
-        if (s.pointwise) b_pix = pix;
-        else { b_ih = pix / s.W + s.pad; b_iw = pix % s.W + s.pad; }
-    }
-    const int ak = tid % BK, am0 = tid / BK;
-    const float* wg = a.w + (long long)g * s.Mg * s.K;
-
-    auto fill_ktab = [&](int kt, int slot) {
-        if (tid < BK) {
-            const int kr_ = kt * BK + tid;
-            int4 e;
-            if (kr_ < a.KR) {
-                const int f = kr_ / kk2, tap = kr_ - f * kk2;
-                const int kr = tap / s.ksz, kc = tap - kr * s.ksz;
-                e.x = f * s.OHOW; e.y = kr | (kc << 16); e.z = f * s.K + tap; e.w = 1;
-            } else { e.x = 0; e.y = 0; e.z = 0; e.w = 0; }
-            ktab[slot][tid] = e;
-        }
-    };
-
-    float ra[A_IT], rb[B_IT];
-    auto load_tile = [&](int slot) {
-        {
-            const int4 e = ktab[slot][ak];
-#pragma unroll
-            for (int i = 0; i < A_IT; ++i) {
-                const int m = am0 + i * (256 / BK);
-                const bool ok = e.w && (c0 + m < s.Cg);
-                ra[i] = ok ? wg[e.z + (c0 + m) * kk2] : 0.f;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i) {
-            const int4 e = ktab[slot][bk0 + i * B_ROWS];
-            float v = 0.f;
-            if (bvalid && e.w) {
-                if (s.pointwise) {
-                    v = gyb[e.x + b_pix];
-                } else {
-                    const int th = b_ih - (e.y & 0xffff), tw = b_iw - (e.y >> 16);
-                    if (th >= 0 && tw >= 0) {
-                        int oh = th, ow = tw;
-                        bool ok = true;
-                        if (s.stride != 1) {
-                            oh = th / s.stride; ow = tw / s.stride;
-                            ok = (oh * s.stride == th) && (ow * s.stride == tw);
-                        }
-                        if (ok && oh < s.OH && ow < s.OW) v = gyb[e.x + oh * s.OW + ow];
-                    }
-                }
-            }
-            rb[i] = v;
-        }
-    };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) As[buf][ak][am0 + i * (256 / BK)] = ra[i];
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i) Bs[buf][bk0 + i * B_ROWS][bj] = rb[i];
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    fill_ktab(0, 0);
-    __syncthreads();
-    load_tile(0);
-    store_tile(0);
-    if (nk > 1) fill_ktab(1, 1);
-    __syncthreads();
-
-    const int l31 = lane & 31, lhi = lane >> 5;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) load_tile(cur ^ 1);
-        int kleft = a.KR - kt * BK;
-        if (kleft > BK) kleft = BK;
-        const int ksteps = (kleft + 1) >> 1;
-        for (int ks = 0; ks < ksteps; ++ks) {
-            float af[TM], bf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = As[cur][2 * ks + lhi][(wm * TM + i) * 32 + l31];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = Bs[cur][2 * ks + lhi][(wn * TN + j) * 32 + l31];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
-        }
-        if (kt + 1 < nk) store_tile(cur ^ 1);
-        if (kt + 2 < nk) fill_ktab(kt + 2, cur);
-        __syncthreads();
-    }
-
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const long long p = p0 + (wn * TN + j) * 32 + l31;
-        if (p >= total_cols) continue;
-        const int n = (int)(p / col_per_img), pix = (int)(p - (long long)n * col_per_img);
-        float* ob = a.dx + ((long long)n * s.C + (long long)g * s.Cg) * s.HW + pix;
-        const int cstride = s.pointwise ? s.OHOW : s.HW;  // raw [Cg][OH*OW] view for 1x1 (quirk 1)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int c = c0 + (wm * TM + i) * 32 + mfma_row(r, lane);
-                if (c < s.Cg) ob[(long long)c * cstride] = acc[i][j][r];
-            }
-    }
-}
-
-template <int WM, int WN, int TM, int TN, int BK>
-static void launch_dx(ConvDxArgs& a) {
-    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    const long long cols = a.s.pointwise ? a.s.total_q : a.s.total_p;
-    a.mtiles = ceil_div(a.s.Cg, BM);
-    a.ptiles = ceil_div(cols, BN);
-    dim3 grid((unsigned)(a.mtiles * a.ptiles), (unsigned)a.s.groups);
-    conv_dx_kernel<WM, WN, TM, TN, BK><<<grid, 256, 0, current_stream()>>>(a);
-    KERNEL_CHECK();
-}
-
-void conv_backward_data(const float* w, const float* dy, float* dx, const ConvShape& s) {
-    if (s.total_p == 0 || s.Cg == 0) return;
-    KTimer kt(K_CONV_DX, 2.0 * (double)s.total_q * s.Mg * s.K * s.groups,
-              4.0 * ((double)s.N * s.C * s.HW + (double)s.F * s.K + (double)s.N * s.F * s.OHOW));
-    ConvDxArgs a;
-    a.w = w; a.dy = dy; a.dx = dx; a.s = s; a.KR = s.Mg * s.ksz * s.ksz;
-    const long long cols = s.pointwise ? s.total_q : s.total_p;
-    if (s.Cg <= 32) launch_dx<1, 4, 1, 1, 16>(a);
-    else if (s.Cg <= 64 || (long long)ceil_div(s.Cg, 128) * ceil_div(cols, 128) * s.groups < 2 * kCUs)
-        launch_dx<2, 2, 1, 2, 16>(a);
-    else launch_dx<2, 2, 2, 2, 16>(a);
 }
 
 }  // namespace bcnn_hip
