@@ -243,33 +243,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const IgemmArgs a) {
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) load_tile(cur ^ 1);  // global loads in flight under the MFMAs
-        const int kleft = KR - kt * BK;
-        if (kleft >= BK) {
+        // always BK/2 steps: entries past the end of the reduction are zero in LDS (table `valid` = 0)
 #pragma unroll
-            for (int ks = 0; ks < BK / 2; ++ks) {
-                float af[TM], bf[TN];
+        for (int ks = 0; ks < BK / 2; ++ks) {
+            float af[TM], bf[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) af[i] = As[cur][2 * ks + lhi][(wm * TM + i) * 32 + l31];
+            for (int i = 0; i < TM; ++i) af[i] = As[cur][2 * ks + lhi][(wm * TM + i) * 32 + l31];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bf[j] = Bs[cur][2 * ks + lhi][(wn * TN + j) * 32 + l31];
+            for (int j = 0; j < TN; ++j) bf[j] = Bs[cur][2 * ks + lhi][(wn * TN + j) * 32 + l31];
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
-            }
-        } else {  // ragged last tile: the LDS tile is zero-padded to an even count
-            const int ksteps = (kleft + 1) >> 1;
-            for (int ks = 0; ks < ksteps; ++ks) {
-                float af[TM], bf[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) af[i] = As[cur][2 * ks + lhi][(wm * TM + i) * 32 + l31];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) bf[j] = Bs[cur][2 * ks + lhi][(wn * TN + j) * 32 + l31];
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
-            }
+                for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
         }
         if (kt + 1 < nk) store_tile(cur ^ 1);
         if (kt + 2 < nk) fill_ktab(kt + 2, cur);
