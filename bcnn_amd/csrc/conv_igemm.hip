@@ -310,6 +310,15 @@ static void dispatch_igemm(IgemmArgs& a, long long max_cols) {
     else launch_igemm<2, 2, 2, 2, 16>(a, max_cols);                  // 128 x 128
 }
 
+bool conv_forward_dma(const float* x, const float* w, const float* bias, const float* slopes, float* y,
+                      const ConvShape& s, int act, int raw);                          // conv_igemm_dma.hip
+bool conv_backward_data_dma(const float* w, const float* dy, float* dx, const ConvShape& s);
+
+static bool dma_enabled() {
+    static const int on = getenv("BCNN_HIP_NO_DMA") ? 0 : 1;  // A/B switch for profiling
+    return on != 0;
+}
+
 // raw = 1: write the bare convolution (no bias, no activation) -- used by the fused-BN path.
 void conv_forward_dispatch(const float* x, const float* w, const float* bias, const float* slopes, float* y,
                            const ConvShape& s, int act, int raw) {
@@ -320,6 +329,7 @@ void conv_forward_dispatch(const float* x, const float* w, const float* bias, co
     }
     KTimer kt(K_CONV_FWD, 2.0 * (double)s.total_q * s.Mg * s.K * s.groups,
               4.0 * ((double)s.N * s.C * s.HW + (double)s.F * s.K + (double)s.N * s.F * s.OHOW));
+    if (dma_enabled() && conv_forward_dma(x, w, bias, slopes, y, s, act, raw)) return;
     IgemmArgs a;
     a.a_base = w; a.b_base = x; a.out = y; a.bias = bias; a.slopes = slopes; a.s = s;
     a.mode = 0;
@@ -341,6 +351,7 @@ void conv_backward_data(const float* w, const float* dy, float* dx, const ConvSh
     }
     KTimer kt(K_CONV_DX, 2.0 * (double)s.total_q * s.Mg * s.K * s.groups,
               4.0 * ((double)s.N * s.C * s.HW + (double)s.F * s.K + (double)s.N * s.F * s.OHOW));
+    if (dma_enabled() && conv_backward_data_dma(w, dy, dx, s)) return;
     IgemmArgs a;
     a.a_base = w; a.b_base = dy; a.out = dx; a.bias = nullptr; a.slopes = nullptr; a.s = s;
     a.mode = 1; a.act = BCNN_HIP_ACT_NONE; a.add_bias = 0;

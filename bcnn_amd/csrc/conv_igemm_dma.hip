@@ -1,0 +1,437 @@
+// conv_igemm_dma.hip -- implicit-GEMM convolution (forward and dX) whose K loop issues NO vector-ALU work:
+// both operand tiles go global -> LDS with `buffer_load_dword ... lds` (LDS-DMA), addressed by a per-lane
+// VGPR offset that is constant for a whole filter tap plus a wave-uniform SGPR offset per reduction row.
+//
+// Why: v_mfma_f32_32x32x2_f32 runs at the fp32 vector rate and shares the SIMD's issue with ordinary VALU
+// instructions (measured: MFMA-only time + VALU-only time == total time of the register-staged kernel in
+// conv_igemm.hip). Every address add / select / ds_write in the K loop is therefore stolen from the MFMAs.
+// Here a K-tile costs a wave 16 DMA loads + 32 ds_read_b32 + 32 MFMAs and a handful of SALU instructions.
+//
+// Reference semantics: bcnn_forward_conv_layer_cpu / bcnn_backward_conv_layer_cpu,
+// src/layers/bcnn_conv_layer.c:438-481 and :556-581 (incl. the 1x1 raw-view addressing :445-446, :562-569).
+//
+//   D[m][col] = sum_{tap t} sum_{j} At[t][j][m] * B_t[j][col]
+//   forward : m = f, j = c, col = (n, oh, ow);  B_t[j][col] = x[n][g*Cg + j][oh*s - p + kr][ow*s - p + kc]
+//   dX      : m = c, j = f, col = (n, ih, iw) of one stride-parity class; B_t = dy[n][g*Mg + j][qa - kr/s][qb - kc/s]
+// The reduction runs tap-major so one K-tile (16 rows) lives inside ONE tap: a lane's gather offset and its
+// zero-padding validity are fixed for the tile (invalid -> an out-of-range buffer offset, which the buffer
+// unit turns into 0.0 in LDS), and the row only moves the wave-uniform soffset by j * plane size.
+// At is the weight tensor re-packed per call to [tap][j (padded to 16)][m (padded to 128)] with zero
+// padding, so ragged M / J need no predicates (a zero A row cancels whatever finite B row was fetched).
+#include "conv_common.h"
+
+namespace bcnn_hip {
+
+constexpr int kDmaMaxTaps = 49;
+constexpr int kDmaMaxClasses = 4;
+constexpr unsigned kOOB = 0x80000000u;  // buffers are limited to < 2 GiB so this is always out of range
+
+struct DmaClass {
+    int ih0, iw0, Hc, Wc;  // dX: first row/col and extent of the stride-parity class (forward: 0,0,OH,OW)
+    int ntaps, tap0;       // taps of the class, index of its first tap in the packed At
+    signed char dy[kDmaMaxTaps], dx[kDmaMaxTaps];  // coordinate shift of the gathered element per tap
+};
+
+struct DmaArgs {
+    const float* at;       // packed weights [groups][kk2][Jpad][Mpad]
+    const float* b_base;   // gathered tensor (x / dy)
+    float* out;
+    const float* bias;
+    const float* slopes;
+    ConvShape s;
+    int mode;              // 0 forward, 1 dX
+    int act, add_bias;
+    int M, J, Jpad, Mpad;  // rows, reduction majors per tap (and their padded sizes)
+    int kk2;               // taps in total (all classes)
+    unsigned at_bytes, b_bytes;
+    int b_major_stride;    // elements between consecutive j in the gathered tensor
+    int mtiles;
+    int nclass;
+    DmaClass cls[kDmaMaxClasses];
+};
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef int rsrc_i4 __attribute__((ext_vector_type(4)));
+
+// One LDS-DMA row slab: 64 lanes x 4 B from rsrc[voff + soff] to LDS[lds_base + 4*lane].
+// Written as inline assembly on purpose: the compiler's waitcnt pass cannot tell the two LDS buffers apart
+// and would put `s_waitcnt vmcnt(0)` in front of the first ds_read of the tile being multiplied, i.e.
+// serialise the prefetch with the MFMAs. The loop drains vmcnt itself right before its barrier (dma_wait).
+#ifndef BCNN_DMA_BUILTIN
+__device__ __forceinline__ void dma_row(rsrc_i4 rs, unsigned lds_base, unsigned voff, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+                 :
+                 : "s"(lds_base), "v"(voff), "s"(rs), "s"(soff)
+                 : "memory", "m0");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#else
+__device__ __forceinline__ void dma_wait() {}
+#endif
+
+template <int WM, int WN>
+__global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const DmaArgs a) {
+    constexpr int TM = 2, TN = 2, BK = 16;
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int AH = BM / 64, BH = BN / 64;
+    static_assert(WM * WN == 4, "4 waves");
+    __shared__ float As[2][BK][BM];
+    __shared__ float Bs[2][BK][BN];
+
+    const ConvShape& s = a.s;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid / WN, wn = wid % WN;
+    const int g = blockIdx.y;
+    const DmaClass& ci = a.cls[blockIdx.z];
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = lb % a.mtiles, pt = lb / a.mtiles;
+    const int m0 = mt * BM;
+    const bool fwd = (a.mode == 0);
+
+    const int c_Wc = ci.Wc;
+    const int col_per_img = s.pointwise ? s.OHOW : ci.Hc * ci.Wc;
+    const int total_cols = s.N * col_per_img;
+    const int p0 = pt * BN;
+    if (p0 >= total_cols) return;  // class smaller than the grid (uniform per block)
+
+    const int lim_y = s.pointwise ? 1 : (fwd ? s.H : s.OH);
+    const int lim_x = s.pointwise ? 1 : (fwd ? s.W : s.OW);
+    const int row_stride = fwd ? s.W : s.OW;
+
+    // decode one column -> element offset of tap (0,0) in the gathered tensor, its coordinates there, output offset
+    auto decode = [&](int col, unsigned& pbase, int& cy, int& cx, unsigned& obase) -> bool {
+        if (col >= total_cols) { pbase = 0; cy = -(1 << 20); cx = -(1 << 20); obase = 0; return false; }
+        const unsigned n = (unsigned)col / (unsigned)col_per_img;
+        const unsigned pix = (unsigned)col - n * (unsigned)col_per_img;
+        const unsigned in_img = n * (unsigned)s.C + (unsigned)(g * s.Cg), out_img = n * (unsigned)s.F + (unsigned)(g * s.Mg);
+        if (s.pointwise) {  // raw [Cg][OH*OW] / [Mg][OH*OW] views on both sides
+            cy = 0; cx = 0;
+            pbase = (fwd ? in_img * (unsigned)s.HW : out_img * (unsigned)s.OHOW) + pix;
+            obase = (fwd ? out_img * (unsigned)s.OHOW : in_img * (unsigned)s.HW) + pix;
+            return true;
+        }
+        const unsigned u = pix / (unsigned)c_Wc, v = pix - u * (unsigned)c_Wc;
+        if (fwd) {
+            cy = (int)u * s.stride - s.pad; cx = (int)v * s.stride - s.pad;
+            pbase = (in_img * (unsigned)s.H + (unsigned)cy) * (unsigned)s.W + (unsigned)cx;
+            obase = out_img * (unsigned)s.OHOW + pix;
+        } else {
+            const int ih = ci.ih0 + (int)u * s.stride, iw = ci.iw0 + (int)v * s.stride;
+            cy = (ih + s.pad) / s.stride; cx = (iw + s.pad) / s.stride;  // exact for this class's taps
+            pbase = (out_img * (unsigned)s.OH + (unsigned)cy) * (unsigned)s.OW + (unsigned)cx;
+            obase = (in_img * (unsigned)s.H + (unsigned)ih) * (unsigned)s.W + (unsigned)iw;
+        }
+        return true;
+    };
+
+    // ---- staging columns of this lane: one per 64-column slab of the B tile ---------------------------
+    unsigned pb[BH];
+    int cy[BH], cx[BH];
+#pragma unroll
+    for (int h = 0; h < BH; ++h) {
+        unsigned ob;
+        decode(p0 + h * 64 + lane, pb[h], cy[h], cx[h], ob);
+    }
+    unsigned voff[BH];
+    auto set_tap = [&](int t) {
+        const int sdy = ci.dy[t], sdx = ci.dx[t];
+        const int shift = sdy * row_stride + sdx;
+#pragma unroll
+        for (int h = 0; h < BH; ++h) {
+            const bool ok = (unsigned)(cy[h] + sdy) < (unsigned)lim_y && (unsigned)(cx[h] + sdx) < (unsigned)lim_x;
+            voff[h] = ok ? (pb[h] + (unsigned)shift) * 4u : kOOB;
+        }
+    };
+
+#ifdef BCNN_DMA_BUILTIN
+    __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)a.b_base, 0, (int)a.b_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)a.at, 0, (int)a.at_bytes, 0x00020000);
+#else
+    auto make_rsrc = [](const void* p, unsigned bytes) {
+        const unsigned long long u = (unsigned long long)p;
+        rsrc_i4 r;
+        r[0] = (int)(unsigned)u; r[1] = (int)(unsigned)((u >> 32) & 0xffffu); r[2] = (int)bytes; r[3] = 0x00020000;
+        return r;
+    };
+    const rsrc_i4 rs_b = make_rsrc(a.b_base, a.b_bytes), rs_a = make_rsrc(a.at, a.at_bytes);
+    const unsigned lds_a0 = (unsigned)(size_t)(lds_void_ptr)&As[0][0][0], lds_b0 = (unsigned)(size_t)(lds_void_ptr)&Bs[0][0][0];
+#endif
+    unsigned a_voff[AH];
+#pragma unroll
+    for (int h = 0; h < AH; ++h) a_voff[h] = (unsigned)(h * 64 + lane) * 4u;
+    const int JB = a.Jpad / BK;
+    const int ntiles = ci.ntaps * JB;
+    const unsigned a_tile0 = ((unsigned)(g * a.kk2 + ci.tap0) * (unsigned)a.Jpad) * (unsigned)a.Mpad + (unsigned)m0;
+
+    // wave `wid` stages rows 4*wid .. 4*wid+3 of both tiles
+    auto stage = [&](int t, int jb, int buf) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * wid + r;
+            const int j = jb * BK + row;
+            const int jc = j < a.J ? j : a.J - 1;  // padded rows meet a zero A row: fetch any legal row
+            const unsigned sb = (unsigned)jc * (unsigned)a.b_major_stride * 4u;
+            const unsigned sa = (a_tile0 + (unsigned)(t * a.Jpad + j) * (unsigned)a.Mpad) * 4u;
+#ifdef BCNN_DMA_BUILTIN
+#pragma unroll
+            for (int h = 0; h < BH; ++h)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void_ptr)&Bs[buf][row][h * 64], 4, voff[h], sb, 0, 0);
+#pragma unroll
+            for (int h = 0; h < AH; ++h)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void_ptr)&As[buf][row][h * 64], 4, a_voff[h], sa, 0, 0);
+#else
+#pragma unroll
+            for (int h = 0; h < BH; ++h) dma_row(rs_b, lds_b0 + (unsigned)(((buf * BK + row) * BN + h * 64) * 4), voff[h], sb);
+#pragma unroll
+            for (int h = 0; h < AH; ++h) dma_row(rs_a, lds_a0 + (unsigned)(((buf * BK + row) * BM + h * 64) * 4), a_voff[h], sa);
+#endif
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int l31 = lane & 31, lhi = lane >> 5;
+    int t_next = 0, jb_next = 0;
+    if (ntiles > 0) {  // a class may own no tap at all (stride > kernel size): it then stores zeros
+        set_tap(0);
+        stage(0, 0, 0);
+    }
+    dma_wait();
+    __syncthreads();
+    for (int it = 0; it < ntiles; ++it) {
+        const int cur = it & 1;
+        if (it + 1 < ntiles) {
+            if (++jb_next == JB) { jb_next = 0; ++t_next; set_tap(t_next); }
+            stage(t_next, jb_next, cur ^ 1);  // DMA in flight under the MFMAs
+        }
+#pragma unroll
+        for (int ks = 0; ks < BK / 2; ++ks) {
+            float af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = As[cur][2 * ks + lhi][(wm * TM + i) * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = Bs[cur][2 * ks + lhi][(wn * TN + j) * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
+        }
+        dma_wait();
+        __syncthreads();
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------------------
+    const unsigned o_row_stride = fwd ? (unsigned)s.OHOW : (s.pointwise ? (unsigned)s.OHOW : (unsigned)s.HW);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        unsigned pbx, ob;
+        int y, x;
+        if (!decode(p0 + (wn * TN + j) * 32 + l31, pbx, y, x, ob)) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * TM + i) * 32 + mfma_row(r, lane);
+                if (m >= a.M) continue;
+                float o = v[r];
+                if (fwd) {
+                    const int fc = g * s.Mg + m;
+                    if (a.add_bias) {
+                        const float b = a.bias[fc];
+                        if (b != 0.0f && b != 1.0f) o += b;  // bcnn_add_scalar (AVX build) skips exactly 0 and 1
+                    }
+                    if (a.act != BCNN_HIP_ACT_NONE)
+                        o = act_fwd_cheap(o, a.act, a.act == BCNN_HIP_ACT_PRELU ? a.slopes[fc] : 0.f);
+                }
+                a.out[(size_t)ob + (size_t)m * o_row_stride] = o;
+            }
+        }
+    }
+}
+
+// ---- weight re-pack: At[g][tap][j][m] = W[g*Mg + f][c][kr][kc] with (m, j) = (f, c) forward, (c, f) dX ----
+struct PackArgs {
+    const float* w;
+    float* at;
+    int Mg, Cg, kk2, ksz;
+    int M, J, Jpad, Mpad;
+    int mode, groups;
+    unsigned char tapoff[kDmaMaxTaps];  // kr*ksz + kc of packed tap index
+};
+
+__global__ __launch_bounds__(256) void conv_pack_weights_kernel(const PackArgs a) {
+    // block: 64 m x 4 j of one (g, tap); m fastest so writes are coalesced
+    const int m = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int j = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int gt = blockIdx.z;
+    const int g = gt / a.kk2, t = gt - g * a.kk2;
+    if (m >= a.Mpad || j >= a.Jpad) return;
+    float v = 0.f;
+    if (m < a.M && j < a.J) {
+        const int f = a.mode == 0 ? m : j, c = a.mode == 0 ? j : m;
+        v = a.w[((size_t)(g * a.Mg + f) * a.Cg + c) * a.kk2 + a.tapoff[t]];
+    }
+    a.at[((size_t)gt * a.Jpad + j) * a.Mpad + m] = v;
+}
+
+// ---- host side ------------------------------------------------------------------------------------------
+struct DmaScratch {
+    float* p = nullptr;
+    size_t cap = 0;
+    int dev = -1;
+};
+static thread_local DmaScratch g_dma_scratch;
+
+static float* dma_scratch(size_t floats) {
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    DmaScratch& sc = g_dma_scratch;
+    if (sc.p == nullptr || sc.cap < floats || sc.dev != dev) {
+        if (sc.p && sc.dev == dev) HIP_CHECK(hipFree(sc.p));  // hipFree synchronises the device
+        const size_t cap = floats < (1u << 20) ? (1u << 20) : floats + floats / 2;
+        HIP_CHECK(hipMalloc((void**)&sc.p, cap * sizeof(float)));
+        sc.cap = cap;
+        sc.dev = dev;
+    }
+    return sc.p;
+}
+
+static int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// Shapes the DMA kernel takes; everything else stays on conv_igemm.hip.
+static bool dma_supported(const ConvShape& s, int M, int J, size_t b_elems) {
+    if (s.ksz > 7 && !s.pointwise) return false;
+    if (M <= 32 || J < 8) return false;                       // tiny GEMM-M / reduction: padding waste
+    if (b_elems * 4 >= 0x7ffffff0ull) return false;           // buffer range / OOB marker
+    const int kk2 = s.pointwise ? 1 : s.ksz * s.ksz;
+    const size_t at = (size_t)s.groups * kk2 * round_up(J, 16) * round_up(M, 128) * 4;
+    if (at >= 0x7ffffff0ull) return false;
+    if ((long long)s.N * (s.OHOW > s.HW ? s.OHOW : s.HW) >= 0x7fffffffLL) return false;
+    return true;
+}
+
+static void launch_dma(DmaArgs& a, int max_cols) {
+    const long long big = (long long)ceil_div(a.M, 128) * ceil_div(max_cols, 128) * a.s.groups * a.nclass;
+    if (a.M <= 64 || (a.M % 128 != 0 && a.M % 128 <= 64 && big < 4 * kCUs)) {
+        a.mtiles = ceil_div(a.M, 64);
+        dim3 grid((unsigned)(a.mtiles * ceil_div(max_cols, 256)), (unsigned)a.s.groups, (unsigned)a.nclass);
+        conv_igemm_dma_kernel<1, 4><<<grid, 256, 0, current_stream()>>>(a);
+    } else {
+        a.mtiles = ceil_div(a.M, 128);
+        dim3 grid((unsigned)(a.mtiles * ceil_div(max_cols, 128)), (unsigned)a.s.groups, (unsigned)a.nclass);
+        conv_igemm_dma_kernel<2, 2><<<grid, 256, 0, current_stream()>>>(a);
+    }
+    KERNEL_CHECK();
+}
+
+static void pack_weights(const float* w, float* at, const ConvShape& s, int mode, int M, int J, int Jpad, int Mpad,
+                         int kk2, const unsigned char* tapoff) {
+    PackArgs p;
+    p.w = w; p.at = at; p.Mg = s.Mg; p.Cg = s.Cg; p.kk2 = kk2; p.ksz = s.ksz;
+    p.M = M; p.J = J; p.Jpad = Jpad; p.Mpad = Mpad; p.mode = mode; p.groups = s.groups;
+    for (int t = 0; t < kk2; ++t) p.tapoff[t] = tapoff[t];
+    dim3 grid((unsigned)(Mpad / 64), (unsigned)ceil_div(Jpad, 4), (unsigned)(s.groups * kk2));
+    conv_pack_weights_kernel<<<grid, 256, 0, current_stream()>>>(p);
+    KERNEL_CHECK();
+}
+
+// Returns false when the shape is not covered (caller falls back to the register-staged kernel).
+bool conv_forward_dma(const float* x, const float* w, const float* bias, const float* slopes, float* y,
+                      const ConvShape& s, int act, int raw) {
+    if (!dma_supported(s, s.Mg, s.Cg, (size_t)s.N * s.C * s.HW)) return false;
+    const int kk2 = s.pointwise ? 1 : s.ksz * s.ksz;
+    DmaArgs a;
+    a.b_base = x; a.out = y; a.bias = bias; a.slopes = slopes; a.s = s;
+    a.mode = 0; a.act = raw ? BCNN_HIP_ACT_NONE : act; a.add_bias = raw ? 0 : 1;
+    a.M = s.Mg; a.J = s.Cg; a.Jpad = round_up(a.J, 16); a.Mpad = round_up(a.M, 128); a.kk2 = kk2;
+    const size_t at_floats = (size_t)s.groups * kk2 * a.Jpad * a.Mpad;
+    float* at = dma_scratch(at_floats);
+    a.at = at; a.at_bytes = (unsigned)(at_floats * 4);
+    a.b_bytes = (unsigned)((size_t)s.N * s.C * s.HW * 4);
+    a.b_major_stride = s.pointwise ? s.OHOW : s.HW;
+    a.nclass = 1;
+    DmaClass& ci = a.cls[0];
+    ci.ih0 = 0; ci.iw0 = 0; ci.Hc = s.OH; ci.Wc = s.OW; ci.ntaps = kk2; ci.tap0 = 0;
+    unsigned char tapoff[kDmaMaxTaps];
+    for (int t = 0; t < kk2; ++t) {
+        tapoff[t] = (unsigned char)t;
+        ci.dy[t] = (signed char)(s.pointwise ? 0 : t / s.ksz);
+        ci.dx[t] = (signed char)(s.pointwise ? 0 : t % s.ksz);
+    }
+    pack_weights(w, at, s, 0, a.M, a.J, a.Jpad, a.Mpad, kk2, tapoff);
+    launch_dma(a, (int)s.total_q);
+    return true;
+}
+
+bool conv_backward_data_dma(const float* w, const float* dy, float* dx, const ConvShape& s) {
+    if (!dma_supported(s, s.Cg, s.Mg, (size_t)s.N * s.F * s.OHOW)) return false;
+    const int kk2 = s.pointwise ? 1 : s.ksz * s.ksz;
+    DmaArgs a;
+    a.b_base = dy; a.out = dx; a.bias = nullptr; a.slopes = nullptr; a.s = s;
+    a.mode = 1; a.act = BCNN_HIP_ACT_NONE; a.add_bias = 0;
+    a.M = s.Cg; a.J = s.Mg; a.Jpad = round_up(a.J, 16); a.Mpad = round_up(a.M, 128); a.kk2 = kk2;
+    const size_t at_floats = (size_t)s.groups * kk2 * a.Jpad * a.Mpad;
+    float* at = dma_scratch(at_floats);
+    a.at = at; a.at_bytes = (unsigned)(at_floats * 4);
+    a.b_bytes = (unsigned)((size_t)s.N * s.F * s.OHOW * 4);
+    a.b_major_stride = s.OHOW;
+    unsigned char tapoff[kDmaMaxTaps];
+    if (s.pointwise) {
+        a.nclass = 1;
+        DmaClass& ci = a.cls[0];
+        ci.ih0 = 0; ci.iw0 = 0; ci.Hc = s.OH; ci.Wc = s.OW; ci.ntaps = 1; ci.tap0 = 0; ci.dy[0] = 0; ci.dx[0] = 0;
+        tapoff[0] = 0;
+        pack_weights(w, at, s, 1, a.M, a.J, a.Jpad, a.Mpad, kk2, tapoff);
+        launch_dma(a, (int)s.total_q);
+        return true;
+    }
+    // stride-parity classes; the packed tap order is class-major
+    const int st = s.stride;
+    struct Pending { DmaClass c; int cols; };
+    Pending all[49];
+    int ncls = 0, tap0 = 0;
+    for (int ra = 0; ra < st; ++ra)
+        for (int rb = 0; rb < st; ++rb) {
+            DmaClass ci;
+            ci.ih0 = ((ra - s.pad) % st + st) % st;  // first row with (ih + pad) % st == ra
+            ci.iw0 = ((rb - s.pad) % st + st) % st;
+            ci.Hc = ci.ih0 < s.H ? (s.H - ci.ih0 + st - 1) / st : 0;
+            ci.Wc = ci.iw0 < s.W ? (s.W - ci.iw0 + st - 1) / st : 0;
+            ci.ntaps = 0; ci.tap0 = tap0;
+            for (int kr = 0; kr < s.ksz; ++kr)
+                for (int kc = 0; kc < s.ksz; ++kc)
+                    if (kr % st == ra && kc % st == rb) {
+                        ci.dy[ci.ntaps] = (signed char)(-(kr / st));
+                        ci.dx[ci.ntaps] = (signed char)(-(kc / st));
+                        tapoff[tap0 + ci.ntaps] = (unsigned char)(kr * s.ksz + kc);
+                        ++ci.ntaps;
+                    }
+            tap0 += ci.ntaps;
+            all[ncls].c = ci;
+            all[ncls].cols = s.N * ci.Hc * ci.Wc;
+            ++ncls;
+        }
+    pack_weights(w, at, s, 1, a.M, a.J, a.Jpad, a.Mpad, kk2, tapoff);
+    for (int c0 = 0; c0 < ncls; c0 += kDmaMaxClasses) {
+        int nc = 0, max_cols = 0;
+        for (int c = c0; c < ncls && nc < kDmaMaxClasses; ++c, ++nc) {
+            a.cls[nc] = all[c].c;
+            if (all[c].cols > max_cols) max_cols = all[c].cols;
+        }
+        a.nclass = nc;
+        if (max_cols > 0) launch_dma(a, max_cols);
+    }
+    return true;
+}
+
+}  // namespace bcnn_hip
