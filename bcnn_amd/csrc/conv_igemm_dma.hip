@@ -29,7 +29,7 @@ constexpr unsigned kOOB = 0x80000000u;  // buffers are limited to < 2 GiB so thi
 struct DmaClass {
     int ih0, iw0, Hc, Wc;  // dX: first row/col and extent of the stride-parity class (forward: 0,0,OH,OW)
     int ntaps, tap0;       // taps of the class, index of its first tap in the packed At
-    signed char dy[kDmaMaxTaps], dx[kDmaMaxTaps];  // coordinate shift of the gathered element per tap
+    int nkx, sgn;          // tap t = (i, j) = (t / nkx, t % nkx) shifts the gathered element by sgn * (i, j)
 };
 
 struct DmaArgs {
@@ -69,8 +69,11 @@ __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" :
 __device__ __forceinline__ void dma_wait() {}
 #endif
 
+#ifndef ABL_LB
+#define ABL_LB 1
+#endif
 template <int WM, int WN>
-__global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const DmaArgs a) {
+__global__ __launch_bounds__(256, ABL_LB) void conv_igemm_dma_kernel(const DmaArgs a) {
     constexpr int TM = 2, TN = 2, BK = 16;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int AH = BM / 64, BH = BN / 64;
@@ -88,6 +91,19 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const DmaArgs a) {
     const int mt = lb % a.mtiles, pt = lb / a.mtiles;
     const int m0 = mt * BM;
     const bool fwd = (a.mode == 0);
+
+    // epilogue constants of this block's rows, staged once (a global load per stored value would serialise
+    // the epilogue on L2 latency). bcnn_add_scalar of the AVX build skips exactly 0 and 1: 1 is stored as 0.
+    __shared__ float s_bias[BM], s_slope[BM];
+    if (fwd && tid < BM) {
+        const int m = m0 + tid;
+        float b = 0.f, sl = 0.f;
+        if (m < a.M) {
+            if (a.add_bias) { b = a.bias[g * s.Mg + m]; if (b == 1.0f) b = 0.f; }
+            if (a.act == BCNN_HIP_ACT_PRELU) sl = a.slopes[g * s.Mg + m];
+        }
+        s_bias[tid] = b; s_slope[tid] = sl;
+    }
 
     const int c_Wc = ci.Wc;
     const int col_per_img = s.pointwise ? s.OHOW : ci.Hc * ci.Wc;
@@ -134,8 +150,10 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const DmaArgs a) {
         decode(p0 + h * 64 + lane, pb[h], cy[h], cx[h], ob);
     }
     unsigned voff[BH];
-    auto set_tap = [&](int t) {
-        const int sdy = ci.dy[t], sdx = ci.dx[t];
+    const int c_nkx = ci.nkx, c_sgn = ci.sgn;
+    int tap_i = 0, tap_j = 0;  // wave-uniform tap counters (SALU)
+    auto set_tap = [&]() {
+        const int sdy = c_sgn * tap_i, sdx = c_sgn * tap_j;
         const int shift = sdy * row_stride + sdx;
 #pragma unroll
         for (int h = 0; h < BH; ++h) {
@@ -200,7 +218,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const DmaArgs a) {
     const int l31 = lane & 31, lhi = lane >> 5;
     int t_next = 0, jb_next = 0;
     if (ntiles > 0) {  // a class may own no tap at all (stride > kernel size): it then stores zeros
-        set_tap(0);
+        set_tap();
         stage(0, 0, 0);
     }
     dma_wait();
@@ -208,23 +226,41 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const DmaArgs a) {
     for (int it = 0; it < ntiles; ++it) {
         const int cur = it & 1;
         if (it + 1 < ntiles) {
-            if (++jb_next == JB) { jb_next = 0; ++t_next; set_tap(t_next); }
+            if (++jb_next == JB) {
+                jb_next = 0; ++t_next;
+                if (++tap_j == c_nkx) { tap_j = 0; ++tap_i; }
+                set_tap();
+            }
+#ifndef ABL_NODMA
             stage(t_next, jb_next, cur ^ 1);  // DMA in flight under the MFMAs
+#endif
         }
+        // fragments of k-step ks+1 are fetched from LDS before the MFMAs of k-step ks are issued
+        float af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[0][i] = As[cur][lhi][(wm * TM + i) * 32 + l31];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[0][j] = Bs[cur][lhi][(wn * TN + j) * 32 + l31];
 #pragma unroll
         for (int ks = 0; ks < BK / 2; ++ks) {
-            float af[TM], bf[TN];
+            const int fc = ks & 1, fn = fc ^ 1;
+            if (ks + 1 < BK / 2) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = As[cur][2 * ks + lhi][(wm * TM + i) * 32 + l31];
+                for (int i = 0; i < TM; ++i) af[fn][i] = As[cur][2 * ks + 2 + lhi][(wm * TM + i) * 32 + l31];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = Bs[cur][2 * ks + lhi][(wn * TN + j) * 32 + l31];
+                for (int j = 0; j < TN; ++j) bf[fn][j] = Bs[cur][2 * ks + 2 + lhi][(wn * TN + j) * 32 + l31];
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMAs (the scheduler sinks it otherwise)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
+                for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(af[fc][i], bf[fc][j], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
         }
+#ifndef ABL_NOBAR
         dma_wait();
         __syncthreads();
+#endif
     }
 
     // ---- epilogue ------------------------------------------------------------------------------------
@@ -245,14 +281,13 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const DmaArgs a) {
                 if (m >= a.M) continue;
                 float o = v[r];
                 if (fwd) {
-                    const int fc = g * s.Mg + m;
-                    if (a.add_bias) {
-                        const float b = a.bias[fc];
-                        if (b != 0.0f && b != 1.0f) o += b;  // bcnn_add_scalar (AVX build) skips exactly 0 and 1
-                    }
-                    if (a.act != BCNN_HIP_ACT_NONE)
-                        o = act_fwd_cheap(o, a.act, a.act == BCNN_HIP_ACT_PRELU ? a.slopes[fc] : 0.f);
+                    const float b = s_bias[m - m0];
+                    if (b != 0.0f) o += b;
+                    if (a.act != BCNN_HIP_ACT_NONE) o = act_fwd_cheap(o, a.act, s_slope[m - m0]);
                 }
+#ifdef ABL_NOSTORE
+                if (o == 123.456f)
+#endif
                 a.out[(size_t)ob + (size_t)m * o_row_stride] = o;
             }
         }
@@ -363,11 +398,8 @@ bool conv_forward_dma(const float* x, const float* w, const float* bias, const f
     DmaClass& ci = a.cls[0];
     ci.ih0 = 0; ci.iw0 = 0; ci.Hc = s.OH; ci.Wc = s.OW; ci.ntaps = kk2; ci.tap0 = 0;
     unsigned char tapoff[kDmaMaxTaps];
-    for (int t = 0; t < kk2; ++t) {
-        tapoff[t] = (unsigned char)t;
-        ci.dy[t] = (signed char)(s.pointwise ? 0 : t / s.ksz);
-        ci.dx[t] = (signed char)(s.pointwise ? 0 : t % s.ksz);
-    }
+    ci.nkx = s.pointwise ? 1 : s.ksz; ci.sgn = 1;
+    for (int t = 0; t < kk2; ++t) tapoff[t] = (unsigned char)t;
     pack_weights(w, at, s, 0, a.M, a.J, a.Jpad, a.Mpad, kk2, tapoff);
     launch_dma(a, (int)s.total_q);
     return true;
@@ -389,7 +421,7 @@ bool conv_backward_data_dma(const float* w, const float* dy, float* dx, const Co
     if (s.pointwise) {
         a.nclass = 1;
         DmaClass& ci = a.cls[0];
-        ci.ih0 = 0; ci.iw0 = 0; ci.Hc = s.OH; ci.Wc = s.OW; ci.ntaps = 1; ci.tap0 = 0; ci.dy[0] = 0; ci.dx[0] = 0;
+        ci.ih0 = 0; ci.iw0 = 0; ci.Hc = s.OH; ci.Wc = s.OW; ci.ntaps = 1; ci.tap0 = 0; ci.nkx = 1; ci.sgn = -1;
         tapoff[0] = 0;
         pack_weights(w, at, s, 1, a.M, a.J, a.Jpad, a.Mpad, kk2, tapoff);
         launch_dma(a, (int)s.total_q);
@@ -407,15 +439,13 @@ bool conv_backward_data_dma(const float* w, const float* dy, float* dx, const Co
             ci.iw0 = ((rb - s.pad) % st + st) % st;
             ci.Hc = ci.ih0 < s.H ? (s.H - ci.ih0 + st - 1) / st : 0;
             ci.Wc = ci.iw0 < s.W ? (s.W - ci.iw0 + st - 1) / st : 0;
-            ci.ntaps = 0; ci.tap0 = tap0;
-            for (int kr = 0; kr < s.ksz; ++kr)
-                for (int kc = 0; kc < s.ksz; ++kc)
-                    if (kr % st == ra && kc % st == rb) {
-                        ci.dy[ci.ntaps] = (signed char)(-(kr / st));
-                        ci.dx[ci.ntaps] = (signed char)(-(kc / st));
-                        tapoff[tap0 + ci.ntaps] = (unsigned char)(kr * s.ksz + kc);
-                        ++ci.ntaps;
-                    }
+            ci.ntaps = 0; ci.tap0 = tap0; ci.sgn = -1;
+            ci.nkx = rb < s.ksz ? (s.ksz - rb + st - 1) / st : 0;  // kc = rb, rb + st, ... ; tap (i, j) <-> (kr/st, kc/st)
+            for (int kr = ra; kr < s.ksz; kr += st)
+                for (int kc = rb; kc < s.ksz; kc += st) {
+                    tapoff[tap0 + ci.ntaps] = (unsigned char)(kr * s.ksz + kc);
+                    ++ci.ntaps;
+                }
             tap0 += ci.ntaps;
             all[ncls].c = ci;
             all[ncls].cols = s.N * ci.Hc * ci.Wc;
