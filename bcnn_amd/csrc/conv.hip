@@ -10,12 +10,24 @@ size_t conv_dw_workspace_floats(const ConvShape& s);
 bool conv_backward_weights(const float* x, const float* dy, float* dw, float* dbias, const ConvShape& s,
                            float* workspace, size_t workspace_floats, bool want_bias);
 void conv_backward_data(const float* w, const float* dy, float* dx, const ConvShape& s);
+// conv_dw_dma.hip: per-tap GEMM with LDS-DMA staging (the general fast path)
+size_t conv_dw_dma_workspace_floats(const ConvShape& s);
+bool conv_backward_weights_dma(const float* x, const float* dy, float* dw, const ConvShape& s, float* workspace,
+                               size_t workspace_floats);
 // conv_direct.hip: LDS-free kernels for small reduction lengths (K <= 32)
 bool conv_forward_direct(const float* x, const float* w, const float* bias, const float* slopes, float* y,
                          const ConvShape& s, int act, int raw);
 size_t conv_dw_direct_workspace_floats(const ConvShape& s);
 bool conv_backward_weights_direct(const float* x, const float* dy, float* dw, float* dbias, const ConvShape& s,
                                   float* workspace, size_t workspace_floats);
+
+static bool conv_backward_weights_dma_timed(const float* x, const float* dy, float* dw, const ConvShape& s,
+                                            float* workspace, size_t workspace_floats) {
+    if (conv_dw_dma_workspace_floats(s) == 0) return false;
+    KTimer kt(K_CONV_DW, 2.0 * (double)s.total_q * s.Mg * s.K * s.groups,
+              4.0 * ((double)s.N * s.C * s.HW + (double)s.F * s.K + (double)s.N * s.F * s.OHOW));
+    return conv_backward_weights_dma(x, dy, dw, s, workspace, workspace_floats);
+}
 
 static void conv_fwd_any(const float* x, const float* w, const float* bias, const float* slopes, float* y,
                          const ConvShape& s, int act, int raw) {
@@ -30,8 +42,11 @@ extern "C" {
 
 size_t bcnn_hip_conv_workspace_size(int n, int c, int h, int w, int f, int k, int stride, int pad, int groups) {
     const ConvShape s = make_conv_shape(n, c, h, w, f, k, stride, pad, groups);
-    const size_t a = conv_dw_workspace_floats(s), b = conv_dw_direct_workspace_floats(s);
-    return a > b ? a : b;
+    size_t m = conv_dw_workspace_floats(s);
+    const size_t b = conv_dw_direct_workspace_floats(s), d = conv_dw_dma_workspace_floats(s);
+    if (b > m) m = b;
+    if (d > m) m = d;
+    return m;
 }
 
 void bcnn_hip_conv_forward(const float* x, const float* w, const float* bias, float* y, int n, int c, int h,
@@ -78,8 +93,11 @@ void bcnn_hip_conv_backward(const float* x, const float* w, const float* y, floa
         bcnn_hip_activation_backward(y, dy, ysize, act, slopes, dslopes, s.OHOW, f);
     }
     bool bias_done;
+    static const int dma_on = getenv("BCNN_HIP_NO_DMA") ? 0 : 1;  // A/B switch for profiling
     if (conv_backward_weights_direct(x, dy, dw, batch_norm ? nullptr : dbias, s, workspace, workspace_elems))
         bias_done = true;
+    else if (dma_on && conv_backward_weights_dma_timed(x, dy, dw, s, workspace, workspace_elems))
+        bias_done = false;
     else
         bias_done = conv_backward_weights(x, dy, dw, dbias, s, workspace, workspace_elems,
                                           /*want_bias=*/!batch_norm);

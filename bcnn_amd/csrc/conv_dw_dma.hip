@@ -1,0 +1,277 @@
+// conv_dw_dma.hip -- convolution weight gradient as a per-tap GEMM whose operand tiles are staged global -> LDS
+// by LDS-DMA, with no vector-ALU work inside the MFMA loop (see conv_igemm_dma.hip for why that matters).
+//
+// Reference semantics: bcnn_backward_conv_layer_cpu, src/layers/bcnn_conv_layer.c:556-561
+//   per image i, group j:  dW_j += dY_ij [Mg x OH*OW] * im2col(x_ij)^T      (beta = 1, accumulates)
+// incl. the 1x1 case where the "col" matrix is the raw source buffer viewed as [Cg][OH*OW] (:562-569).
+//
+// For one filter tap t = (kr, kc):   dW[f][c][t] = sum_q dY[f][q] * X_t[c][q],   q = (n, oh, ow),
+//   X_t[c][q] = x[n][c][oh*s - p + kr][ow*s - p + kc]   (0 outside the image)
+// i.e. a GEMM with M = Mg, N = Cg and the reduction over all output pixels of the batch. A workgroup owns a
+// (f-tile, c-tile, tap, q-range); partial tiles go to the workspace and a second kernel adds them to dW in a
+// fixed order (deterministic; keeps the `+=` onto the momentum carry).
+//
+// Data movement: both tiles are [row][32 q] with q contiguous in memory, so one DMA instruction fills TWO
+// rows (lanes 0-31 / 32-63): the per-lane VGPR offset carries (n, pixel, tap shift, validity, row parity),
+// the wave-uniform SGPR offset carries the row (f or c). Row pairs are laid 66 floats apart in LDS, which
+// makes the MFMA fragment reads (ds_read_b64: lane (row, k-pair)) hit all 64 banks exactly once.
+#include "conv_common.h"
+#include "lds_dma.h"
+
+namespace bcnn_hip {
+
+struct DwDmaArgs {
+    const float* x;
+    const float* dy;
+    float* partials;       // [qsplits][groups][kk2][Mpad][Npad]
+    ConvShape s;
+    int mtiles, ntiles;    // f tiles, c tiles
+    int qsplits, q_per_split;  // q_per_split is a multiple of 32
+    int Mpad, Npad;
+    unsigned x_bytes, dy_bytes;
+    unsigned ow_magic;     // ceil(2^32 / OW)
+    int b_row_stride;      // elements between consecutive c rows of the gathered operand (HW; OH*OW for 1x1)
+    int kk2;
+};
+
+constexpr int DWQ = 32;    // q per K-tile
+constexpr int DWPAIR = 66; // floats per LDS row pair (2 x 32 + 2 pad)
+
+template <int WTM, int WTN>
+__global__ __launch_bounds__(256) void conv_dw_dma_kernel(const DwDmaArgs a) {
+    constexpr int BM = 64 * WTM, BN = 64 * WTN;
+    constexpr int APAIRS = BM / 2, BPAIRS = BN / 2;
+    constexpr int BUF = (APAIRS + BPAIRS) * DWPAIR;  // floats per stage buffer
+    __shared__ float lds[2 * BUF];
+
+    const ConvShape& s = a.s;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int g = blockIdx.y;
+    // taps vary fastest so the workgroups that re-read the same dY / x range run together (L2 reuse)
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int tap = lb % a.kk2;
+    const int rest = lb / a.kk2;
+    const int tiles = a.mtiles * a.ntiles;
+    const int tile = rest % tiles, qs = rest / tiles;
+    const int mt = tile % a.mtiles, nt = tile / a.mtiles;
+    const int f0 = mt * BM, c0 = nt * BN;
+    const int kr = s.pointwise ? 0 : tap / s.ksz, kc = s.pointwise ? 0 : tap - (tap / s.ksz) * s.ksz;
+
+    const unsigned qbeg = (unsigned)qs * (unsigned)a.q_per_split;
+    unsigned qend = qbeg + (unsigned)a.q_per_split;
+    if (qend > (unsigned)s.total_q) qend = (unsigned)s.total_q;
+    const int nkt = qbeg < qend ? (int)((qend - qbeg + DWQ - 1) / DWQ) : 0;
+
+    // ---- per-lane gather state: lane = (q within the K-tile, row parity) -------------------------------
+    unsigned q = qbeg + (unsigned)l31;
+    unsigned n = q / (unsigned)s.OHOW;
+    unsigned pix = q - n * (unsigned)s.OHOW;
+    const unsigned row_a = (unsigned)lhi * (unsigned)s.OHOW, row_b = (unsigned)lhi * (unsigned)a.b_row_stride;
+    unsigned va = kOOB, vb = kOOB;
+    auto lane_offsets = [&]() {
+        const bool qv = q < qend;
+        const unsigned offa = n * (unsigned)(s.F * s.OHOW) + pix + row_a;
+        unsigned offb;
+        bool ok = qv;
+        if (s.pointwise) {
+            offb = n * (unsigned)(s.C * s.HW) + pix + row_b;
+        } else {
+            const unsigned oh = magic_div(pix, a.ow_magic), ow = pix - oh * (unsigned)s.OW;
+            const int ih = (int)oh * s.stride - s.pad + kr, iw = (int)ow * s.stride - s.pad + kc;
+            ok = ok && (unsigned)ih < (unsigned)s.H && (unsigned)iw < (unsigned)s.W;
+            offb = (n * (unsigned)(s.C * s.H) + (unsigned)ih) * (unsigned)s.W + (unsigned)iw + row_b;
+        }
+        va = qv ? offa * 4u : kOOB;
+        vb = ok ? offb * 4u : kOOB;
+    };
+    auto advance = [&]() {  // q += 32 (OH*OW >= 32 is a launch precondition)
+        q += DWQ; pix += DWQ;
+        if (pix >= (unsigned)s.OHOW) { pix -= (unsigned)s.OHOW; ++n; }
+    };
+
+    const rsrc_i4 rs_a = make_rsrc(a.dy, a.dy_bytes), rs_b = make_rsrc(a.x, a.x_bytes);
+    const unsigned lds0 = lds_offset(&lds[0]);
+    const unsigned a_row0 = (unsigned)(g * s.Mg), b_grp = (unsigned)(g * s.Cg) * (unsigned)s.HW;
+
+    // wave `wid` stages APAIRS/4 + BPAIRS/4 row pairs; rows past the end are fetched from row 0 (finite
+    // values that only reach accumulator rows / columns which are never published)
+    auto stage = [&](int buf) {
+        const unsigned base = lds0 + (unsigned)(buf * BUF * 4);
+#pragma unroll
+        for (int i = 0; i < APAIRS / 4; ++i) {
+            const int p = wid * (APAIRS / 4) + i;
+            const int f = f0 + 2 * p;
+            const unsigned soff = (a_row0 + (unsigned)(f < s.Mg ? f : 0)) * (unsigned)s.OHOW * 4u;
+            dma_row(rs_a, base + (unsigned)(p * DWPAIR * 4), va, soff);
+        }
+#pragma unroll
+        for (int i = 0; i < BPAIRS / 4; ++i) {
+            const int p = wid * (BPAIRS / 4) + i;
+            const int c = c0 + 2 * p;
+            const unsigned soff = (b_grp + (unsigned)(c < s.Cg ? c : 0) * (unsigned)a.b_row_stride) * 4u;
+            dma_row(rs_b, base + (unsigned)((APAIRS + p) * DWPAIR * 4), vb, soff);
+        }
+    };
+
+    f32x16 acc[WTM][WTN];
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+        for (int j = 0; j < WTN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment addresses (floats): row rr -> (rr >> 1) * 66 + (rr & 1) * 32, k-pair offset 2 * lhi
+    int a_off[WTM], b_off[WTN];
+#pragma unroll
+    for (int i = 0; i < WTM; ++i) a_off[i] = ((wm * WTM + i) * 16 + (l31 >> 1)) * DWPAIR + (l31 & 1) * 32 + 2 * lhi;
+#pragma unroll
+    for (int j = 0; j < WTN; ++j) b_off[j] = (APAIRS + (wn * WTN + j) * 16 + (l31 >> 1)) * DWPAIR + (l31 & 1) * 32 + 2 * lhi;
+
+    if (nkt > 0) {
+        lane_offsets();
+        stage(0);
+    }
+    dma_wait();
+    __syncthreads();
+    for (int it = 0; it < nkt; ++it) {
+        const int cur = it & 1;
+        if (it + 1 < nkt) {
+            advance();
+            lane_offsets();
+            stage(cur ^ 1);  // DMA in flight under the MFMAs
+        }
+        const float* buf = lds + cur * BUF;
+#pragma unroll
+        for (int kp = 0; kp < DWQ / 4; ++kp) {
+            float2 av[WTM], bv[WTN];
+#pragma unroll
+            for (int i = 0; i < WTM; ++i) av[i] = *reinterpret_cast<const float2*>(buf + a_off[i] + 4 * kp);
+#pragma unroll
+            for (int j = 0; j < WTN; ++j) bv[j] = *reinterpret_cast<const float2*>(buf + b_off[j] + 4 * kp);
+#pragma unroll
+            for (int i = 0; i < WTM; ++i)
+#pragma unroll
+                for (int j = 0; j < WTN; ++j) acc[i][j] = mfma32(av[i].x, bv[j].x, acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < WTM; ++i)
+#pragma unroll
+                for (int j = 0; j < WTN; ++j) acc[i][j] = mfma32(av[i].y, bv[j].y, acc[i][j]);
+        }
+        dma_wait();
+        __syncthreads();
+    }
+
+    // ---- publish the partial tile ---------------------------------------------------------------------
+    float* out = a.partials + ((((size_t)qs * s.groups + g) * a.kk2 + tap) * a.Mpad) * (size_t)a.Npad;
+#pragma unroll
+    for (int i = 0; i < WTM; ++i)
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) {
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int f = f0 + (wm * WTM + i) * 32 + mfma_row(r, lane);
+                const int c = c0 + (wn * WTN + j) * 32 + l31;
+                out[(size_t)f * a.Npad + c] = v[r];
+            }
+        }
+}
+
+// dW[g][f][c][tap] += sum_qs partials[qs][g][tap][f][c]   (fixed order => deterministic)
+__global__ __launch_bounds__(256) void conv_dw_dma_finalize_kernel(const float* __restrict__ partials, int qsplits,
+                                                                   int groups, int Mg, int Cg, int kk2, int Mpad,
+                                                                   int Npad, float* __restrict__ dw) {
+    const size_t total = (size_t)groups * Mg * Cg * kk2;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t plane = (size_t)Mpad * Npad;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int tap = (int)(i % kk2);
+        size_t t = i / kk2;
+        const int c = (int)(t % Cg);
+        t /= Cg;
+        const int f = (int)(t % Mg), g = (int)(t / Mg);
+        const float* p = partials + ((size_t)g * kk2 + tap) * plane + (size_t)f * Npad + c;
+        const size_t qstride = (size_t)groups * kk2 * plane;
+        float sum = 0.f;
+        for (int qs = 0; qs < qsplits; ++qs) sum += p[(size_t)qs * qstride];
+        dw[i] += sum;
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------
+struct DwDmaPlan {
+    bool ok;
+    int WTM, WTN, mtiles, ntiles, qsplits, q_per_split, Mpad, Npad, kk2;
+    size_t partial_floats;
+};
+
+static DwDmaPlan plan_dw_dma(const ConvShape& s) {
+    DwDmaPlan p;
+    p.ok = false;
+    p.partial_floats = 0;
+    if (s.ksz > 7 && !s.pointwise) return p;
+    if (s.Mg < 32 || s.Cg < 16 || (s.Mg & 1) || (s.Cg & 1)) return p;  // row pairs; tiny GEMMs stay on conv_bwd.hip
+    if (s.OHOW < DWQ || s.total_q < 4 * DWQ) return p;
+    if ((size_t)s.N * s.C * s.HW * 4 >= 0x7ffffff0ull || (size_t)s.N * s.F * s.OHOW * 4 >= 0x7ffffff0ull) return p;
+    p.kk2 = s.pointwise ? 1 : s.ksz * s.ksz;
+    p.WTM = s.Mg > 64 ? 2 : 1;
+    p.WTN = s.Cg > 64 ? 2 : 1;
+    const int BM = 64 * p.WTM, BN = 64 * p.WTN;
+    p.mtiles = ceil_div(s.Mg, BM); p.ntiles = ceil_div(s.Cg, BN);
+    p.Mpad = p.mtiles * BM; p.Npad = p.ntiles * BN;
+    const long long tiles = (long long)p.mtiles * p.ntiles * p.kk2 * s.groups;
+    long long want = (6LL * kCUs + tiles - 1) / tiles;                 // ~6 workgroups per CU in total
+    const long long maxs = (s.total_q + 8 * DWQ - 1) / (8 * DWQ);      // >= 8 K-tiles per workgroup
+    if (want > maxs) want = maxs;
+    if (want < 1) want = 1;
+    long long per = (s.total_q + want - 1) / want;
+    per = (per + DWQ - 1) / DWQ * DWQ;
+    p.q_per_split = (int)per;
+    p.qsplits = (int)((s.total_q + per - 1) / per);
+    p.partial_floats = (size_t)p.qsplits * s.groups * p.kk2 * (size_t)p.Mpad * p.Npad;
+    p.ok = true;
+    return p;
+}
+
+size_t conv_dw_dma_workspace_floats(const ConvShape& s) { return plan_dw_dma(s).partial_floats; }
+
+static unsigned magic_of_u(int d) { return d > 1 ? (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned)d) : 0u; }
+
+// Returns false when the shape is not covered (caller falls back to conv_bwd.hip's kernel).
+bool conv_backward_weights_dma(const float* x, const float* dy, float* dw, const ConvShape& s, float* workspace,
+                               size_t workspace_floats) {
+    const DwDmaPlan p = plan_dw_dma(s);
+    if (!p.ok) return false;
+    if (workspace == nullptr || workspace_floats < p.partial_floats) {
+        fprintf(stderr, "[bcnn_hip] conv backward: workspace too small (%zu floats given, %zu needed)\n",
+                workspace_floats, p.partial_floats);
+        exit(1);
+    }
+    DwDmaArgs a;
+    a.x = x; a.dy = dy; a.partials = workspace; a.s = s;
+    a.mtiles = p.mtiles; a.ntiles = p.ntiles; a.qsplits = p.qsplits; a.q_per_split = p.q_per_split;
+    a.Mpad = p.Mpad; a.Npad = p.Npad; a.kk2 = p.kk2;
+    a.x_bytes = (unsigned)((size_t)s.N * s.C * s.HW * 4);
+    a.dy_bytes = (unsigned)((size_t)s.N * s.F * s.OHOW * 4);
+    a.ow_magic = magic_of_u(s.OW);
+    a.b_row_stride = s.pointwise ? s.OHOW : s.HW;
+    dim3 grid((unsigned)(p.mtiles * p.ntiles * p.kk2 * p.qsplits), (unsigned)s.groups);
+    if (p.WTM == 1 && p.WTN == 1) conv_dw_dma_kernel<1, 1><<<grid, 256, 0, current_stream()>>>(a);
+    else if (p.WTM == 1 && p.WTN == 2) conv_dw_dma_kernel<1, 2><<<grid, 256, 0, current_stream()>>>(a);
+    else if (p.WTM == 2 && p.WTN == 1) conv_dw_dma_kernel<2, 1><<<grid, 256, 0, current_stream()>>>(a);
+    else conv_dw_dma_kernel<2, 2><<<grid, 256, 0, current_stream()>>>(a);
+    KERNEL_CHECK();
+    const size_t total = (size_t)s.groups * s.Mg * s.Cg * p.kk2;
+    conv_dw_dma_finalize_kernel<<<stream_grid(total, 256), 256, 0, current_stream()>>>(
+        workspace, p.qsplits, s.groups, s.Mg, s.Cg, p.kk2, p.Mpad, p.Npad, dw);
+    KERNEL_CHECK();
+    return true;
+}
+
+}  // namespace bcnn_hip

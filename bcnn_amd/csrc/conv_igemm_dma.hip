@@ -19,12 +19,12 @@
 // At is the weight tensor re-packed per call to [tap][j (padded to 16)][m (padded to 128)] with zero
 // padding, so ragged M / J need no predicates (a zero A row cancels whatever finite B row was fetched).
 #include "conv_common.h"
+#include "lds_dma.h"
 
 namespace bcnn_hip {
 
 constexpr int kDmaMaxTaps = 49;
 constexpr int kDmaMaxClasses = 4;
-constexpr unsigned kOOB = 0x80000000u;  // buffers are limited to < 2 GiB so this is always out of range
 
 struct DmaClass {
     int ih0, iw0, Hc, Wc;  // dX: first row/col and extent of the stride-parity class (forward: 0,0,OH,OW)
@@ -49,25 +49,6 @@ struct DmaArgs {
     int nclass;
     DmaClass cls[kDmaMaxClasses];
 };
-
-typedef __attribute__((address_space(3))) void* lds_void_ptr;
-typedef int rsrc_i4 __attribute__((ext_vector_type(4)));
-
-// One LDS-DMA row slab: 64 lanes x 4 B from rsrc[voff + soff] to LDS[lds_base + 4*lane].
-// Written as inline assembly on purpose: the compiler's waitcnt pass cannot tell the two LDS buffers apart
-// and would put `s_waitcnt vmcnt(0)` in front of the first ds_read of the tile being multiplied, i.e.
-// serialise the prefetch with the MFMAs. The loop drains vmcnt itself right before its barrier (dma_wait).
-#ifndef BCNN_DMA_BUILTIN
-__device__ __forceinline__ void dma_row(rsrc_i4 rs, unsigned lds_base, unsigned voff, unsigned soff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
-                 :
-                 : "s"(lds_base), "v"(voff), "s"(rs), "s"(soff)
-                 : "memory", "m0");
-}
-__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-#else
-__device__ __forceinline__ void dma_wait() {}
-#endif
 
 #ifndef ABL_LB
 #define ABL_LB 1
@@ -162,19 +143,8 @@ __global__ __launch_bounds__(256, ABL_LB) void conv_igemm_dma_kernel(const DmaAr
         }
     };
 
-#ifdef BCNN_DMA_BUILTIN
-    __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)a.b_base, 0, (int)a.b_bytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)a.at, 0, (int)a.at_bytes, 0x00020000);
-#else
-    auto make_rsrc = [](const void* p, unsigned bytes) {
-        const unsigned long long u = (unsigned long long)p;
-        rsrc_i4 r;
-        r[0] = (int)(unsigned)u; r[1] = (int)(unsigned)((u >> 32) & 0xffffu); r[2] = (int)bytes; r[3] = 0x00020000;
-        return r;
-    };
     const rsrc_i4 rs_b = make_rsrc(a.b_base, a.b_bytes), rs_a = make_rsrc(a.at, a.at_bytes);
-    const unsigned lds_a0 = (unsigned)(size_t)(lds_void_ptr)&As[0][0][0], lds_b0 = (unsigned)(size_t)(lds_void_ptr)&Bs[0][0][0];
-#endif
+    const unsigned lds_a0 = lds_offset(&As[0][0][0]), lds_b0 = lds_offset(&Bs[0][0][0]);
     unsigned a_voff[AH];
 #pragma unroll
     for (int h = 0; h < AH; ++h) a_voff[h] = (unsigned)(h * 64 + lane) * 4u;
@@ -191,19 +161,10 @@ __global__ __launch_bounds__(256, ABL_LB) void conv_igemm_dma_kernel(const DmaAr
             const int jc = j < a.J ? j : a.J - 1;  // padded rows meet a zero A row: fetch any legal row
             const unsigned sb = (unsigned)jc * (unsigned)a.b_major_stride * 4u;
             const unsigned sa = (a_tile0 + (unsigned)(t * a.Jpad + j) * (unsigned)a.Mpad) * 4u;
-#ifdef BCNN_DMA_BUILTIN
-#pragma unroll
-            for (int h = 0; h < BH; ++h)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_void_ptr)&Bs[buf][row][h * 64], 4, voff[h], sb, 0, 0);
-#pragma unroll
-            for (int h = 0; h < AH; ++h)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_void_ptr)&As[buf][row][h * 64], 4, a_voff[h], sa, 0, 0);
-#else
 #pragma unroll
             for (int h = 0; h < BH; ++h) dma_row(rs_b, lds_b0 + (unsigned)(((buf * BK + row) * BN + h * 64) * 4), voff[h], sb);
 #pragma unroll
             for (int h = 0; h < AH; ++h) dma_row(rs_a, lds_a0 + (unsigned)(((buf * BK + row) * BM + h * 64) * 4), a_voff[h], sa);
-#endif
         }
     };
 

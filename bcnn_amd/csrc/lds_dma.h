@@ -1,0 +1,38 @@
+// lds_dma.h -- global -> LDS direct loads (`buffer_load_dword ... lds`) for the DMA-staged GEMM kernels.
+#pragma once
+#include "common.h"
+
+namespace bcnn_hip {
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef int rsrc_i4 __attribute__((ext_vector_type(4)));
+
+constexpr unsigned kOOB = 0x80000000u;  // buffers are limited to < 2 GiB so this voffset is always out of range
+
+// raw buffer descriptor (stride 0, no swizzle): range check on voffset + inst_offset only, soffset is unchecked
+__device__ __forceinline__ rsrc_i4 make_rsrc(const void* p, unsigned bytes) {
+    const unsigned long long u = (unsigned long long)p;
+    rsrc_i4 r;
+    r[0] = (int)(unsigned)u; r[1] = (int)(unsigned)((u >> 32) & 0xffffu); r[2] = (int)bytes; r[3] = 0x00020000;
+    return r;
+}
+
+__device__ __forceinline__ unsigned lds_offset(const void* p) { return (unsigned)(size_t)(lds_void_ptr)p; }
+
+// One LDS-DMA slab: 64 lanes x 4 B from rsrc[voff + soff] to LDS[lds_base + 4*lane]; an out-of-range voff
+// deposits 0.0. Written as inline assembly on purpose: the compiler's waitcnt pass cannot tell the two LDS
+// buffers apart and would put `s_waitcnt vmcnt(0)` in front of the first ds_read of the tile being
+// multiplied, i.e. serialise the prefetch with the MFMAs. The loops drain vmcnt themselves right before
+// their barrier (dma_wait).
+__device__ __forceinline__ void dma_row(rsrc_i4 rs, unsigned lds_base, unsigned voff, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+                 :
+                 : "s"(lds_base), "v"(voff), "s"(rs), "s"(soff)
+                 : "memory", "m0");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// n / d via multiply-high with magic = ceil(2^32 / d) (exact while n * d < 2^32); d == 1 is encoded as magic 0.
+__device__ __forceinline__ unsigned magic_div(unsigned n, unsigned magic) { return magic ? __umulhi(n, magic) : n; }
+
+}  // namespace bcnn_hip
