@@ -122,6 +122,20 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ w, float* 
     }
 }
 
+// one workgroup per table entry (<= BCNN_HIP_SGD_CHUNK elements of one buffer)
+__global__ __launch_bounds__(256) void sgd_chunks_kernel(const bcnn_hip_sgd_chunk* __restrict__ chunks, float wd_b,
+                                                         float neg_lr_b, float momentum) {
+    const bcnn_hip_sgd_chunk ch = chunks[blockIdx.x];
+    const float wd = ch.use_decay ? wd_b : 0.f;
+    for (unsigned i = threadIdx.x; i < ch.count; i += 256) {
+        float gi = ch.g_d[i], wi = ch.w_d[i];
+        if (wd != 0.f) gi = __fadd_rn(__fmul_rn(wi, wd), gi);
+        wi = __fadd_rn(__fmul_rn(gi, neg_lr_b), wi);
+        ch.w_d[i] = wi;
+        ch.g_d[i] = (momentum == 0.0f) ? 0.f : ((momentum == 1.0f) ? gi : gi * momentum);
+    }
+}
+
 }  // namespace bcnn_hip
 
 using namespace bcnn_hip;
@@ -187,6 +201,14 @@ void bcnn_hip_sgd_update(float* w, float* b, float* dw, float* db, size_t w_size
                                                                          neg_lr_b, momentum);
         KERNEL_CHECK();
     }
+}
+
+void bcnn_hip_sgd_update_chunks(const bcnn_hip_sgd_chunk* chunks_d, int num_chunks, int batch_size, float lr,
+                                float momentum, float decay) {
+    if (num_chunks <= 0) return;
+    sgd_chunks_kernel<<<num_chunks, 256, 0, current_stream()>>>(chunks_d, decay * batch_size, -lr / batch_size,
+                                                              momentum);
+    KERNEL_CHECK();
 }
 
 }  // extern "C"

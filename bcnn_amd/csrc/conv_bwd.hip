@@ -160,22 +160,33 @@ __global__ __launch_bounds__(256) void conv_dw_kernel(const ConvDwArgs a) {
 }
 
 // dW[g][f][k] += sum_p partials[p][g][f][k]; column K (if bias_col) goes to dbias[g*Mg + f].
+// 16 outputs x 16 interleaved sub-sums per workgroup, combined in a fixed order (deterministic): the split
+// counts run into the hundreds for small GEMMs, a single thread per output would be a serial latency chain.
 __global__ __launch_bounds__(256) void conv_dw_finalize_kernel(const float* __restrict__ partials, int nparts,
                                                                int groups, int Mg, int K, int MP, int NP,
                                                                int bias_col, float* __restrict__ dw,
                                                                float* __restrict__ dbias) {
+    __shared__ float red[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int kcols = K + (bias_col ? 1 : 0);
     const long long total = (long long)groups * Mg * kcols;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const int k = (int)(i % kcols);
+    const long long i = (long long)blockIdx.x * 16 + tx;
+    int k = 0, f = 0, g = 0;
+    float sum = 0.f;
+    if (i < total) {
+        k = (int)(i % kcols);
         const long long t = i / kcols;
-        const int f = (int)(t % Mg), g = (int)(t / Mg);
-        float sum = 0.f;
-        for (int p = 0; p < nparts; ++p)
-            sum += partials[(((long long)p * groups + g) * MP + f) * NP + k];
-        if (k < K) dw[((long long)g * Mg + f) * K + k] += sum;
-        else dbias[g * Mg + f] += sum;
+        f = (int)(t % Mg); g = (int)(t / Mg);
+        for (int p = ty; p < nparts; p += 16) sum += partials[(((long long)p * groups + g) * MP + f) * NP + k];
+    }
+    red[ty][tx] = sum;
+    __syncthreads();
+    if (ty == 0 && i < total) {
+        float tot = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tot += red[r][tx];
+        if (k < K) dw[((long long)g * Mg + f) * K + k] += tot;
+        else dbias[g * Mg + f] += tot;
     }
 }
 
@@ -230,7 +241,7 @@ bool conv_backward_weights(const float* x, const float* dy, float* dw, float* db
     else conv_dw_kernel<2, 2><<<grid, 256, 0, current_stream()>>>(a);
     KERNEL_CHECK();
     const long long total = (long long)s.groups * s.Mg * (s.K + p.bias_col);
-    conv_dw_finalize_kernel<<<stream_grid((size_t)total, 256), 256, 0, current_stream()>>>(
+    conv_dw_finalize_kernel<<<(unsigned)((total + 15) / 16), 256, 0, current_stream()>>>(
         workspace, p.qsplits * 4, s.groups, s.Mg, s.K, p.mtiles * p.TM * 32, p.ntiles * p.TN * 32, p.bias_col,
         dw, dbias);
     KERNEL_CHECK();

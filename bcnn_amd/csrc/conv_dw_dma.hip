@@ -184,24 +184,32 @@ __global__ __launch_bounds__(256) void conv_dw_dma_kernel(const DwDmaArgs a) {
 }
 
 // dW[g][f][c][tap] += sum_qs partials[qs][g][tap][f][c]   (fixed order => deterministic)
+// 64 outputs x 4 interleaved sub-sums per workgroup; threads run along c so the (qsplits x larger) partial
+// reads are coalesced and only the single dW read-modify-write is strided by the tap count.
 __global__ __launch_bounds__(256) void conv_dw_dma_finalize_kernel(const float* __restrict__ partials, int qsplits,
                                                                    int groups, int Mg, int Cg, int kk2, int Mpad,
                                                                    int Npad, float* __restrict__ dw) {
-    const size_t total = (size_t)groups * Mg * Cg * kk2;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const size_t total = (size_t)groups * kk2 * Mg * Cg;
+    const size_t i = (size_t)blockIdx.x * 64 + tx;
     const size_t plane = (size_t)Mpad * Npad;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const int tap = (int)(i % kk2);
-        size_t t = i / kk2;
-        const int c = (int)(t % Cg);
-        t /= Cg;
-        const int f = (int)(t % Mg), g = (int)(t / Mg);
+    const size_t qstride = (size_t)groups * kk2 * plane;
+    float sum = 0.f;
+    size_t o = 0;
+    if (i < total) {
+        const int c = (int)(i % Cg);
+        size_t t = i / Cg;
+        const int f = (int)(t % Mg);
+        t /= Mg;
+        const int tap = (int)(t % kk2), g = (int)(t / kk2);
         const float* p = partials + ((size_t)g * kk2 + tap) * plane + (size_t)f * Npad + c;
-        const size_t qstride = (size_t)groups * kk2 * plane;
-        float sum = 0.f;
-        for (int qs = 0; qs < qsplits; ++qs) sum += p[(size_t)qs * qstride];
-        dw[i] += sum;
+        for (int qs = ty; qs < qsplits; qs += 4) sum += p[(size_t)qs * qstride];
+        o = (((size_t)g * Mg + f) * Cg + c) * kk2 + tap;
     }
+    red[ty][tx] = sum;
+    __syncthreads();
+    if (ty == 0 && i < total) dw[o] += ((red[0][tx] + red[1][tx]) + red[2][tx]) + red[3][tx];
 }
 
 // ---- host side ------------------------------------------------------------------------------------------
@@ -268,7 +276,7 @@ bool conv_backward_weights_dma(const float* x, const float* dy, float* dw, const
     else conv_dw_dma_kernel<2, 2><<<grid, 256, 0, current_stream()>>>(a);
     KERNEL_CHECK();
     const size_t total = (size_t)s.groups * s.Mg * s.Cg * p.kk2;
-    conv_dw_dma_finalize_kernel<<<stream_grid(total, 256), 256, 0, current_stream()>>>(
+    conv_dw_dma_finalize_kernel<<<(unsigned)((total + 63) / 64), 256, 0, current_stream()>>>(
         workspace, p.qsplits, s.groups, s.Mg, s.Cg, p.kk2, p.Mpad, p.Npad, dw);
     KERNEL_CHECK();
     return true;

@@ -28,23 +28,28 @@ __global__ __launch_bounds__(256) void add_rowvec_kernel(float* __restrict__ y, 
     for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gs) y[t] += v[t % (unsigned)cols];
 }
 
-// one thread per (n, spatial position): max, log-sum-exp, exp(x - lse); exp/log in double like the reference
+// one wave per (n, spatial position): max, log-sum-exp, exp(x - lse); exp/log in double like the reference
+// (src/layers/bcnn_softmax_layer.c:95-123). The reference adds the exponentials sequentially in float; here
+// the 64 lane partials are accumulated in double and rounded once, which differs from it by a few float ulps.
 __global__ __launch_bounds__(256) void softmax_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int HW,
                                                       unsigned total) {
-    const unsigned gs = gridDim.x * blockDim.x;
-    for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gs) {
+    const int lane = threadIdx.x & 63;
+    const unsigned wave = blockIdx.x * 4u + (threadIdx.x >> 6), nwaves = gridDim.x * 4u;
+    for (unsigned t = wave; t < total; t += nwaves) {
         const unsigned i = t % (unsigned)HW, n = t / (unsigned)HW;
         const float* px = x + (size_t)n * C * HW + i;
         float* py = y + (size_t)n * C * HW + i;
         float vmax = -FLT_MAX;
-        for (int c = 0; c < C; ++c) {
-            const float v = px[(size_t)c * HW];
-            if (v > vmax) vmax = v;
-        }
-        float sum = 0.f;
-        for (int c = 0; c < C; ++c) sum += (float)exp((double)(px[(size_t)c * HW] - vmax));
+        for (int c = lane; c < C; c += 64) vmax = fmaxf(vmax, px[(size_t)c * HW]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+        double part = 0.0;
+        for (int c = lane; c < C; c += 64) part += (double)(float)exp((double)(px[(size_t)c * HW] - vmax));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+        float sum = (float)part;
         sum = (sum != 0.f) ? vmax + (float)log((double)sum) : vmax - 100.0f;
-        for (int c = 0; c < C; ++c) py[(size_t)c * HW] = (float)exp((double)(px[(size_t)c * HW] - sum));
+        for (int c = lane; c < C; c += 64) py[(size_t)c * HW] = (float)exp((double)(px[(size_t)c * HW] - sum));
     }
 }
 
@@ -73,7 +78,7 @@ void bcnn_hip_add_rowvec(float* y, const float* v, int rows, int cols) {
 void bcnn_hip_softmax_forward(const float* x, float* y, int n, int c, int hw) {
     const long long total = (long long)n * hw;
     if (total <= 0) return;
-    softmax_kernel<<<stream_grid((size_t)total, 256), 256, 0, current_stream()>>>(x, y, c, hw, (unsigned)total);
+    softmax_kernel<<<stream_grid((size_t)total * 64, 256), 256, 0, current_stream()>>>(x, y, c, hw, (unsigned)total);
     KERNEL_CHECK();
 }
 

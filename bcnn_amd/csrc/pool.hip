@@ -67,6 +67,38 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
     }
 }
 
+// Same gather, vectorised: one thread per 4 consecutive source pixels of a row (16-byte read-modify-write of
+// dx, one division per 4 elements). The windows covering the 4 pixels are visited
+// in ascending output order, so every dx element still sees its additions in the reference's order.
+__global__ __launch_bounds__(256) void maxpool_bwd_vec4_kernel(const float* __restrict__ dy, const int* __restrict__ idx,
+                                                               float* __restrict__ dx, int H, int W, int OH, int OW,
+                                                               int size, int stride) {
+    const int W4 = W >> 2;
+    const int t = blockIdx.x * 256 + threadIdx.x;  // (row, group of 4) within the plane
+    const int plane = blockIdx.y;
+    if (t >= H * W4) return;
+    const int h = t / W4, w0 = (t - h * W4) * 4;
+    const int s0 = (plane * H + h) * W + w0;
+    int i0 = (h - size + stride) / stride; if (h - size + 1 <= 0) i0 = 0;
+    int j0 = (w0 - size + stride) / stride; if (w0 - size + 1 <= 0) j0 = 0;
+    int i1 = h / stride; if (i1 > OH - 1) i1 = OH - 1;
+    int j1 = (w0 + 3) / stride; if (j1 > OW - 1) j1 = OW - 1;
+    float4 v = *reinterpret_cast<const float4*>(dx + s0);
+    bool hit = false;
+    for (int i = i0; i <= i1; ++i) {
+        const int o = (plane * OH + i) * OW;
+        for (int j = j0; j <= j1; ++j) {
+            const unsigned d = (unsigned)(idx[o + j] - s0);
+            if (d < 4u) {
+                const float g = dy[o + j];
+                if (d == 0) v.x += g; else if (d == 1) v.y += g; else if (d == 2) v.z += g; else v.w += g;
+                hit = true;
+            }
+        }
+    }
+    if (hit) *reinterpret_cast<float4*>(dx + s0) = v;
+}
+
 // Global average pooling: one wave64 per (n,c) plane, shuffle reduction, then / (H*W).
 __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                           int planes, int HW) {
@@ -110,6 +142,13 @@ void bcnn_hip_maxpool_backward(const float* dy, const int* indexes, float* dx, i
                                int out_h, int out_w, int size, int stride) {
     const long long total = (long long)n * c * h * w;
     if (!total || !(out_h * out_w)) return;
+    if ((w & 3) == 0 && total < 0x7fffffffLL && (long long)n * c <= 65535 &&
+        (reinterpret_cast<uintptr_t>(dx) & 15) == 0) {
+        dim3 grid((unsigned)ceil_div(h * (w / 4), 256), (unsigned)(n * c));
+        maxpool_bwd_vec4_kernel<<<grid, 256, 0, current_stream()>>>(dy, indexes, dx, h, w, out_h, out_w, size, stride);
+        KERNEL_CHECK();
+        return;
+    }
     maxpool_bwd_kernel<<<stream_grid((size_t)total, 256), 256, 0, current_stream()>>>(
         dy, indexes, dx, h, w, out_h, out_w, size, stride, (unsigned)total);
     KERNEL_CHECK();

@@ -235,6 +235,8 @@ void bcnn_end_net(bcnn_net **pnet) {
         }
         bcnn_hip_free(hc->param_arena_gpu);
         bcnn_hip_free(hc->grad_arena_gpu);
+        bcnn_hip_free(hc->sgd_chunks_gpu);
+        free(hc->sgd_chunks_host);
     }
     for (int i = 0; i < net->num_nodes; ++i) {
         bcnn_node *nd = &net->nodes[i];
@@ -393,10 +395,42 @@ static void step_learning_rate(bcnn_net *net) {
     }
 }
 
+/* The reference walks the nodes and issues one SGD step per node (bcnn_net.c:316-326). Here the first
+ * call only RECORDS which buffers the nodes' update() workers step (and with which rule); the table goes
+ * to the device once and every update is then a single launch over all of them. */
+static void sgd_table_add(bcnn_hip_context *hc, float *w, float *g, size_t n, int use_decay) {
+    for (size_t off = 0; off < n; off += BCNN_HIP_SGD_CHUNK) {
+        if (hc->num_sgd_chunks == hc->cap_sgd_chunks) {
+            hc->cap_sgd_chunks = hc->cap_sgd_chunks ? 2 * hc->cap_sgd_chunks : 1024;
+            hc->sgd_chunks_host = (bcnn_hip_sgd_chunk *)realloc(hc->sgd_chunks_host,
+                                                                (size_t)hc->cap_sgd_chunks * sizeof(bcnn_hip_sgd_chunk));
+        }
+        bcnn_hip_sgd_chunk *c = &hc->sgd_chunks_host[hc->num_sgd_chunks++];
+        c->w_d = w + off;
+        c->g_d = g + off;
+        c->count = (unsigned int)((n - off < BCNN_HIP_SGD_CHUNK) ? (n - off) : BCNN_HIP_SGD_CHUNK);
+        c->use_decay = (unsigned int)use_decay;
+    }
+}
+
 void bcnn_update(bcnn_net *net) {
+    bcnn_hip_context *hc = hctx(net);
     step_learning_rate(net);
-    for (int i = 0; i < net->num_nodes; ++i)
-        if (net->nodes[i].update) net->nodes[i].update(net, &net->nodes[i]);
+    if (hc->sgd_chunks_gpu == NULL) {
+        hc->sgd_collecting = 1;
+        hc->num_sgd_chunks = 0;
+        for (int i = 0; i < net->num_nodes; ++i)
+            if (net->nodes[i].update) net->nodes[i].update(net, &net->nodes[i]);
+        hc->sgd_collecting = 0;
+        if (hc->num_sgd_chunks == 0) return;
+        hc->sgd_chunks_gpu = bcnn_hip_malloc_f32(((size_t)hc->num_sgd_chunks * sizeof(bcnn_hip_sgd_chunk) + 3) / 4);
+        bcnn_hip_memcpy_h2d(hc->sgd_chunks_gpu, hc->sgd_chunks_host,
+                            (size_t)hc->num_sgd_chunks * sizeof(bcnn_hip_sgd_chunk));
+    }
+    const bcnn_learner *ln = net->learner;
+    bcnn_hip_sgd_update_chunks((const bcnn_hip_sgd_chunk *)hc->sgd_chunks_gpu, hc->num_sgd_chunks,
+                               net->batch_size * hc->dp_world, ln->learning_rate, ln->momentum / (float)hc->dp_world,
+                               ln->decay);
 }
 
 /* One fused pass per buffer (reference: axpy/axpy/scal sequence, bcnn_learner.c:67-104). Under data
@@ -406,6 +440,13 @@ void bcnn_update(bcnn_net *net) {
 void bcnn_node_sgd_step(bcnn_net *net, bcnn_tensor *weights, bcnn_tensor *biases) {
     const bcnn_learner *ln = net->learner;
     const int world = hctx(net)->dp_world;
+    if (hctx(net)->sgd_collecting) { /* bcnn_update is building its one-launch table */
+        if (biases && biases->data_gpu && biases->grad_data_gpu)
+            sgd_table_add(hctx(net), biases->data_gpu, biases->grad_data_gpu, (size_t)bcnn_tensor_size(biases), 0);
+        if (weights && weights->data_gpu && weights->grad_data_gpu)
+            sgd_table_add(hctx(net), weights->data_gpu, weights->grad_data_gpu, (size_t)bcnn_tensor_size(weights), 1);
+        return;
+    }
     bcnn_hip_sgd_update(weights ? weights->data_gpu : NULL, biases ? biases->data_gpu : NULL,
                         weights ? weights->grad_data_gpu : NULL, biases ? biases->grad_data_gpu : NULL,
                         weights ? (size_t)bcnn_tensor_size(weights) : 0, biases ? (size_t)bcnn_tensor_size(biases) : 0,

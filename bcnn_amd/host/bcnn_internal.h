@@ -120,6 +120,12 @@ typedef struct bcnn_hip_context {
     int dp_rank;
     int dp_world;
     int compiled;
+    /* update loop folded into one launch: table of (buffer, gradient, count, rule) chunks, built by the
+     * first bcnn_update from what the nodes' update() workers ask for */
+    struct bcnn_hip_sgd_chunk *sgd_chunks_host;
+    void *sgd_chunks_gpu;
+    int num_sgd_chunks, cap_sgd_chunks;
+    int sgd_collecting;
 } bcnn_hip_context;
 
 /* ---- net ------------------------------------------------------------------------------------------ */

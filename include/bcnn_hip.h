@@ -208,6 +208,20 @@ void bcnn_hip_sgd_update(float *w_d, float *b_d, float *dw_d, float *db_d, size_
                          size_t b_size, int batch_size, float learning_rate, float momentum,
                          float decay);
 
+/* The same step for MANY buffers in one launch (a net's update loop, bcnn_net.c:316-326, issues one
+ * bcnn_sgd_update per node: ~40 tiny launches for ResNet-18). `chunks_d` is a device array of
+ * bcnn_hip_sgd_chunk, each at most BCNN_HIP_SGD_CHUNK elements of one buffer; `use_decay` selects the
+ * weights rule (decay term) or the biases rule. The caller builds the table once per net. */
+#define BCNN_HIP_SGD_CHUNK 2048
+typedef struct bcnn_hip_sgd_chunk {
+    float *w_d;
+    float *g_d;
+    unsigned int count;
+    unsigned int use_decay;
+} bcnn_hip_sgd_chunk;
+void bcnn_hip_sgd_update_chunks(const bcnn_hip_sgd_chunk *chunks_d, int num_chunks, int batch_size,
+                                float learning_rate, float momentum, float decay);
+
 /* ---------------------------------------------------------------------------------------------
  * "Next" rows: the nodes either side of the hot path that a ResNet-style
  * graph needs, kept on the device so that a training step has no host round trip.
