@@ -14,7 +14,10 @@
 // Data movement: both tiles are [row][32 q] with q contiguous in memory, so one DMA instruction fills TWO
 // rows (lanes 0-31 / 32-63): the per-lane VGPR offset carries (n, pixel, tap shift, validity, row parity),
 // the wave-uniform SGPR offset carries the row (f or c). Row pairs are laid 66 floats apart in LDS, which
-// makes the MFMA fragment reads (ds_read_b64: lane (row, k-pair)) hit all 64 banks exactly once.
+// makes the MFMA fragment reads (ds_read_b64: lane (row, k-pair)) hit all 64 banks exactly once (the
+// compiler pairs them into ds_read2_b64, which is 2-way conflicted on its 32-bank view; LDS is ~20 % busy so
+// that is harmless, and the alternative -- interleaving the two rows lane by lane so that ds_read2_b32 is
+// conflict-free -- measured 6 % SLOWER because the global side of the DMA then gathers 8-byte pieces).
 #include "conv_common.h"
 #include "lds_dma.h"
 
@@ -142,7 +145,9 @@ __global__ __launch_bounds__(256) void conv_dw_dma_kernel(const DwDmaArgs a) {
         if (it + 1 < nkt) {
             advance();
             lane_offsets();
+#ifndef ABL_NODMA
             stage(cur ^ 1);  // DMA in flight under the MFMAs
+#endif
         }
         const float* buf = lds + cur * BUF;
 #pragma unroll
@@ -161,8 +166,10 @@ __global__ __launch_bounds__(256) void conv_dw_dma_kernel(const DwDmaArgs a) {
 #pragma unroll
                 for (int j = 0; j < WTN; ++j) acc[i][j] = mfma32(av[i].y, bv[j].y, acc[i][j]);
         }
+#ifndef ABL_NOBAR
         dma_wait();
         __syncthreads();
+#endif
     }
 
     // ---- publish the partial tile ---------------------------------------------------------------------
