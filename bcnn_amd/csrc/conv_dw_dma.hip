@@ -235,13 +235,17 @@ static DwDmaPlan plan_dw_dma(const ConvShape& s) {
     if (s.OHOW < DWQ || s.total_q < 4 * DWQ) return p;
     if ((size_t)s.N * s.C * s.HW * 4 >= 0x7ffffff0ull || (size_t)s.N * s.F * s.OHOW * 4 >= 0x7ffffff0ull) return p;
     p.kk2 = s.pointwise ? 1 : s.ksz * s.ksz;
-    p.WTM = s.Mg > 64 ? 2 : 1;
-    p.WTN = s.Cg > 64 ? 2 : 1;
+    p.WTM = s.Mg > 64 ? 2 : 1;  // measured on the ResNet shapes: 128 x 64 tiles with ~8 workgroups per CU win
+    p.WTN = 1;                  // (more resident waves beat the larger tile's DMA / fragment reuse)
+    static const char* forced = getenv("BCNN_HIP_DW_TILE");  // experiments: "11", "12", "21", "22"
+    if (forced && forced[0] && forced[1]) { p.WTM = forced[0] == '2' ? 2 : 1; p.WTN = forced[1] == '2' ? 2 : 1; }
+    static const char* wantenv = getenv("BCNN_HIP_DW_WANT");
+    const int want_per_cu = wantenv ? atoi(wantenv) : 8;
     const int BM = 64 * p.WTM, BN = 64 * p.WTN;
     p.mtiles = ceil_div(s.Mg, BM); p.ntiles = ceil_div(s.Cg, BN);
     p.Mpad = p.mtiles * BM; p.Npad = p.ntiles * BN;
     const long long tiles = (long long)p.mtiles * p.ntiles * p.kk2 * s.groups;
-    long long want = (6LL * kCUs + tiles - 1) / tiles;                 // ~6 workgroups per CU in total
+    long long want = ((long long)want_per_cu * kCUs + tiles - 1) / tiles;  // workgroups per CU in total
     const long long maxs = (s.total_q + 8 * DWQ - 1) / (8 * DWQ);      // >= 8 K-tiles per workgroup
     if (want > maxs) want = maxs;
     if (want < 1) want = 1;

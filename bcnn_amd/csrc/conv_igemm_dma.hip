@@ -53,9 +53,9 @@ struct DmaArgs {
 #ifndef ABL_LB
 #define ABL_LB 1
 #endif
-template <int WM, int WN>
+template <int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(256, ABL_LB) void conv_igemm_dma_kernel(const DmaArgs a) {
-    constexpr int TM = 2, TN = 2, BK = 16;
+    constexpr int BK = 16;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int AH = BM / 64, BH = BN / 64;
     static_assert(WM * WN == 4, "4 waves");
@@ -316,18 +316,40 @@ static bool dma_supported(const ConvShape& s, int M, int J, size_t b_elems) {
     return true;
 }
 
-static void launch_dma(DmaArgs& a, int max_cols) {
-    const long long big = (long long)ceil_div(a.M, 128) * ceil_div(max_cols, 128) * a.s.groups * a.nclass;
-    if (a.M <= 64 || (a.M % 128 != 0 && a.M % 128 <= 64 && big < 4 * kCUs)) {
-        a.mtiles = ceil_div(a.M, 64);
-        dim3 grid((unsigned)(a.mtiles * ceil_div(max_cols, 256)), (unsigned)a.s.groups, (unsigned)a.nclass);
-        conv_igemm_dma_kernel<1, 4><<<grid, 256, 0, current_stream()>>>(a);
-    } else {
-        a.mtiles = ceil_div(a.M, 128);
-        dim3 grid((unsigned)(a.mtiles * ceil_div(max_cols, 128)), (unsigned)a.s.groups, (unsigned)a.nclass);
-        conv_igemm_dma_kernel<2, 2><<<grid, 256, 0, current_stream()>>>(a);
-    }
+// Tile shapes. Measured on the ResNet-18 shapes (tools/exp/tile_sweep.sh, TFLOP/s forward / dX):
+//                      128x128   64x256   128x64   64x128   64x64
+//   64ch  56x56 3x3      53/56    87/92    56/57    95/97   95/98
+//   128ch 28x28 3x3      82/85    82/85    91/93    92/95   98/100
+//   256ch 14x14 3x3      89/91    87/90    90/91    89/91   99/100
+//   512ch  7x7  3x3      69/71    65/66    84/86    85/87   88/90
+// The 64x64 tile (four waves of one 32x32 accumulator) wins everywhere: it keeps 8+ waves per SIMD resident
+// (16 accumulator registers, 16 KB of LDS) so DMA latency, barriers and epilogues of one workgroup hide under
+// the MFMAs of the others, and N*OH*OW = 2^k * 49 quantises onto the 256 CUs far better in small tiles (a
+// 128x128 grid lands on 3.06 / 1.53 workgroups per CU: a quarter of the chip idles in the last round).
+static int pick_dma_tile(const DmaArgs& a, int max_cols) {
+    static const char* forced = getenv("BCNN_HIP_IGEMM_TILE");  // experiments: 0..4
+    if (forced && forced[0] >= '0' && forced[0] <= '4') return forced[0] - '0';
+    (void)a; (void)max_cols;
+    return 4;
+}
+
+template <int WM, int WN, int TM, int TN>
+static void launch_dma_cfg(DmaArgs& a, int max_cols) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    a.mtiles = ceil_div(a.M, BM);
+    dim3 grid((unsigned)(a.mtiles * ceil_div(max_cols, BN)), (unsigned)a.s.groups, (unsigned)a.nclass);
+    conv_igemm_dma_kernel<WM, WN, TM, TN><<<grid, 256, 0, current_stream()>>>(a);
     KERNEL_CHECK();
+}
+
+static void launch_dma(DmaArgs& a, int max_cols) {
+    switch (pick_dma_tile(a, max_cols)) {
+        case 0: launch_dma_cfg<2, 2, 2, 2>(a, max_cols); break;  // 128 x 128
+        case 1: launch_dma_cfg<1, 4, 2, 2>(a, max_cols); break;  //  64 x 256
+        case 2: launch_dma_cfg<2, 2, 2, 1>(a, max_cols); break;  // 128 x  64
+        case 3: launch_dma_cfg<1, 4, 2, 1>(a, max_cols); break;  //  64 x 128
+        default: launch_dma_cfg<2, 2, 1, 1>(a, max_cols); break; //  64 x  64
+    }
 }
 
 static void pack_weights(const float* w, float* at, const ConvShape& s, int mode, int M, int J, int Jpad, int Mpad,

@@ -237,6 +237,7 @@ void bcnn_end_net(bcnn_net **pnet) {
         bcnn_hip_free(hc->grad_arena_gpu);
         bcnn_hip_free(hc->sgd_chunks_gpu);
         free(hc->sgd_chunks_host);
+        free(hc->grad_fill_dead);
     }
     for (int i = 0; i < net->num_nodes; ++i) {
         bcnn_node *nd = &net->nodes[i];
@@ -312,6 +313,32 @@ static void build_arenas(bcnn_net *net) {
     }
 }
 
+/* The reference zero-fills every dst gradient before the node's forward (bcnn_net.c:361-375) because
+ * pooling / eltwise / fc / softmax backward accumulate. Backward visits a tensor's consumers in reverse
+ * node order, so the consumer with the LOWEST index writes the gradient last; when that consumer is a
+ * convolution its data-gradient pass overwrites every element (col2im zero-fills first, conv_layer.c:571)
+ * and whatever the fill and the earlier `+=` left there is never read. Such fills are skipped -- same
+ * values everywhere a reader can see, ~0.65 GB less memset traffic per ResNet-18 step. */
+static void mark_dead_grad_fills(bcnn_net *net) {
+    bcnn_hip_context *hc = hctx(net);
+    free(hc->grad_fill_dead);
+    hc->grad_fill_dead = (unsigned char *)calloc((size_t)net->num_tensors + 1, 1);
+    for (int t = 0; t < net->num_tensors; ++t) {
+        int first = -1;
+        for (int i = 0; i < net->num_nodes && first < 0; ++i)
+            for (int k = 0; k < net->nodes[i].num_src; ++k)
+                if (net->nodes[i].src[k] == t) { first = i; break; }
+        if (first < 0) continue;
+        const bcnn_node *nd = &net->nodes[first];
+        if (nd->type != BCNN_LAYER_CONV2D || nd->src[0] != t) continue;
+        const bcnn_conv_param *p = (const bcnn_conv_param *)nd->param;
+        const bcnn_tensor *x = &net->tensors[t], *y = &net->tensors[nd->dst[0]];
+        /* 1x1 kernels write dX through the raw [C/g][OH*OW] view: only complete when OH*OW == H*W */
+        if (p->size == 1 && y->h * y->w != x->h * x->w) continue;
+        hc->grad_fill_dead[t] = 1;
+    }
+}
+
 bcnn_status bcnn_compile_net(bcnn_net *net) {
     bcnn_hip_context *hc = hctx(net);
     /* (re)allocate the input tensor, as bcnn_init_workload does (reference bcnn_net.c:337-359) */
@@ -338,6 +365,7 @@ bcnn_status bcnn_compile_net(bcnn_net *net) {
         build_arenas(net);
         hc->compiled = 1;
     }
+    mark_dead_grad_fills(net);
     bcnn_hip_sync();
     return BCNN_SUCCESS;
 }
@@ -358,6 +386,8 @@ void bcnn_forward(bcnn_net *net) {
              * pooling / eltwise / fc / softmax backward ACCUMULATE into it */
             for (int d = 0; d < node->num_dst; ++d) {
                 bcnn_tensor *t = &net->tensors[node->dst[d]];
+                const bcnn_hip_context *hc = hctx(net);
+                if (hc->grad_fill_dead && hc->grad_fill_dead[node->dst[d]]) continue;
                 if (t->grad_data_gpu) bcnn_hip_fill_f32(t->grad_data_gpu, (size_t)bcnn_tensor_size(t), 0.0f);
             }
         }

@@ -122,6 +122,8 @@ typedef struct bcnn_hip_context {
     int compiled;
     /* update loop folded into one launch: table of (buffer, gradient, count, rule) chunks, built by the
      * first bcnn_update from what the nodes' update() workers ask for */
+    /* per tensor: 1 = the zero-fill of its gradient before forward is dead (see mark_dead_grad_fills) */
+    unsigned char *grad_fill_dead;
     struct bcnn_hip_sgd_chunk *sgd_chunks_host;
     void *sgd_chunks_gpu;
     int num_sgd_chunks, cap_sgd_chunks;
