@@ -40,9 +40,11 @@ struct DwDmaArgs {
 constexpr int DWQ = 32;    // q per K-tile
 constexpr int DWPAIR = 66; // floats per LDS row pair (2 x 32 + 2 pad)
 
-template <int WTM, int WTN>
-__global__ __launch_bounds__(256) void conv_dw_dma_kernel(const DwDmaArgs a) {
-    constexpr int BM = 64 * WTM, BN = 64 * WTN;
+template <int WM, int WN, int WTM, int WTN>
+__global__ __launch_bounds__(64 * WM * WN) void conv_dw_dma_kernel(const DwDmaArgs a) {
+    constexpr int NW = WM * WN;  // waves per workgroup, arranged WM x WN, each owning WTM x WTN accumulators
+    constexpr int BM = 32 * WM * WTM, BN = 32 * WN * WTN;
+    static_assert((BM / 2) % NW == 0 && (BN / 2) % NW == 0, "row pairs must split evenly over the waves");
     constexpr int APAIRS = BM / 2, BPAIRS = BN / 2;
     constexpr int BUF = (APAIRS + BPAIRS) * DWPAIR;  // floats per stage buffer
     __shared__ float lds[2 * BUF];
@@ -50,7 +52,7 @@ __global__ __launch_bounds__(256) void conv_dw_dma_kernel(const DwDmaArgs a) {
     const ConvShape& s = a.s;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wid >> 1, wn = wid & 1;
+    const int wm = wid / WN, wn = wid % WN;
     const int l31 = lane & 31, lhi = lane >> 5;
     const int g = blockIdx.y;
     // taps vary fastest so the workgroups that re-read the same dY / x range run together (L2 reuse)
@@ -99,20 +101,20 @@ __global__ __launch_bounds__(256) void conv_dw_dma_kernel(const DwDmaArgs a) {
     const unsigned lds0 = lds_offset(&lds[0]);
     const unsigned a_row0 = (unsigned)(g * s.Mg), b_grp = (unsigned)(g * s.Cg) * (unsigned)s.HW;
 
-    // wave `wid` stages APAIRS/4 + BPAIRS/4 row pairs; rows past the end are fetched from row 0 (finite
+    // wave `wid` stages APAIRS/NW + BPAIRS/NW row pairs; rows past the end are fetched from row 0 (finite
     // values that only reach accumulator rows / columns which are never published)
     auto stage = [&](int buf) {
         const unsigned base = lds0 + (unsigned)(buf * BUF * 4);
 #pragma unroll
-        for (int i = 0; i < APAIRS / 4; ++i) {
-            const int p = wid * (APAIRS / 4) + i;
+        for (int i = 0; i < APAIRS / NW; ++i) {
+            const int p = wid * (APAIRS / NW) + i;
             const int f = f0 + 2 * p;
             const unsigned soff = (a_row0 + (unsigned)(f < s.Mg ? f : 0)) * (unsigned)s.OHOW * 4u;
             dma_row(rs_a, base + (unsigned)(p * DWPAIR * 4), va, soff);
         }
 #pragma unroll
-        for (int i = 0; i < BPAIRS / 4; ++i) {
-            const int p = wid * (BPAIRS / 4) + i;
+        for (int i = 0; i < BPAIRS / NW; ++i) {
+            const int p = wid * (BPAIRS / NW) + i;
             const int c = c0 + 2 * p;
             const unsigned soff = (b_grp + (unsigned)(c < s.Cg ? c : 0) * (unsigned)a.b_row_stride) * 4u;
             dma_row(rs_b, base + (unsigned)((APAIRS + p) * DWPAIR * 4), vb, soff);
@@ -220,9 +222,21 @@ __global__ __launch_bounds__(256) void conv_dw_dma_finalize_kernel(const float* 
 }
 
 // ---- host side ------------------------------------------------------------------------------------------
+struct DwTile { int bm, bn, threads; };
+constexpr int kNumDwTiles = 6;
+static const DwTile kDwTiles[kNumDwTiles] = {
+    {64, 64, 256},    // 0: 2x2 waves of 32x32
+    {128, 64, 256},   // 1: 2x2 waves of 64x32
+    {128, 64, 512},   // 2: 4x2 waves of 32x32
+    {128, 128, 256},  // 3: 2x2 waves of 64x64
+    {128, 128, 1024}, // 4: 4x4 waves of 32x32
+    {64, 128, 512},   // 5: 2x4 waves of 32x32
+};
+
 struct DwDmaPlan {
     bool ok;
-    int WTM, WTN, mtiles, ntiles, qsplits, q_per_split, Mpad, Npad, kk2;
+    int cfg;  // index into kDwTiles
+    int mtiles, ntiles, qsplits, q_per_split, Mpad, Npad, kk2;
     size_t partial_floats;
 };
 
@@ -235,13 +249,12 @@ static DwDmaPlan plan_dw_dma(const ConvShape& s) {
     if (s.OHOW < DWQ || s.total_q < 4 * DWQ) return p;
     if ((size_t)s.N * s.C * s.HW * 4 >= 0x7ffffff0ull || (size_t)s.N * s.F * s.OHOW * 4 >= 0x7ffffff0ull) return p;
     p.kk2 = s.pointwise ? 1 : s.ksz * s.ksz;
-    p.WTM = s.Mg > 64 ? 2 : 1;  // measured on the ResNet shapes: 128 x 64 tiles with ~8 workgroups per CU win
-    p.WTN = 1;                  // (more resident waves beat the larger tile's DMA / fragment reuse)
-    static const char* forced = getenv("BCNN_HIP_DW_TILE");  // experiments: "11", "12", "21", "22"
-    if (forced && forced[0] && forced[1]) { p.WTM = forced[0] == '2' ? 2 : 1; p.WTN = forced[1] == '2' ? 2 : 1; }
+    p.cfg = s.Mg > 64 ? 1 : 0;
+    static const char* forced = getenv("BCNN_HIP_DW_TILE");  // experiments: index into kDwTiles
+    if (forced && forced[0] >= '0' && forced[0] < '0' + kNumDwTiles) p.cfg = forced[0] - '0';
     static const char* wantenv = getenv("BCNN_HIP_DW_WANT");
     const int want_per_cu = wantenv ? atoi(wantenv) : 8;
-    const int BM = 64 * p.WTM, BN = 64 * p.WTN;
+    const int BM = kDwTiles[p.cfg].bm, BN = kDwTiles[p.cfg].bn;
     p.mtiles = ceil_div(s.Mg, BM); p.ntiles = ceil_div(s.Cg, BN);
     p.Mpad = p.mtiles * BM; p.Npad = p.ntiles * BN;
     const long long tiles = (long long)p.mtiles * p.ntiles * p.kk2 * s.groups;
@@ -281,10 +294,15 @@ bool conv_backward_weights_dma(const float* x, const float* dy, float* dw, const
     a.ow_magic = magic_of_u(s.OW);
     a.b_row_stride = s.pointwise ? s.OHOW : s.HW;
     dim3 grid((unsigned)(p.mtiles * p.ntiles * p.kk2 * p.qsplits), (unsigned)s.groups);
-    if (p.WTM == 1 && p.WTN == 1) conv_dw_dma_kernel<1, 1><<<grid, 256, 0, current_stream()>>>(a);
-    else if (p.WTM == 1 && p.WTN == 2) conv_dw_dma_kernel<1, 2><<<grid, 256, 0, current_stream()>>>(a);
-    else if (p.WTM == 2 && p.WTN == 1) conv_dw_dma_kernel<2, 1><<<grid, 256, 0, current_stream()>>>(a);
-    else conv_dw_dma_kernel<2, 2><<<grid, 256, 0, current_stream()>>>(a);
+    const unsigned threads = (unsigned)kDwTiles[p.cfg].threads;
+    switch (p.cfg) {
+        case 0: conv_dw_dma_kernel<2, 2, 1, 1><<<grid, threads, 0, current_stream()>>>(a); break;
+        case 1: conv_dw_dma_kernel<2, 2, 2, 1><<<grid, threads, 0, current_stream()>>>(a); break;
+        case 2: conv_dw_dma_kernel<4, 2, 1, 1><<<grid, threads, 0, current_stream()>>>(a); break;
+        case 3: conv_dw_dma_kernel<2, 2, 2, 2><<<grid, threads, 0, current_stream()>>>(a); break;
+        case 4: conv_dw_dma_kernel<4, 4, 1, 1><<<grid, threads, 0, current_stream()>>>(a); break;
+        default: conv_dw_dma_kernel<2, 4, 1, 1><<<grid, threads, 0, current_stream()>>>(a); break;
+    }
     KERNEL_CHECK();
     const size_t total = (size_t)s.groups * s.Mg * s.Cg * p.kk2;
     conv_dw_dma_finalize_kernel<<<(unsigned)((total + 63) / 64), 256, 0, current_stream()>>>(
