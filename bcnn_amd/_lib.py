@@ -57,7 +57,7 @@ SIGNATURES = {
     "bcnn_hip_batchnorm_backward": (None, [vp, vp, vp, i] + [vp] * 9 + [i, i, i]),
     "bcnn_hip_conv_workspace_size": (sz, [i] * 9),
     "bcnn_hip_conv_forward": (None, [vp, vp, vp, vp] + [i] * 10 + [vp, i, vp, vp, vp, vp, vp, vp, vp, i]),
-    "bcnn_hip_conv_backward": (None, [vp] * 7 + [i] * 10 + [vp, vp, i] + [vp] * 8 + [vp, sz]),
+    "bcnn_hip_conv_backward": (None, [vp] * 8 + [i] * 10 + [vp, vp, i] + [vp] * 8 + [vp, sz]),
     "bcnn_hip_maxpool_forward": (None, [vp, vp, vp] + [i] * 8),
     "bcnn_hip_maxpool_backward": (None, [vp, vp, vp] + [i] * 8),
     "bcnn_hip_avgpool_forward": (None, [vp, vp, i, i, i, i]),

@@ -8,6 +8,7 @@
 // with the activation fused); backward = 1 pass of reads (sums) + 1 read/write pass (apply). The
 // reference CPU path makes ~10 forward sweeps (two copies, x_norm, scale and bias passes).
 #include "chan_reduce.h"
+#include "conv_common.h"
 
 namespace bcnn_hip {
 
@@ -42,6 +43,40 @@ __global__ void bn_stats_finalize_kernel(const float* __restrict__ partials, int
     saved_mean[c] = mean;
     saved_var[c] = var;
     run_mean[c] = __fadd_rn(__fmul_rn(mean, 0.1f), __fmul_rn(run_mean[c], 0.9f));        // scal 0.9, axpy 0.1
+    run_var[c] = __fadd_rn(__fmul_rn(var, 0.1f), __fmul_rn(run_var[c], 0.9f));
+}
+
+// Same result for MANY partials per channel (the convolution epilogue emits one per column tile, up to a
+// few thousand): one workgroup per channel, threads stride over the partials in double, fixed-shape
+// butterfly + a fixed-order cross-wave step.
+__global__ __launch_bounds__(256) void bn_stats_finalize_wide_kernel(const float* __restrict__ partials, int C, int splits,
+                                                                    int M, float* __restrict__ saved_mean,
+                                                                    float* __restrict__ saved_var,
+                                                                    float* __restrict__ run_mean,
+                                                                    float* __restrict__ run_var) {
+    __shared__ double red[4][2];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int c = blockIdx.x;
+    const float2* p = reinterpret_cast<const float2*>(partials) + (long long)c * splits;
+    double s = 0.0, ss = 0.0;
+    for (int i = threadIdx.x; i < splits; i += 256) {
+        const float2 v = p[i];
+        s += (double)v.x;
+        ss += (double)v.y;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
+    if (lane == 0) { red[wid][0] = s; red[wid][1] = ss; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    s = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+    ss = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+    const float inv = 1.0f / (float)M;
+    const float mean = __fmul_rn((float)s, inv);
+    const float var = __fsub_rn(__fmul_rn((float)ss, inv), __fmul_rn(mean, mean));
+    saved_mean[c] = mean;
+    saved_var[c] = var;
+    run_mean[c] = __fadd_rn(__fmul_rn(mean, 0.1f), __fmul_rn(run_mean[c], 0.9f));
     run_var[c] = __fadd_rn(__fmul_rn(var, 0.1f), __fmul_rn(run_var[c], 0.9f));
 }
 
@@ -111,22 +146,40 @@ struct BnApplyBody {
 // g' = dy * act'(y) (optional fused activation backward);  S1 = sum g',  S2 = sum g' * (x - mean)
 struct BwdSumsF {
     const float* dy;
-    const float* y;   // post-activation output, used only when act != NONE
+    const float* y;   // post-activation output, used only when act != NONE and fwd_bias == NULL
     const float* x;   // pre-normalisation input (workspace)
     const float* mean;
+    // when fwd_bias != NULL the forward output is RECOMPUTED from x (same operations, same rounding as the
+    // forward apply => bit-identical y) instead of being read: one full-tensor read less per pass
+    const float* fwd_bias;
+    const float* var;
+    const float* scale;
     int act, C, HW;
+    __device__ float fwd_y(float xv, int c) const {
+        float dummy;
+        return bn_one(xv, mean[c], sqrtf(var[c] + 0.000001f), scale[c], fwd_bias[c], 0, act, &dummy);
+    }
     __device__ void operator()(long long off, int c, float (&acc)[2]) const {
         float g = dy[off];
-        if (act != BCNN_HIP_ACT_NONE) g *= act_bwd_cheap(y[off], act, 0.f);
+        const float xv = x[off];
+        if (act != BCNN_HIP_ACT_NONE) g *= act_bwd_cheap(fwd_bias ? fwd_y(xv, c) : y[off], act, 0.f);
         acc[0] += g;
-        acc[1] += g * (x[off] - mean[c]);
+        acc[1] += g * (xv - mean[c]);
     }
     __device__ void vec4(long long off, int c, float (&acc)[2]) const {
         const float m = mean[c];
         float4 g = *reinterpret_cast<const float4*>(dy + off);
         const float4 xv = *reinterpret_cast<const float4*>(x + off);
         if (act != BCNN_HIP_ACT_NONE) {
-            const float4 yv = *reinterpret_cast<const float4*>(y + off);
+            float4 yv;
+            if (fwd_bias) {
+                float dummy;
+                const float rs = sqrtf(var[c] + 0.000001f), sc = scale[c], b = fwd_bias[c];
+                yv.x = bn_one(xv.x, m, rs, sc, b, 0, act, &dummy); yv.y = bn_one(xv.y, m, rs, sc, b, 0, act, &dummy);
+                yv.z = bn_one(xv.z, m, rs, sc, b, 0, act, &dummy); yv.w = bn_one(xv.w, m, rs, sc, b, 0, act, &dummy);
+            } else {
+                yv = *reinterpret_cast<const float4*>(y + off);
+            }
             g.x *= act_bwd_cheap(yv.x, act, 0.f); g.y *= act_bwd_cheap(yv.y, act, 0.f);
             g.z *= act_bwd_cheap(yv.z, act, 0.f); g.w *= act_bwd_cheap(yv.w, act, 0.f);
         }
@@ -169,6 +222,7 @@ struct BnBwdApplyArgs {
     const float* scale;
     const float* dmean;
     const float* dvar;
+    const float* fwd_bias;  // != NULL: recompute the forward output from x instead of reading y
     int C, HW, act, M;
     long long total;
 };
@@ -189,14 +243,20 @@ struct BnBwdApplyBody {
     bool al;
     __device__ void operator()(unsigned off, int c, int cnt) const {
         const float fM = (float)a.M;
-        const bool use_y = a.act != BCNN_HIP_ACT_NONE;
+        const bool use_act = a.act != BCNN_HIP_ACT_NONE, use_y = use_act && a.fwd_bias == nullptr;
         const float mean = a.mean[c], rs = sqrtf(a.var[c] + 0.00001f), sc = a.scale[c];
+        const float rs_fwd = sqrtf(a.var[c] + 0.000001f), fb = a.fwd_bias ? a.fwd_bias[c] : 0.f;
+        float dummy;
         const float dmm = __fdiv_rn(a.dmean[c], fM), dv = a.dvar[c];
         if (cnt == 4 && al && (off & 3u) == 0) {
             const float4 g = *reinterpret_cast<const float4*>(a.dy + off);
             const float4 xv = *reinterpret_cast<const float4*>(a.x + off);
             float4 yv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (use_y) yv = *reinterpret_cast<const float4*>(a.y + off);
+            else if (use_act) {
+                yv.x = bn_one(xv.x, mean, rs_fwd, sc, fb, 0, a.act, &dummy); yv.y = bn_one(xv.y, mean, rs_fwd, sc, fb, 0, a.act, &dummy);
+                yv.z = bn_one(xv.z, mean, rs_fwd, sc, fb, 0, a.act, &dummy); yv.w = bn_one(xv.w, mean, rs_fwd, sc, fb, 0, a.act, &dummy);
+            }
             float4 o;
             o.x = bn_bwd_one(g.x, yv.x, xv.x, mean, rs, sc, dmm, dv, fM, a.act);
             o.y = bn_bwd_one(g.y, yv.y, xv.y, mean, rs, sc, dmm, dv, fM, a.act);
@@ -206,8 +266,9 @@ struct BnBwdApplyBody {
             if (a.dx) *reinterpret_cast<float4*>(a.dx + off) = o;
         } else {
             for (int k = 0; k < cnt; ++k) {
-                const float o = bn_bwd_one(a.dy[off + k], use_y ? a.y[off + k] : 0.f, a.x[off + k], mean, rs,
-                                           sc, dmm, dv, fM, a.act);
+                const float xk = a.x[off + k];
+                const float yk = use_y ? a.y[off + k] : (use_act ? bn_one(xk, mean, rs_fwd, sc, fb, 0, a.act, &dummy) : 0.f);
+                const float o = bn_bwd_one(a.dy[off + k], yk, xk, mean, rs, sc, dmm, dv, fM, a.act);
                 a.dy[off + k] = o;
                 if (a.dx) a.dx[off + k] = o;
             }
@@ -215,19 +276,16 @@ struct BnBwdApplyBody {
     }
 };
 
-}  // namespace bcnn_hip
 
-using namespace bcnn_hip;
-
-extern "C" {
-
-void bcnn_hip_batchnorm_forward(const float* x, float* y, float* run_mean, float* run_var,
-                                const float* scales, const float* bias, float* saved_mean,
-                                float* saved_var, float* x_norm, float* workspace, int n, int c, int hw,
-                                int mode, int act) {
+// pre: statistics partials already produced by the convolution epilogue (pre->splits > 0), else NULL
+void batchnorm_forward_impl(const float* x, float* y, float* run_mean, float* run_var, const float* scales,
+                            const float* bias, float* saved_mean, float* saved_var, float* x_norm, float* workspace,
+                            int n, int c, int hw, int mode, int act, const ConvStats* pre) {
     const long long M = (long long)n * hw, total = M * c;
     if (!total) return;
-    KTimer kt(K_BN_FWD, 0.0, 4.0 * 3.0 * (double)total);  // read x twice (statistics, apply) + write y
+    const bool have_pre = pre && pre->splits > 0 && mode == BCNN_HIP_MODE_TRAIN;
+    // read x twice (statistics, apply) + write y; one read less with fused statistics
+    KTimer kt(K_BN_FWD, 0.0, 4.0 * (have_pre ? 2.0 : 3.0) * (double)total);
     const int want_act = act;
     if (!act_is_cheap(act)) act = BCNN_HIP_ACT_NONE;  // tanh/softplus/logistic: separate pass below
     BnApplyArgs a;
@@ -237,7 +295,12 @@ void bcnn_hip_batchnorm_forward(const float* x, float* y, float* run_mean, float
     a.mean = run_mean; a.var = run_var;
     if (mode == BCNN_HIP_MODE_PREDICT) a.ws = nullptr;  // the reference keeps no copy in PREDICT mode
     if (mode == BCNN_HIP_MODE_VALID) a.xn = nullptr;    // x_norm is only written in TRAIN mode (:230)
-    if (mode == BCNN_HIP_MODE_TRAIN) {
+    if (have_pre) {
+        bn_stats_finalize_wide_kernel<<<c, 256, 0, current_stream()>>>(
+            pre->partials, c, pre->splits, (int)M, saved_mean, saved_var, run_mean, run_var);
+        KERNEL_CHECK();
+        a.mean = saved_mean; a.var = saved_var;
+    } else if (mode == BCNN_HIP_MODE_TRAIN) {
         const int splits = chan_splits(c, M);
         float* part = reduce_scratch((size_t)c * splits * 2);
         launch_chan_reduce<2>(StatsF{x}, c, hw, M, splits, part);
@@ -251,14 +314,33 @@ void bcnn_hip_batchnorm_forward(const float* x, float* y, float* run_mean, float
     if (want_act != act) bcnn_hip_activation_forward(y, (size_t)total, want_act, nullptr, hw, c);
 }
 
-void bcnn_hip_batchnorm_backward(float* dy, float* dx, const float* y, int act, const float* scales,
-                                 float* dscales, float* dbias, const float* saved_mean,
-                                 const float* saved_var, float* dmean, float* dvar, const float* x_norm,
-                                 const float* workspace, int n, int c, int hw) {
-    (void)x_norm;  // recomputed from workspace/mean/var: saves a full-tensor read (and its write in forward)
+}  // namespace bcnn_hip
+
+using namespace bcnn_hip;
+
+extern "C" {
+
+void bcnn_hip_batchnorm_forward(const float* x, float* y, float* run_mean, float* run_var,
+                                const float* scales, const float* bias, float* saved_mean,
+                                float* saved_var, float* x_norm, float* workspace, int n, int c, int hw,
+                                int mode, int act) {
+    batchnorm_forward_impl(x, y, run_mean, run_var, scales, bias, saved_mean, saved_var, x_norm, workspace, n, c, hw,
+                           mode, act, nullptr);
+}
+
+}  // extern "C"
+
+namespace bcnn_hip {
+// fwd_bias (optional): the bias the forward pass added; with it the forward output is recomputed from the
+// workspace copy of the input instead of read from y (fused activation backward only).
+void batchnorm_backward_impl(float* dy, float* dx, const float* y, int act, const float* scales, float* dscales,
+                             float* dbias, const float* saved_mean, const float* saved_var, float* dmean,
+                             float* dvar, const float* workspace, int n, int c, int hw, const float* fwd_bias) {
     const long long M = (long long)n * hw, total = M * c;
     if (!total) return;
-    KTimer kt(K_BN_BWD, 0.0, 4.0 * 6.0 * (double)total);  // 2 passes x (dy, x[, y]) + write dy
+    if (act == BCNN_HIP_ACT_NONE || !act_bwd_is_cheap(act)) fwd_bias = nullptr;
+    // 2 passes over (dy, x[, y]) + write dy
+    KTimer kt(K_BN_BWD, 0.0, 4.0 * ((act != BCNN_HIP_ACT_NONE && !fwd_bias) ? 7.0 : 5.0) * (double)total);
     if (!act_bwd_is_cheap(act)) {  // softplus: its derivative needs exp() -> separate in-place pass first
         bcnn_hip_activation_backward(y, dy, (size_t)total, act, nullptr, nullptr, hw, c);
         act = BCNN_HIP_ACT_NONE;
@@ -267,6 +349,7 @@ void bcnn_hip_batchnorm_backward(float* dy, float* dx, const float* y, int act, 
     float* part = reduce_scratch((size_t)c * splits * 2);
     BwdSumsF f;
     f.dy = dy; f.y = y; f.x = workspace; f.mean = saved_mean; f.act = act; f.C = c; f.HW = hw;
+    f.fwd_bias = fwd_bias; f.var = saved_var; f.scale = scales;
     launch_chan_reduce<2>(f, c, hw, M, splits, part);
     bn_bwd_finalize_kernel<<<ceil_div(c, 256), 256, 0, current_stream()>>>(part, c, splits, scales, saved_var,
                                                                           dbias, dscales, dmean, dvar);
@@ -274,9 +357,21 @@ void bcnn_hip_batchnorm_backward(float* dy, float* dx, const float* y, int act, 
     BnBwdApplyArgs a;
     a.dy = dy; a.dx = (dx && dx != dy) ? dx : nullptr; a.y = y; a.x = workspace;
     a.mean = saved_mean; a.var = saved_var; a.scale = scales; a.dmean = dmean; a.dvar = dvar;
-    a.C = c; a.HW = hw; a.act = act; a.M = (int)M; a.total = total;
+    a.C = c; a.HW = hw; a.act = act; a.M = (int)M; a.total = total; a.fwd_bias = fwd_bias;
     auto al16 = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     launch_chan_map(BnBwdApplyBody{a, al16(dy) && al16(a.dx) && al16(workspace) && al16(y)}, n, c, hw);
+}
+}  // namespace bcnn_hip
+
+extern "C" {
+
+void bcnn_hip_batchnorm_backward(float* dy, float* dx, const float* y, int act, const float* scales,
+                                 float* dscales, float* dbias, const float* saved_mean,
+                                 const float* saved_var, float* dmean, float* dvar, const float* x_norm,
+                                 const float* workspace, int n, int c, int hw) {
+    (void)x_norm;  // recomputed from workspace/mean/var: saves a full-tensor read (and its write in forward)
+    batchnorm_backward_impl(dy, dx, y, act, scales, dscales, dbias, saved_mean, saved_var, dmean, dvar, workspace, n,
+                            c, hw, nullptr);
 }
 
 }  // extern "C"

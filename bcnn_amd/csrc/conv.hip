@@ -5,7 +5,14 @@
 
 namespace bcnn_hip {
 void conv_forward_dispatch(const float* x, const float* w, const float* bias, const float* slopes, float* y,
-                           const ConvShape& s, int act, int raw);
+                           const ConvShape& s, int act, int raw, ConvStats* stats);
+void batchnorm_forward_impl(const float* x, float* y, float* run_mean, float* run_var, const float* scales,
+                            const float* bias, float* saved_mean, float* saved_var, float* x_norm, float* workspace,
+                            int n, int c, int hw, int mode, int act, const ConvStats* pre);  // batchnorm.hip
+void batchnorm_backward_impl(float* dy, float* dx, const float* y, int act, const float* scales, float* dscales,
+                             float* dbias, const float* saved_mean, const float* saved_var, float* dmean,
+                             float* dvar, const float* workspace, int n, int c, int hw, const float* fwd_bias);
+float* reduce_scratch(size_t floats);                                                        // blas1.hip
 size_t conv_dw_workspace_floats(const ConvShape& s);
 bool conv_backward_weights(const float* x, const float* dy, float* dw, float* dbias, const ConvShape& s,
                            float* workspace, size_t workspace_floats, bool want_bias);
@@ -30,9 +37,10 @@ static bool conv_backward_weights_dma_timed(const float* x, const float* dy, flo
 }
 
 static void conv_fwd_any(const float* x, const float* w, const float* bias, const float* slopes, float* y,
-                         const ConvShape& s, int act, int raw) {
+                         const ConvShape& s, int act, int raw, ConvStats* stats = nullptr) {
+    if (stats) stats->splits = 0;
     if (!conv_forward_direct(x, w, bias, slopes, y, s, act, raw))
-        conv_forward_dispatch(x, w, bias, slopes, y, s, act, raw);
+        conv_forward_dispatch(x, w, bias, slopes, y, s, act, raw, stats);
 }
 }  // namespace bcnn_hip
 
@@ -65,16 +73,25 @@ void bcnn_hip_conv_forward(const float* x, const float* w, const float* bias, fl
     }
     // conv -> (pre-normalisation values, kept for backward) -> statistics -> normalise+scale+bias+act
     float* raw = (bn_workspace && mode != BCNN_HIP_MODE_PREDICT) ? bn_workspace : y;
-    conv_fwd_any(x, w, nullptr, nullptr, raw, s, BCNN_HIP_ACT_NONE, /*raw=*/1);
+    // TRAIN: the convolution epilogue also emits the per-channel sum / sum of squares of what it stores
+    ConvStats st;
+    st.partials = nullptr; st.splits = 0;
+    static const int fuse_stats = getenv("BCNN_HIP_NO_FUSED_STATS") ? 0 : 1;  // A/B switch for profiling
+    if (fuse_stats && mode == BCNN_HIP_MODE_TRAIN && s.total_q < 0x7fffffffLL)
+        st.partials = reduce_scratch((size_t)f * (size_t)ceil_div(s.total_q, 64) * 2);
+    conv_fwd_any(x, w, nullptr, nullptr, raw, s, BCNN_HIP_ACT_NONE, /*raw=*/1, st.partials ? &st : nullptr);
     const int fused_act = (act == BCNN_HIP_ACT_PRELU) ? BCNN_HIP_ACT_NONE : act;
-    bcnn_hip_batchnorm_forward(raw, y, run_mean, run_var, scales, bias, saved_mean, saved_var, x_norm, raw, n, f,
-                               s.OHOW, mode, fused_act);
+    // x_norm is not materialised on this path: the backward pass recomputes it from the raw convolution
+    // output kept in bn_workspace (a full-tensor write and read less per layer and step).
+    (void)x_norm;
+    batchnorm_forward_impl(raw, y, run_mean, run_var, scales, bias, saved_mean, saved_var, nullptr, raw, n, f, s.OHOW,
+                           mode, fused_act, &st);
     if (act == BCNN_HIP_ACT_PRELU)
         bcnn_hip_activation_forward(y, (size_t)n * f * s.OHOW, act, slopes, s.OHOW, f);
 }
 
-void bcnn_hip_conv_backward(const float* x, const float* w, const float* y, float* dy, float* dx, float* dw,
-                            float* dbias, int n, int c, int h, int wd, int f, int k, int stride, int pad,
+void bcnn_hip_conv_backward(const float* x, const float* w, const float* bias, const float* y, float* dy, float* dx,
+                            float* dw, float* dbias, int n, int c, int h, int wd, int f, int k, int stride, int pad,
                             int groups, int act, const float* slopes, float* dslopes, int batch_norm,
                             const float* scales, float* dscales, const float* saved_mean,
                             const float* saved_var, float* dmean, float* dvar, const float* x_norm,
@@ -87,8 +104,10 @@ void bcnn_hip_conv_backward(const float* x, const float* w, const float* y, floa
             bcnn_hip_activation_backward(y, dy, ysize, act, slopes, dslopes, s.OHOW, f);
             fused_act = BCNN_HIP_ACT_NONE;
         }
-        bcnn_hip_batchnorm_backward(dy, nullptr, y, fused_act, scales, dscales, dbias, saved_mean, saved_var,
-                                    dmean, dvar, x_norm, bn_workspace, n, f, s.OHOW);
+        // `bias` lets the batch-norm backward recompute the forward output from bn_workspace (no read of y)
+        (void)x_norm;
+        batchnorm_backward_impl(dy, nullptr, y, fused_act, scales, dscales, dbias, saved_mean, saved_var, dmean, dvar,
+                                bn_workspace, n, f, s.OHOW, bias);
     } else {
         bcnn_hip_activation_backward(y, dy, ysize, act, slopes, dslopes, s.OHOW, f);
     }

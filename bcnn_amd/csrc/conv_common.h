@@ -28,6 +28,13 @@ inline ConvShape make_conv_shape(int n, int c, int h, int w, int f, int k, int s
     return s;
 }
 
+// Batch-norm statistics produced by a convolution kernel's epilogue (conv_igemm_dma.hip):
+// partials[(channel * splits + i) * 2 + {sum, sum of squares}], the layout bn_stats_finalize consumes.
+struct ConvStats {
+    float* partials;
+    int splits;
+};
+
 #ifdef __HIPCC__
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

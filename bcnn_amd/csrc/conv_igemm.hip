@@ -311,7 +311,7 @@ static void dispatch_igemm(IgemmArgs& a, long long max_cols) {
 }
 
 bool conv_forward_dma(const float* x, const float* w, const float* bias, const float* slopes, float* y,
-                      const ConvShape& s, int act, int raw);                          // conv_igemm_dma.hip
+                      const ConvShape& s, int act, int raw, ConvStats* stats);        // conv_igemm_dma.hip
 bool conv_backward_data_dma(const float* w, const float* dy, float* dx, const ConvShape& s);
 
 static bool dma_enabled() {
@@ -321,7 +321,8 @@ static bool dma_enabled() {
 
 // raw = 1: write the bare convolution (no bias, no activation) -- used by the fused-BN path.
 void conv_forward_dispatch(const float* x, const float* w, const float* bias, const float* slopes, float* y,
-                           const ConvShape& s, int act, int raw) {
+                           const ConvShape& s, int act, int raw, ConvStats* stats) {
+    if (stats) stats->splits = 0;
     if (s.total_q == 0 || s.Mg == 0) return;
     if (s.ksz > 7 && !s.pointwise) {
         fprintf(stderr, "[bcnn_hip] conv forward: kernel size %d > 7 is not supported\n", s.ksz);
@@ -329,7 +330,7 @@ void conv_forward_dispatch(const float* x, const float* w, const float* bias, co
     }
     KTimer kt(K_CONV_FWD, 2.0 * (double)s.total_q * s.Mg * s.K * s.groups,
               4.0 * ((double)s.N * s.C * s.HW + (double)s.F * s.K + (double)s.N * s.F * s.OHOW));
-    if (dma_enabled() && conv_forward_dma(x, w, bias, slopes, y, s, act, raw)) return;
+    if (dma_enabled() && conv_forward_dma(x, w, bias, slopes, y, s, act, raw, stats)) return;
     IgemmArgs a;
     a.a_base = w; a.b_base = x; a.out = y; a.bias = bias; a.slopes = slopes; a.s = s;
     a.mode = 0;

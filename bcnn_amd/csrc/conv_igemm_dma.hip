@@ -47,6 +47,10 @@ struct DmaArgs {
     int b_major_stride;    // elements between consecutive j in the gathered tensor
     int mtiles;
     int nclass;
+    // forward only, optional: per-channel partial sums of the stored values for the batch-norm statistics,
+    // stats[((g*Mg + m) * stats_splits + column tile) * 2 + {0: sum, 1: sum of squares}]
+    float* stats;
+    int stats_splits;
     DmaClass cls[kDmaMaxClasses];
 };
 
@@ -59,8 +63,13 @@ __global__ __launch_bounds__(256, ABL_LB) void conv_igemm_dma_kernel(const DmaAr
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int AH = BM / 64, BH = BN / 64;
     static_assert(WM * WN == 4, "4 waves");
-    __shared__ float As[2][BK][BM];
-    __shared__ float Bs[2][BK][BN];
+    // one block of LDS: As[2][BK][BM] | Bs[2][BK][BN]; after the K loop the same bytes hold one 32x32
+    // transposition pad per wave for the fused statistics
+    constexpr int SMEM = 2 * BK * (BM + BN);
+    static_assert(SMEM >= 4 * 1024, "statistics pads");
+    __shared__ float smem[SMEM];
+    float (*As)[BK][BM] = reinterpret_cast<float (*)[BK][BM]>(smem);
+    float (*Bs)[BK][BN] = reinterpret_cast<float (*)[BK][BN]>(smem + 2 * BK * BM);
 
     const ConvShape& s = a.s;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -224,6 +233,54 @@ __global__ __launch_bounds__(256, ABL_LB) void conv_igemm_dma_kernel(const DmaAr
 #endif
     }
 
+    // ---- batch-norm statistics of this tile (fused: saves the separate read of the whole output) -----
+    // Columns past the end hold exact zeros (their B columns were zero-filled), so no masking is needed.
+    // Each wave transposes its 32x32 accumulator tile through a private XOR-swizzled LDS pad so that a lane
+    // owns half a ROW (16 values): ~50 VALU per tile instead of the ~600 a shuffle butterfly over the
+    // accumulator layout costs -- fp32 MFMAs and VALU share the SIMD, epilogue VALU is not free.
+    if (a.stats != nullptr) {
+        __shared__ float s_stat[BM][WN * TN][2];
+        float* pad = smem + wid * 1024;
+        const int prow = lane & 31, phalf = lane >> 5;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r];
+                __syncthreads();  // K-loop reads (first tile) / previous tile's pad reads are done
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = mfma_row(r, lane);
+                    pad[row * 32 + (l31 ^ row)] = v[r];
+                }
+                __syncthreads();
+                float sv = 0.f, sq = 0.f;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    const float t = pad[prow * 32 + ((phalf * 16 + c) ^ prow)];
+                    sv += t;
+                    sq += t * t;
+                }
+                sv += __shfl_xor(sv, 32);
+                sq += __shfl_xor(sq, 32);
+                if (phalf == 0) {
+                    const int row = (wm * TM + i) * 32 + prow;
+                    s_stat[row][wn * TN + j][0] = sv;
+                    s_stat[row][wn * TN + j][1] = sq;
+                }
+            }
+        __syncthreads();
+        if (tid < BM && m0 + tid < a.M) {
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < WN * TN; ++k) { s0 += s_stat[tid][k][0]; s1 += s_stat[tid][k][1]; }
+            float* dst = a.stats + ((size_t)(g * s.Mg + m0 + tid) * a.stats_splits + pt) * 2;
+            dst[0] = s0; dst[1] = s1;
+        }
+    }
+
     // ---- epilogue ------------------------------------------------------------------------------------
     const unsigned o_row_stride = fwd ? (unsigned)s.OHOW : (s.pointwise ? (unsigned)s.OHOW : (unsigned)s.HW);
 #pragma unroll
@@ -337,7 +394,8 @@ template <int WM, int WN, int TM, int TN>
 static void launch_dma_cfg(DmaArgs& a, int max_cols) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     a.mtiles = ceil_div(a.M, BM);
-    dim3 grid((unsigned)(a.mtiles * ceil_div(max_cols, BN)), (unsigned)a.s.groups, (unsigned)a.nclass);
+    a.stats_splits = ceil_div(max_cols, BN);
+    dim3 grid((unsigned)(a.mtiles * a.stats_splits), (unsigned)a.s.groups, (unsigned)a.nclass);
     conv_igemm_dma_kernel<WM, WN, TM, TN><<<grid, 256, 0, current_stream()>>>(a);
     KERNEL_CHECK();
 }
@@ -364,8 +422,11 @@ static void pack_weights(const float* w, float* at, const ConvShape& s, int mode
 }
 
 // Returns false when the shape is not covered (caller falls back to the register-staged kernel).
+// stats (optional, raw mode only): in  -> partials buffer with room for F * ceil(N*OH*OW / 64) * 2 floats
+//                                   out -> splits = number of column tiles written per channel (0: none)
 bool conv_forward_dma(const float* x, const float* w, const float* bias, const float* slopes, float* y,
-                      const ConvShape& s, int act, int raw) {
+                      const ConvShape& s, int act, int raw, ConvStats* stats) {
+    if (stats) stats->splits = 0;
     if (!dma_supported(s, s.Mg, s.Cg, (size_t)s.N * s.C * s.HW)) return false;
     const int kk2 = s.pointwise ? 1 : s.ksz * s.ksz;
     DmaArgs a;
@@ -384,7 +445,9 @@ bool conv_forward_dma(const float* x, const float* w, const float* bias, const f
     ci.nkx = s.pointwise ? 1 : s.ksz; ci.sgn = 1;
     for (int t = 0; t < kk2; ++t) tapoff[t] = (unsigned char)t;
     pack_weights(w, at, s, 0, a.M, a.J, a.Jpad, a.Mpad, kk2, tapoff);
+    a.stats = (stats && raw) ? stats->partials : nullptr;
     launch_dma(a, (int)s.total_q);
+    if (a.stats) stats->splits = a.stats_splits;
     return true;
 }
 
@@ -393,7 +456,7 @@ bool conv_backward_data_dma(const float* w, const float* dy, float* dx, const Co
     const int kk2 = s.pointwise ? 1 : s.ksz * s.ksz;
     DmaArgs a;
     a.b_base = dy; a.out = dx; a.bias = nullptr; a.slopes = nullptr; a.s = s;
-    a.mode = 1; a.act = BCNN_HIP_ACT_NONE; a.add_bias = 0;
+    a.mode = 1; a.act = BCNN_HIP_ACT_NONE; a.add_bias = 0; a.stats = nullptr; a.stats_splits = 0;
     a.M = s.Cg; a.J = s.Mg; a.Jpad = round_up(a.J, 16); a.Mpad = round_up(a.M, 128); a.kk2 = kk2;
     const size_t at_floats = (size_t)s.groups * kk2 * a.Jpad * a.Mpad;
     float* at = dma_scratch(at_floats);

@@ -158,7 +158,7 @@ void bcnn_forward_conv_layer(bcnn_net *net, bcnn_node *node) {
 void bcnn_backward_conv_layer(bcnn_net *net, bcnn_node *node) {
     bcnn_conv_param *p = (bcnn_conv_param *)node->param;
     conv_io io = conv_tensors(net, node);
-    bcnn_hip_conv_backward(io.x->data_gpu, io.w->data_gpu, io.y->data_gpu, io.y->grad_data_gpu,
+    bcnn_hip_conv_backward(io.x->data_gpu, io.w->data_gpu, io.b->data_gpu, io.y->data_gpu, io.y->grad_data_gpu,
                            io.x->grad_data_gpu /* NULL for the net input: no dX */, io.w->grad_data_gpu,
                            io.b->grad_data_gpu, io.x->n, io.x->c, io.x->h, io.x->w, p->num, p->size, p->stride,
                            p->pad, p->num_groups, (int)p->activation, io.slopes ? io.slopes->data_gpu : NULL,

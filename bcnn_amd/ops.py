@@ -48,13 +48,14 @@ def conv_forward(x, wt, bias, y, k, stride, pad, groups=1, act=0, slopes=None, b
 
 
 def conv_backward(x, wt, y, dy, dx, dw, dbias, k, stride, pad, groups, act, workspace, slopes=None,
-                  dslopes=None, bn=None):
-    """bcnn_backward_conv_layer (bcnn_conv_layer.c:487-587). dy is updated in place; dx may be None."""
+                  dslopes=None, bn=None, bias=None):
+    """bcnn_backward_conv_layer (bcnn_conv_layer.c:487-587). dy is updated in place; dx may be None.
+    bias (optional): the forward bias; lets the fused batch-norm backward recompute y instead of reading it."""
     n, c, h, w = x.shape
     f = wt.shape[0]
     L = _lib.load()
     b = bn or {}
-    L.bcnn_hip_conv_backward(_f32(x), _f32(wt), _f32(y), _f32(dy), _f32(dx), _f32(dw), _f32(dbias), n, c, h, w,
+    L.bcnn_hip_conv_backward(_f32(x), _f32(wt), _f32(bias), _f32(y), _f32(dy), _f32(dx), _f32(dw), _f32(dbias), n, c, h, w,
                              f, k, stride, pad, groups, act, _f32(slopes), _f32(dslopes), 1 if bn else 0,
                              _f32(b.get("scales")), _f32(b.get("dscales")), _f32(b.get("saved_mean")),
                              _f32(b.get("saved_var")), _f32(b.get("dmean")), _f32(b.get("dvar")),

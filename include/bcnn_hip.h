@@ -151,6 +151,11 @@ void bcnn_hip_batchnorm_backward(float *dy_d, float *dx_d, const float *y_d, int
  * workspace_d: scratch of at least bcnn_hip_conv_workspace_size(...) floats (split-K partials of dw;
  * the reference's per-net conv workspace, bcnn_net.c:337-352, plays the same role).
  * PReLU slopes: slopes_d (one per output channel), else NULL.
+ * backward bias_d: the bias the forward pass used (the reference worker has it as node->src[2]); may be
+ * NULL. With it the fused batch-norm backward recomputes the forward output from bn_workspace_d bit for
+ * bit instead of reading y_d (one full-tensor read less in each of its two passes).
+ * x_norm_d is accepted for signature parity with the reference layer and never touched: the normalised
+ * values are recomputed from bn_workspace_d, saved_mean_d and saved_var_d.
  * ------------------------------------------------------------------------------------------- */
 size_t bcnn_hip_conv_workspace_size(int n, int c, int h, int w, int f, int k, int stride, int pad,
                                     int groups);
@@ -161,8 +166,8 @@ void bcnn_hip_conv_forward(const float *x_d, const float *w_d, const float *bias
                            int batch_norm, float *run_mean_d, float *run_var_d, const float *scales_d,
                            float *saved_mean_d, float *saved_var_d, float *x_norm_d,
                            float *bn_workspace_d, int mode);
-void bcnn_hip_conv_backward(const float *x_d, const float *w_d, const float *y_d, float *dy_d,
-                            float *dx_d, float *dw_d, float *dbias_d, int n, int c, int h, int w, int f,
+void bcnn_hip_conv_backward(const float *x_d, const float *w_d, const float *bias_d, const float *y_d,
+                            float *dy_d, float *dx_d, float *dw_d, float *dbias_d, int n, int c, int h, int w, int f,
                             int k, int stride, int pad, int groups, int act, const float *slopes_d,
                             float *dslopes_d, int batch_norm, const float *scales_d, float *dscales_d,
                             const float *saved_mean_d, const float *saved_var_d, float *dmean_d,

@@ -45,7 +45,7 @@ def hip_conv(cs):
         if bn:
             b.update(dscales=D(cs["dscales0"]) if "dscales0" in cs else Z(f), dmean=Z(f), dvar=Z(f))
         ws = Z(max(1, ops.conv_workspace_size(n, c, h, w, f, k, s, p, g)))
-        ops.conv_backward(x, wt, y, dy, dx, dw, db, k, s, p, g, act, ws, None, None, b)
+        ops.conv_backward(x, wt, y, dy, dx, dw, db, k, s, p, g, act, ws, None, None, b, bias)
         out.update(dy_out=H(dy), dw=H(dw), db=H(db))
         if dx is not None:
             out["dx"] = H(dx)
