@@ -46,6 +46,20 @@ CASES = [
     rc.make_conv(22, 2, 2, 6, 6, 3, 3, 1, 1, act=A.ACT_CLAMP, name="conv_clamp"),
     rc.make_conv(23, 2, 2, 6, 6, 3, 3, 1, 1, act=A.ACT_ABS, name="conv_abs"),
     rc.make_conv(24, 2, 2, 6, 6, 3, 3, 1, 1, act=A.ACT_SOFTPLUS, name="conv_softplus"),
+    # ---- conv at channel counts that reach the LDS-DMA GEMM kernels (M > 32, reduction majors >= 8/16):
+    #      ragged M and J tiles, stride-parity classes, 1x1 raw views, groups, fused batch-norm statistics
+    rc.make_conv(101, 3, 48, 12, 12, 80, 3, 1, 1, act=A.ACT_RELU, name="conv_dma_c48_f80_k3"),
+    rc.make_conv(102, 2, 40, 13, 11, 72, 3, 2, 1, name="conv_dma_c40_f72_k3s2_odd"),
+    rc.make_conv(103, 2, 64, 9, 9, 64, 1, 1, 0, act=A.ACT_LRELU, name="conv_dma_c64_f64_k1"),
+    rc.make_conv(104, 2, 48, 10, 10, 64, 1, 2, 0, name="conv_dma_c48_f64_k1s2_quirk1"),
+    rc.make_conv(105, 2, 64, 8, 8, 128, 3, 1, 1, g=2, name="conv_dma_groups2_c64_f128"),
+    rc.make_conv(106, 2, 34, 10, 10, 66, 5, 1, 2, name="conv_dma_c34_f66_k5p2"),
+    rc.make_conv(107, 4, 32, 14, 14, 64, 3, 1, 1, bn=1, act=A.ACT_RELU, name="conv_dma_bn_relu_c32_f64"),
+    rc.make_conv(108, 2, 33, 7, 9, 65, 3, 1, 1, name="conv_dma_odd_c33_f65"),
+    rc.make_conv(109, 2, 36, 11, 11, 64, 3, 3, 0, name="conv_dma_c36_f64_k3s3"),
+    rc.make_conv(110, 2, 36, 10, 10, 40, 2, 3, 0, name="conv_dma_c36_f40_k2s3_empty_classes"),
+    rc.make_conv(111, 6, 64, 8, 8, 64, 3, 1, 1, bn=1, act=A.ACT_RELU, carry=True, name="conv_dma_bn_carry_c64_f64"),
+    rc.make_conv(112, 2, 64, 12, 12, 96, 3, 2, 1, bn=1, act=A.ACT_RELU, name="conv_dma_bn_c64_f96_s2"),
     # ---- stand-alone batchnorm -----------------------------------------------------------------
     rc.make_bn(30, 2, 3, 5, 5, name="bn_train"),
     rc.make_bn(31, 4, 8, 7, 9, carry=True, name="bn_train_carry"),
@@ -94,6 +108,8 @@ def main():
         name = case["name"]
         assert name not in names, name
         names.add(name)
+        if os.path.exists(os.path.join(out_dir, name + ".npz")) and "--force" not in sys.argv:
+            continue  # fixtures are pins: existing ones are only rewritten on request
         outs = rc.run_ref(case)
         blob = {}
         for k, v in case.items():
