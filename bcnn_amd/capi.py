@@ -63,6 +63,7 @@ def lib():
         "bcnn_add_softmax_layer": (i, [vp, cp, cp]), "bcnn_add_cost_layer": (i, [vp, i, i, f, cp, cp, cp]),
         "bcnn_upload_tensor": (i, [vp, i, i]), "bcnn_download_tensor": (i, [vp, i, i]),
         "bcnn_set_data_parallel": (i, [vp, i, i]),
+        "bcnn_set_gradient_ready_callback": (None, [vp, vp, vp]),
         "bcnn_get_gradient_arena": (vp, [vp, C.POINTER(sz)]), "bcnn_get_parameter_arena": (vp, [vp, C.POINTER(sz)]),
         "bcnn_synchronize": (None, [vp]), "bcnn_peek_tensor": (tp, [vp, i]), "bcnn_get_num_nodes": (i, [vp]),
         "bcnn_get_node_tensor": (i, [vp, i, i, i]), "bcnn_get_node_state": (vp, [vp, i, i]),
@@ -193,6 +194,17 @@ class Net:
 
     def set_data_parallel(self, rank, world):
         assert self.L.bcnn_set_data_parallel(self.net, rank, world) == 0
+
+    def set_gradient_ready_callback(self, fn):
+        """fn(first_float, num_floats) is called inside backward() as tail ranges of the gradient arena
+        become final (see include/bcnn/bcnn.h); None removes it."""
+        if fn is None:
+            self._grad_cb = None
+            self.L.bcnn_set_gradient_ready_callback(self.net, None, None)
+            return
+        proto = C.CFUNCTYPE(None, C.c_size_t, C.c_size_t, C.c_void_p)
+        self._grad_cb = proto(lambda first, count, user: fn(int(first), int(count)))  # keep alive
+        self.L.bcnn_set_gradient_ready_callback(self.net, C.cast(self._grad_cb, C.c_void_p), None)
 
     def gradient_arena(self):
         n = C.c_size_t()

@@ -238,6 +238,7 @@ void bcnn_end_net(bcnn_net **pnet) {
         bcnn_hip_free(hc->sgd_chunks_gpu);
         free(hc->sgd_chunks_host);
         free(hc->grad_fill_dead);
+        free(hc->node_grad_first);
     }
     for (int i = 0; i < net->num_nodes; ++i) {
         bcnn_node *nd = &net->nodes[i];
@@ -396,7 +397,39 @@ void bcnn_forward(bcnn_net *net) {
 }
 
 void bcnn_backward(bcnn_net *net) {
-    for (int i = net->num_nodes - 1; i >= 0; --i) net->nodes[i].backward(net, &net->nodes[i]);
+    bcnn_hip_context *hc = hctx(net);
+    size_t ready_from = hc->arena_size;
+    for (int i = net->num_nodes - 1; i >= 0; --i) {
+        net->nodes[i].backward(net, &net->nodes[i]);
+        if (hc->grad_ready_fn && hc->node_grad_first && hc->node_grad_first[i] < ready_from) {
+            hc->grad_ready_fn(hc->node_grad_first[i], ready_from - hc->node_grad_first[i], hc->grad_ready_user);
+            ready_from = hc->node_grad_first[i];
+        }
+    }
+    if (hc->grad_ready_fn && ready_from > 0 && hc->arena_size > 0)  /* members no node claims (none today) */
+        hc->grad_ready_fn(0, ready_from, hc->grad_ready_user);
+}
+
+void bcnn_set_gradient_ready_callback(bcnn_net *net, bcnn_gradient_ready_fn fn, void *user) {
+    bcnn_hip_context *hc = hctx(net);
+    hc->grad_ready_fn = fn;
+    hc->grad_ready_user = user;
+    free(hc->node_grad_first);
+    hc->node_grad_first = NULL;
+    if (!fn || !hc->grad_arena_gpu) return;
+    hc->node_grad_first = (size_t *)malloc((size_t)net->num_nodes * sizeof(size_t));
+    for (int i = 0; i < net->num_nodes; ++i) {
+        size_t first = (size_t)-1;
+        for (int k = 0; k < net->nodes[i].num_src; ++k) {
+            const bcnn_tensor *t = &net->tensors[net->nodes[i].src[k]];
+            if (!t->grad_data_gpu || t->grad_data_gpu < hc->grad_arena_gpu ||
+                t->grad_data_gpu >= hc->grad_arena_gpu + hc->arena_size)
+                continue;
+            const size_t off = (size_t)(t->grad_data_gpu - hc->grad_arena_gpu);
+            if (off < first) first = off;
+        }
+        hc->node_grad_first[i] = first;
+    }
 }
 
 /* learning-rate schedules, reference bcnn_learner.c:29-65 */

@@ -122,6 +122,11 @@ typedef struct bcnn_hip_context {
     int compiled;
     /* update loop folded into one launch: table of (buffer, gradient, count, rule) chunks, built by the
      * first bcnn_update from what the nodes' update() workers ask for */
+    /* gradient-ready callback (bcnn_set_gradient_ready_callback): node_grad_first[i] = arena offset of the first
+     * parameter owned by node i, or (size_t)-1 */
+    void (*grad_ready_fn)(size_t, size_t, void *);
+    void *grad_ready_user;
+    size_t *node_grad_first;
     /* per tensor: 1 = the zero-fill of its gradient before forward is dead (see mark_dead_grad_fills) */
     unsigned char *grad_fill_dead;
     struct bcnn_hip_sgd_chunk *sgd_chunks_host;

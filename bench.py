@@ -113,6 +113,8 @@ def main():
     ap.add_argument("--workload", default="resnet18", choices=["resnet18", "conv3x3"])
     ap.add_argument("--batch", type=int, default=128, help="images per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="data-parallel runs: one blocking all-reduce after backward instead of overlapped buckets")
     args = ap.parse_args()
 
     import torch
@@ -126,8 +128,9 @@ def main():
     torch.cuda.set_device(local_rank)
     L = _lib.load()
     L.bcnn_hip_set_device(local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get("BENCH_FORCE_DP") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world)  # "nccl" IS RCCL on ROCm
     dev = torch.device("cuda", local_rank)
     n = args.batch
@@ -156,15 +159,47 @@ def main():
         L.bcnn_hip_memcpy_d2d(t_lab.data_gpu, lab.data_ptr(), lab.numel() * 4)
         L.bcnn_hip_sync()
         gptr, gsize = net.gradient_arena()
-        grads = torch.as_tensor(capi.DeviceArray(gptr, gsize), device=dev) if world > 1 else None
+        dp = world > 1 or os.environ.get("BENCH_FORCE_DP") == "1"   # the env switch exercises the DP plumbing on 1 GPU
+        grads = torch.as_tensor(capi.DeviceArray(gptr, gsize), device=dev) if dp else None
+        overlap = dp and not args.no_overlap
+        if overlap:
+            # Gradient all-reduce overlapped with backward: the C executor reports growing tail ranges of the
+            # gradient arena as their nodes finish (bcnn_set_gradient_ready_callback); ranges are gathered into
+            # ~8 MB buckets and each bucket is all-reduced asynchronously on RCCL's stream, ordered after the
+            # work queued so far on OUR stream (torch sees it as an ExternalStream). Nothing blocks the host;
+            # update() is ordered behind the last bucket by work.wait() on the same stream.
+            ext = torch.cuda.ExternalStream(stream, device=dev)
+            bucket_floats = max(1, (8 << 20) // 4)
+            pending = {"lo": gsize, "hi": gsize, "works": []}
+
+            def flush():
+                if pending["lo"] < pending["hi"]:
+                    with torch.cuda.stream(ext):
+                        pending["works"].append(dist.all_reduce(grads[pending["lo"]:pending["hi"]], async_op=True))
+                    pending["hi"] = pending["lo"]
+
+            def on_ready(first, count):
+                pending["lo"] = first
+                if pending["hi"] - pending["lo"] >= bucket_floats:
+                    flush()
+            net.set_gradient_ready_callback(on_ready)
 
         def step():
             net.forward()
-            net.backward()
-            if world > 1:
-                L.bcnn_hip_sync()           # gradients complete on our stream before RCCL reads them
-                dist.all_reduce(grads)      # ONE all-reduce of the flat weight/bias-gradient arena (xGMI)
-                torch.cuda.synchronize()
+            if overlap:
+                pending["lo"] = pending["hi"] = gsize
+                net.backward()
+                flush()
+                with torch.cuda.stream(ext):
+                    for w in pending["works"]:
+                        w.wait()            # stream-side wait: update() below is ordered after every bucket
+                pending["works"].clear()
+            else:
+                net.backward()
+                if dp:
+                    L.bcnn_hip_sync()           # gradients complete on our stream before RCCL reads them
+                    dist.all_reduce(grads)      # ONE all-reduce of the flat weight/bias-gradient arena (xGMI)
+                    torch.cuda.synchronize()
             net.update()
         desc = ("ResNet-18 224x224 (BASELINE configs[2]), N=%d per GPU, fwd+bwd+SGD through bcnn_net C API; "
                 "CIFAR-example topology + ImageNet stem, fc-1000" % n)
@@ -262,7 +297,7 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, sample_n)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

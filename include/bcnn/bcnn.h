@@ -207,6 +207,13 @@ BCNN_API bcnn_status bcnn_download_tensor(bcnn_net *net, int tensor_index, int w
 BCNN_API bcnn_status bcnn_set_data_parallel(bcnn_net *net, int rank, int world_size);
 BCNN_API float *bcnn_get_gradient_arena(bcnn_net *net, size_t *num_floats);  /* device pointer */
 BCNN_API float *bcnn_get_parameter_arena(bcnn_net *net, size_t *num_floats); /* device pointer */
+/* Overlap of the gradient all-reduce with backward. Parameters sit in the arena in node order and backward
+ * visits the nodes in reverse, so the finished gradients always form a growing TAIL of the arena: `fn` is
+ * called from inside bcnn_backward (same thread, after the owning node's work has been queued on the
+ * stream) with the newly completed range [first_float, first_float + num_floats). The caller may queue a
+ * collective on that range that depends on the stream's work so far. NULL removes the callback. */
+typedef void (*bcnn_gradient_ready_fn)(size_t first_float, size_t num_floats, void *user);
+BCNN_API void bcnn_set_gradient_ready_callback(bcnn_net *net, bcnn_gradient_ready_fn fn, void *user);
 BCNN_API void bcnn_synchronize(bcnn_net *net);
 /* borrowed pointer to tensor `index` WITHOUT the device->host refresh bcnn_get_tensor_by_index performs */
 BCNN_API bcnn_tensor *bcnn_peek_tensor(bcnn_net *net, int index);

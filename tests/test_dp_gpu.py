@@ -77,3 +77,37 @@ def test_two_replicas_with_summed_arena_match_reference_on_global_batch():
     for net in reps:
         net.close()
     ref.close()
+
+
+def test_gradient_ready_ranges_tile_the_arena():
+    """bcnn_set_gradient_ready_callback reports growing TAIL ranges of the gradient arena during backward:
+    contiguous, descending, and together exactly the arena -- what the bucketed all-reduce in bench.py relies on."""
+    from bcnn_amd import capi
+    net = capi.Net(mode=capi.MODE_TRAIN, n=2, w=12, h=12, c=3)
+    graph(net)
+    net.compile()
+    net.set_sgd(0.05, 0.9, 5e-4)
+    net.set_data_parallel(0, 1)
+    _, gsize = net.gradient_arena()
+    seen = []
+    net.set_gradient_ready_callback(lambda first, count: seen.append((first, count)))
+    rs = np.random.RandomState(3)
+    net.data(0)[...] = rs.uniform(-1, 1, (2, 3, 12, 12)).astype(np.float32)
+    lab = np.zeros((2, 5, 1, 1), np.float32)
+    lab[0, 1] = lab[1, 3] = 1.0
+    net.data(1)[...] = lab
+    net.upload(0); net.upload(1)
+    net.forward(); net.backward(); net.sync()
+    assert seen, "callback never fired"
+    hi = gsize
+    for first, count in seen:
+        assert count > 0 and first + count == hi, (seen, gsize)
+        hi = first
+    assert hi == 0, (seen, gsize)
+    # a second backward reports the same ranges (state is reset per call), and None removes the callback
+    n_first = len(seen)
+    net.forward(); net.backward(); net.sync()
+    assert seen[n_first:] == seen[:n_first]
+    net.set_gradient_ready_callback(None)
+    net.forward(); net.backward(); net.sync()
+    assert len(seen) == 2 * n_first
