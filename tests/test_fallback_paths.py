@@ -1,0 +1,24 @@
+"""The convolution has two generations of GEMM kernels: the LDS-DMA ones (conv_igemm_dma.hip, conv_dw_dma.hip)
+take every shape they support, the register-staged ones (conv_igemm.hip, conv_bwd.hip) the rest. The switch
+BCNN_HIP_NO_DMA=1 (read once per process) forces the second set, so the whole golden suite is replayed in a
+child process to keep both generations pinned to the reference."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"BCNN_HIP_NO_DMA": "1"}, {"BCNN_HIP_NO_FUSED_STATS": "1"}],
+                         ids=["register_staged_kernels", "unfused_bn_statistics"])
+def test_golden_suite_on_the_other_code_path(env):
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_hip_parity.py"), "-m", "gpu",
+                        "-q", "-x", "-p", "no:cacheprovider"], cwd=ROOT, env=e, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
