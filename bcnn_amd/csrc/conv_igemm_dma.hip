@@ -63,13 +63,20 @@ __global__ __launch_bounds__(256, ABL_LB) void conv_igemm_dma_kernel(const DmaAr
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int AH = BM / 64, BH = BN / 64;
     static_assert(WM * WN == 4, "4 waves");
-    // one block of LDS: As[2][BK][BM] | Bs[2][BK][BN]; after the K loop the same bytes hold one 32x32
+    // one block of LDS: As[NS][BK][BM] | Bs[NS][BK][BN]; after the K loop the same bytes hold one 32x32
     // transposition pad per wave for the fused statistics
-    constexpr int SMEM = 2 * BK * (BM + BN);
+#ifndef DMA_NSTAGE
+#define DMA_NSTAGE 2
+#endif
+    // LDS ring depth: the DMA runs NS - 1 tiles ahead of the MFMAs. 3 stages measured no faster than 2 on any
+    // ResNet shape and 3-6 % slower on the 14x14 / 7x7 layers (24 KB instead of 16 KB of LDS: 6 instead of 8
+    // resident workgroups per CU) -- with 8 waves per SIMD the DMA latency is already hidden.
+    constexpr int NS = DMA_NSTAGE;
+    constexpr int SMEM = NS * BK * (BM + BN);
     static_assert(SMEM >= 4 * 1024, "statistics pads");
     __shared__ float smem[SMEM];
     float (*As)[BK][BM] = reinterpret_cast<float (*)[BK][BM]>(smem);
-    float (*Bs)[BK][BN] = reinterpret_cast<float (*)[BK][BN]>(smem + 2 * BK * BM);
+    float (*Bs)[BK][BN] = reinterpret_cast<float (*)[BK][BN]>(smem + NS * BK * BM);
 
     const ConvShape& s = a.s;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -186,25 +193,31 @@ __global__ __launch_bounds__(256, ABL_LB) void conv_igemm_dma_kernel(const DmaAr
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int l31 = lane & 31, lhi = lane >> 5;
-    int t_next = 0, jb_next = 0;
-    if (ntiles > 0) {  // a class may own no tap at all (stride > kernel size): it then stores zeros
-        set_tap();
-        stage(0, 0, 0);
-    }
-    dma_wait();
-    __syncthreads();
-    for (int it = 0; it < ntiles; ++it) {
-        const int cur = it & 1;
-        if (it + 1 < ntiles) {
-            if (++jb_next == JB) {
-                jb_next = 0; ++t_next;
-                if (++tap_j == c_nkx) { tap_j = 0; ++tap_i; }
-                set_tap();
-            }
-#ifndef ABL_NODMA
-            stage(t_next, jb_next, cur ^ 1);  // DMA in flight under the MFMAs
-#endif
+    // ---- K loop: ring of NS LDS stages. Tile it + NS - 1 is requested before the MFMAs of tile it; at the
+    // end of the iteration only tile it + 1 has to have landed, i.e. the wave waits until at most the loads
+    // of the NS - 2 younger tiles are still in flight (vmcnt is in-order) and then meets the barrier.
+    constexpr int LOADS_PER_TILE = 4 * (AH + BH);  // DMA instructions one wave issues per tile
+    int t_next = 0, jb_next = 0, issued = 0;       // (tap, major block) of the next tile to request
+    auto request_next = [&](int buf) {
+        if (issued > 0 && ++jb_next == JB) {
+            jb_next = 0; ++t_next;
+            if (++tap_j == c_nkx) { tap_j = 0; ++tap_i; }
+            set_tap();
         }
+        stage(t_next, jb_next, buf);
+        ++issued;
+    };
+    if (ntiles > 0) set_tap();  // a class may own no tap at all (stride > kernel size): it then stores zeros
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p)
+        if (p < ntiles) request_next(p);
+    if (NS == 3 && ntiles > 1) dma_wait_n<LOADS_PER_TILE>(); else dma_wait();
+    __syncthreads();
+    int cur = 0, fill = NS - 1;  // stage being multiplied / stage to refill
+    for (int it = 0; it < ntiles; ++it) {
+#ifndef ABL_NODMA
+        if (it + NS - 1 < ntiles) request_next(fill);  // DMA in flight under the MFMAs
+#endif
         // fragments of k-step ks+1 are fetched from LDS before the MFMAs of k-step ks are issued
         float af[2][TM], bf[2][TN];
 #pragma unroll
@@ -228,9 +241,11 @@ __global__ __launch_bounds__(256, ABL_LB) void conv_igemm_dma_kernel(const DmaAr
             __builtin_amdgcn_sched_barrier(0);
         }
 #ifndef ABL_NOBAR
-        dma_wait();
+        if (NS == 3 && it + 2 < ntiles) dma_wait_n<LOADS_PER_TILE>(); else dma_wait();
         __syncthreads();
 #endif
+        cur = (cur + 1 == NS) ? 0 : cur + 1;
+        fill = (fill + 1 == NS) ? 0 : fill + 1;
     }
 
     // ---- batch-norm statistics of this tile (fused: saves the separate read of the whole output) -----

@@ -31,6 +31,12 @@ __device__ __forceinline__ void dma_row(rsrc_i4 rs, unsigned lds_base, unsigned 
                  : "memory", "m0");
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// wait until at most N of this wave's loads are outstanding (vmcnt retires in order: the N youngest may fly)
+template <int N>
+__device__ __forceinline__ void dma_wait_n() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 
 // n / d via multiply-high with magic = ceil(2^32 / d) (exact while n * d < 2^32); d == 1 is encoded as magic 0.
 __device__ __forceinline__ unsigned magic_div(unsigned n, unsigned magic) { return magic ? __umulhi(n, magic) : n; }
