@@ -67,7 +67,7 @@ def lib():
         "bcnn_get_gradient_arena": (vp, [vp, C.POINTER(sz)]), "bcnn_get_parameter_arena": (vp, [vp, C.POINTER(sz)]),
         "bcnn_synchronize": (None, [vp]), "bcnn_peek_tensor": (tp, [vp, i]), "bcnn_get_num_nodes": (i, [vp]),
         "bcnn_get_node_tensor": (i, [vp, i, i, i]), "bcnn_get_node_state": (vp, [vp, i, i]),
-        "bcnn_load_net": (i, [vp, cp, cp]), "bcnn_save_weights": (i, [vp, cp]),
+        "bcnn_load_net": (i, [vp, cp, cp]), "bcnn_save_weights": (i, [vp, cp]), "bcnn_load_weights": (i, [vp, cp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -187,6 +187,14 @@ class Net:
 
     def sync(self):
         self.L.bcnn_synchronize(self.net)
+
+    def save_weights(self, path):
+        """bcnn_save_weights (reference bcnn_net.c:597-681); returns the bcnn_status"""
+        return self.L.bcnn_save_weights(self.net, path.encode())
+
+    def load_weights(self, path):
+        """bcnn_load_weights (reference bcnn_net.c:1485-1558); returns the bcnn_status"""
+        return self.L.bcnn_load_weights(self.net, path.encode())
 
     def set_sgd(self, lr, momentum, decay=0.0):
         self.L.bcnn_set_sgd_optimizer(self.net, lr, momentum)

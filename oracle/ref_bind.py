@@ -66,6 +66,9 @@ def lib():
     L.bcnn_add_maxpool_layer.argtypes = [vp, i, i, i, cp, cp]; L.bcnn_add_maxpool_layer.restype = i
     L.bcnn_add_avgpool_layer.argtypes = [vp, cp, cp]; L.bcnn_add_avgpool_layer.restype = i
     L.bcnn_add_eltwise_layer.argtypes = [vp, i, cp, cp, cp]; L.bcnn_add_eltwise_layer.restype = i
+    L.bcnn_add_activation_layer.argtypes = [vp, i, cp]; L.bcnn_add_activation_layer.restype = i
+    L.bcnn_save_weights.argtypes = [vp, cp]; L.bcnn_save_weights.restype = i
+    L.bcnn_load_weights.argtypes = [vp, cp]; L.bcnn_load_weights.restype = i
     L.bcnn_add_fullc_layer.argtypes = [vp, i, i, i, i, cp, cp]; L.bcnn_add_fullc_layer.restype = i
     L.bcnn_add_softmax_layer.argtypes = [vp, cp, cp]; L.bcnn_add_softmax_layer.restype = i
     L.bcnn_add_cost_layer.argtypes = [vp, i, i, f, cp, cp, cp]; L.bcnn_add_cost_layer.restype = i
@@ -169,9 +172,20 @@ class RefNet:
         assert st == 0, st
         return self.L.ref_num_nodes(self.net) - 1
 
+    def activation(self, act, src):
+        st = self.L.bcnn_add_activation_layer(self.net, act, src.encode())
+        assert st == 0, st
+        return self.L.ref_num_nodes(self.net) - 1
+
     def compile(self):
         assert self.L.bcnn_compile_net(self.net) == 0
         self.compiled = True
+
+    def save_weights(self, path):
+        return self.L.bcnn_save_weights(self.net, path.encode())
+
+    def load_weights(self, path):
+        return self.L.bcnn_load_weights(self.net, path.encode())
 
     # --- tensors ------------------------------------------------------------------------------
     def tensor(self, idx):
