@@ -148,6 +148,269 @@ __global__ void dw_weight_accumulate_kernel(const float* __restrict__ partials, 
     dw[i] += (float)s;
 }
 
+// ================================================================================================
+// 3x3 fast paths: one thread per FOUR consecutive output columns of a row. The (plane, row, column group)
+// index is split with two multiply-high divisions per thread instead of three hardware divisions per
+// element; the 3 x (3*S + 3) input window is fetched once with zero fill (adding w * 0 is what skipping an
+// out-of-image tap amounts to) and reused by the four outputs; outputs leave as one 16-byte store when the
+// row allows it. Same tap order as the reference (kh outer, kw inner, separate multiply and add).
+// ================================================================================================
+struct Dw3Args {
+    DwShape s;
+    unsigned groups_per_row;   // ceil(OW / 4)
+    unsigned gpr_magic, oh_magic;
+    unsigned total_groups;     // planes * OH * groups_per_row
+};
+__device__ __forceinline__ unsigned dw_div(unsigned n, unsigned d, unsigned magic) {
+    // magic = ceil(2^32 / d); one correction step makes it exact for every n < 2^32 / 2
+    if (d == 1) return n;
+    unsigned q = __umulhi(n, magic);
+    if (q * d > n) --q;
+    return q;
+}
+
+// zero-filled window of WIN consecutive floats starting at column iw0 of `row` (row == NULL: all zero).
+// `fast` (wave-uniform): rows are 16-byte aligned and iw0 + 1 is a multiple of 4, so the body of the window
+// is one or two aligned 16-byte loads and only the first / last column are scalar.
+template <int WIN>
+__device__ __forceinline__ void dw_window(const float* row, int iw0, int W, bool fast, float (&xv)[WIN]) {
+    if (row == nullptr) {
+#pragma unroll
+        for (int i = 0; i < WIN; ++i) xv[i] = 0.f;
+        return;
+    }
+    if (fast) {
+        xv[0] = iw0 >= 0 ? row[iw0] : 0.f;
+#pragma unroll
+        for (int v = 0; v + 4 < WIN; v += 4) {
+            const int col = iw0 + 1 + v;
+            if (col + 3 < W) {
+                const float4 t = *reinterpret_cast<const float4*>(row + col);
+                xv[1 + v] = t.x; xv[2 + v] = t.y; xv[3 + v] = t.z; xv[4 + v] = t.w;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xv[1 + v + i] = (col + i < W) ? row[col + i] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int i = 1 + ((WIN - 1) / 4) * 4; i < WIN; ++i) xv[i] = (iw0 + i < W) ? row[iw0 + i] : 0.f;
+    } else {
+#pragma unroll
+        for (int i = 0; i < WIN; ++i) {
+            const int iw = iw0 + i;
+            xv[i] = (unsigned)iw < (unsigned)W ? row[iw] : 0.f;
+        }
+    }
+}
+
+template <int S>
+__global__ __launch_bounds__(256) void dw3_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, float* __restrict__ y,
+                                                      const Dw3Args a, int act) {
+    constexpr int WIN = 3 * S + 3;  // input columns feeding 4 outputs
+    const DwShape& s = a.s;
+    const unsigned t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= a.total_groups) return;
+    const unsigned rowid = dw_div(t, a.groups_per_row, a.gpr_magic), q = t - rowid * a.groups_per_row;
+    const unsigned plane = dw_div(rowid, (unsigned)s.OH, a.oh_magic), oh = rowid - plane * (unsigned)s.OH;
+    const int c = (int)(plane % (unsigned)s.C);
+    const float* src = x + (size_t)plane * s.H * s.W;
+    const float* wk = w + c * 9;
+    float wv[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) wv[i] = wk[i];
+    const int ow0 = (int)q * 4, ih0 = (int)oh * S - s.pad, iw0 = ow0 * S - s.pad;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool fast = s.pad == 1 && (s.W & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int ih = ih0 + kh;
+        const bool rv = (unsigned)ih < (unsigned)s.H;
+        float xv[WIN];
+        dw_window<WIN>(rv ? src + ih * s.W : nullptr, iw0, s.W, fast, xv);
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __fadd_rn(acc[j], __fmul_rn(wv[kh * 3 + kw], xv[j * S + kw]));
+    }
+    const float b = bias[c];
+    float* dst = y + ((size_t)plane * s.OH + oh) * s.OW + ow0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (b != 0.0f && b != 1.0f) acc[j] += b;
+        acc[j] = act_fwd_cheap(acc[j], act, 0.f);
+    }
+    if (ow0 + 4 <= s.OW && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+        *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (ow0 + j < s.OW) dst[j] = acc[j];
+    }
+}
+
+// dw partial sums: grid-stride over the same 4-column groups, restricted to ONE channel per workgroup row
+// (blockIdx.y = channel) so the nine accumulators reduce without atomics; blockIdx.x = split of the channel's
+// (image, row, group) space.
+template <int S>
+__global__ __launch_bounds__(256) void dw3_bwd_weight_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                             const Dw3Args a, int splits,
+                                                             float* __restrict__ partials) {
+    constexpr int WIN = 3 * S + 3;
+    __shared__ float red[4][9];
+    const DwShape& s = a.s;
+    const int c = blockIdx.y, sp = blockIdx.x;
+    const unsigned per_img = (unsigned)s.OH * a.groups_per_row;       // groups per (image, channel) plane
+    const unsigned M = (unsigned)s.N * per_img;
+    const unsigned per = (M + splits - 1) / splits;
+    const unsigned lo = sp * per;
+    unsigned hi = lo + per;
+    if (hi > M) hi = M;
+    float acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) acc[i] = 0.f;
+    const bool fast = s.pad == 1 && (s.W & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    for (unsigned idx = lo + threadIdx.x; idx < hi; idx += 256) {
+        const unsigned rowid = dw_div(idx, a.groups_per_row, a.gpr_magic), q = idx - rowid * a.groups_per_row;
+        const unsigned n = dw_div(rowid, (unsigned)s.OH, a.oh_magic), oh = rowid - n * (unsigned)s.OH;
+        const size_t plane = (size_t)n * s.C + c;
+        const float* src = x + plane * s.H * s.W;
+        const float* gp = g + (plane * s.OH + oh) * s.OW;
+        const int ow0 = (int)q * 4, ih0 = (int)oh * S - s.pad, iw0 = ow0 * S - s.pad;
+        float gv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gv[j] = (ow0 + j < s.OW) ? gp[ow0 + j] : 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ih = ih0 + kh;
+            const bool rv = (unsigned)ih < (unsigned)s.H;
+            float xv[WIN];
+            dw_window<WIN>(rv ? src + ih * s.W : nullptr, iw0, s.W, fast, xv);
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[kh * 3 + kw] += xv[j * S + kw] * gv[j];
+        }
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const float v = wave_sum(acc[i]);
+        if (lane == 0) red[wid][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 9)
+        partials[((long long)c * splits + sp) * 9 + threadIdx.x] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// dx += gather, one thread per four consecutive INPUT columns; any stride (tap parity tested per pixel).
+// Tap order per pixel as in dw_bwd_data_kernel (descending kh, kw = ascending output position).
+struct Dw3DxArgs {
+    DwShape s;
+    unsigned groups_per_row;   // ceil(W / 4)
+    unsigned gpr_magic, h_magic;
+    unsigned total_groups;     // planes * H * groups_per_row
+};
+template <int S>  // S = compile-time stride (1, 2), 0 = runtime stride
+__global__ __launch_bounds__(256) void dw3_bwd_data_kernel(const float* __restrict__ g, const float* __restrict__ w,
+                                                           float* __restrict__ dx, const Dw3DxArgs a) {
+    const DwShape& s = a.s;
+    const unsigned t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= a.total_groups) return;
+    const unsigned rowid = dw_div(t, a.groups_per_row, a.gpr_magic), q = t - rowid * a.groups_per_row;
+    const unsigned plane = dw_div(rowid, (unsigned)s.H, a.h_magic), ih = rowid - plane * (unsigned)s.H;
+    const int c = (int)(plane % (unsigned)s.C);
+    const float* gp = g + (size_t)plane * s.OH * s.OW;
+    const float* wk = w + c * 9;
+    float wv[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) wv[i] = wk[i];
+    const int iw0 = (int)q * 4;
+    float* dst = dx + ((size_t)plane * s.H + ih) * s.W + iw0;
+    const bool vec = iw0 + 4 <= s.W && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
+    float acc[4];
+    if (vec) {
+        const float4 v = *reinterpret_cast<const float4*>(dst);
+        acc[0] = v.x; acc[1] = v.y; acc[2] = v.z; acc[3] = v.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = (iw0 + j < s.W) ? dst[j] : 0.f;
+    }
+    if (S == 1 || S == 2) {
+        // tw = e + j - kw with e = iw0 + pad; the dy columns the four pixels can meet form a short window that
+        // is fetched once per row with zero fill: S == 1: ow = e - 2 .. e + 3; S == 2: ow = eb - 1 .. eb + 2
+        // where e = 2 * eb + par (iw0 is a multiple of 4, so par is the parity of pad: wave-uniform)
+        constexpr int WIN = (S == 1) ? 6 : 4;
+        const int e = iw0 + s.pad;
+        const int par = (S == 2) ? (e & 1) : 0;
+        const int wbase = (S == 1) ? e - 2 : ((e - par) >> 1) - 1;
+#pragma unroll
+        for (int kh = 2; kh >= 0; --kh) {
+            const int th = (int)ih + s.pad - kh;
+            if (th < 0 || (S == 2 && (th & 1))) continue;
+            const int oh = (S == 2) ? th >> 1 : th;
+            if (oh >= s.OH) continue;
+            const float* grow = gp + oh * s.OW;
+            float gw[WIN];
+#pragma unroll
+            for (int i = 0; i < WIN; ++i) {
+                const int ow = wbase + i;
+                gw[i] = (unsigned)ow < (unsigned)s.OW ? grow[ow] : 0.f;
+            }
+            if (S == 1) {
+#pragma unroll
+                for (int kw = 2; kw >= 0; --kw)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[j] = __fadd_rn(acc[j], __fmul_rn(wv[kh * 3 + kw], gw[j + 2 - kw]));
+            } else if (par == 0) {
+#pragma unroll
+                for (int kw = 2; kw >= 0; --kw)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (((j - kw) & 1) == 0)
+                            acc[j] = __fadd_rn(acc[j], __fmul_rn(wv[kh * 3 + kw], gw[(j - kw + 2) / 2]));
+            } else {
+#pragma unroll
+                for (int kw = 2; kw >= 0; --kw)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (((1 + j - kw) & 1) == 0)
+                            acc[j] = __fadd_rn(acc[j], __fmul_rn(wv[kh * 3 + kw], gw[(1 + j - kw + 2) / 2]));
+            }
+        }
+    } else {
+#pragma unroll
+        for (int kh = 2; kh >= 0; --kh) {
+            const int stride = s.stride;
+            const int th = (int)ih + s.pad - kh;
+            if (th < 0) continue;
+            const int oh = th / stride;
+            if (oh * stride != th || oh >= s.OH) continue;
+            const float* grow = gp + oh * s.OW;
+#pragma unroll
+            for (int kw = 2; kw >= 0; --kw)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int tw = iw0 + j + s.pad - kw;
+                    const int ow = tw / stride;
+                    if (tw >= 0 && ow * stride == tw && ow < s.OW)
+                        acc[j] = __fadd_rn(acc[j], __fmul_rn(wv[kh * 3 + kw], grow[ow]));
+                }
+        }
+    }
+    if (vec) {
+        *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (iw0 + j < s.W) dst[j] = acc[j];
+    }
+}
+
+static unsigned dw_magic(unsigned d) { return d > 1 ? (unsigned)((0x100000000ULL + d - 1) / d) : 0u; }
+
 }  // namespace bcnn_hip
 
 using namespace bcnn_hip;
@@ -160,8 +423,19 @@ void bcnn_hip_depthwise_forward(const float* x, const float* w, const float* bia
     const long long total = (long long)n * c * s.OH * s.OW;
     if (total <= 0) return;
     const int fused = act_is_cheap(act) ? act : BCNN_HIP_ACT_NONE;
-    dw_fwd_kernel<<<stream_grid((size_t)total, 256), 256, 0, current_stream()>>>(x, w, bias, y, s, fused,
-                                                                               (unsigned)total);
+    const unsigned gpr = (unsigned)ceil_div(s.OW, 4);
+    const long long groups = (long long)n * c * s.OH * gpr;
+    if (k == 3 && (stride == 1 || stride == 2) && groups < 0x7fffffffLL) {
+        Dw3Args a;
+        a.s = s; a.groups_per_row = gpr; a.gpr_magic = dw_magic(gpr); a.oh_magic = dw_magic((unsigned)s.OH);
+        a.total_groups = (unsigned)groups;
+        const unsigned blocks = (unsigned)((groups + 255) / 256);
+        if (stride == 1) dw3_fwd_kernel<1><<<blocks, 256, 0, current_stream()>>>(x, w, bias, y, a, fused);
+        else dw3_fwd_kernel<2><<<blocks, 256, 0, current_stream()>>>(x, w, bias, y, a, fused);
+    } else {
+        dw_fwd_kernel<<<stream_grid((size_t)total, 256), 256, 0, current_stream()>>>(x, w, bias, y, s, fused,
+                                                                                   (unsigned)total);
+    }
     KERNEL_CHECK();
     if (fused != act) bcnn_hip_activation_forward(y, (size_t)total, act, nullptr, s.OH * s.OW, c);
 }
@@ -181,7 +455,15 @@ void bcnn_hip_depthwise_backward(const float* x, const float* w, const float* y,
     const int splits = chan_splits(c, M);
     float* part = reduce_scratch((size_t)c * splits * NT);
     dim3 grid((unsigned)c, (unsigned)splits);
-    if (k == 3) dw_bwd_weight_kernel<3><<<grid, 256, 0, current_stream()>>>(x, dy, s, splits, part);
+    const unsigned gpr = (unsigned)ceil_div(s.OW, 4);
+    if (k == 3 && (stride == 1 || stride == 2) && (long long)n * s.OH * gpr < 0x7fffffffLL && c <= 65535) {
+        Dw3Args a;
+        a.s = s; a.groups_per_row = gpr; a.gpr_magic = dw_magic(gpr); a.oh_magic = dw_magic((unsigned)s.OH);
+        a.total_groups = 0;
+        dim3 g2((unsigned)splits, (unsigned)c);
+        if (stride == 1) dw3_bwd_weight_kernel<1><<<g2, 256, 0, current_stream()>>>(x, dy, a, splits, part);
+        else dw3_bwd_weight_kernel<2><<<g2, 256, 0, current_stream()>>>(x, dy, a, splits, part);
+    } else if (k == 3) dw_bwd_weight_kernel<3><<<grid, 256, 0, current_stream()>>>(x, dy, s, splits, part);
     else if (k == 5) dw_bwd_weight_kernel<5><<<grid, 256, 0, current_stream()>>>(x, dy, s, splits, part);
     else {
         dim3 g3((unsigned)c, (unsigned)splits, (unsigned)NT);
@@ -191,8 +473,20 @@ void bcnn_hip_depthwise_backward(const float* x, const float* w, const float* y,
     dw_weight_accumulate_kernel<<<ceil_div(c * NT, 256), 256, 0, current_stream()>>>(part, c, NT, splits, dw);
     KERNEL_CHECK();
     const long long total_i = (long long)n * c * h * wd;
-    dw_bwd_data_kernel<<<stream_grid((size_t)total_i, 256), 256, 0, current_stream()>>>(dy, w, dx, s,
-                                                                                     (unsigned)total_i);
+    const unsigned gpr_i = (unsigned)ceil_div(wd, 4);
+    const long long groups_i = (long long)n * c * h * gpr_i;
+    if (k == 3 && groups_i < 0x7fffffffLL) {
+        Dw3DxArgs a;
+        a.s = s; a.groups_per_row = gpr_i; a.gpr_magic = dw_magic(gpr_i); a.h_magic = dw_magic((unsigned)h);
+        a.total_groups = (unsigned)groups_i;
+        const unsigned blocks = (unsigned)((groups_i + 255) / 256);
+        if (stride == 1) dw3_bwd_data_kernel<1><<<blocks, 256, 0, current_stream()>>>(dy, w, dx, a);
+        else if (stride == 2) dw3_bwd_data_kernel<2><<<blocks, 256, 0, current_stream()>>>(dy, w, dx, a);
+        else dw3_bwd_data_kernel<0><<<blocks, 256, 0, current_stream()>>>(dy, w, dx, a);
+    } else {
+        dw_bwd_data_kernel<<<stream_grid((size_t)total_i, 256), 256, 0, current_stream()>>>(dy, w, dx, s,
+                                                                                         (unsigned)total_i);
+    }
     KERNEL_CHECK();
 }
 

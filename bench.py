@@ -59,6 +59,25 @@ def build_resnet18(net, A, classes=1000):
     net.cost("prob", "label", "cost", 1.0)
 
 
+def build_mobilenet_v1(net, A, classes=1000):
+    """MobileNet-v1 (1.0, 224): conv3x3/s2 stem, 13 depthwise-separable blocks, global average pool, fc. In
+    bcnn terms: the depthwise layer has no fused batch-norm, so each block is depthwise(+ReLU) -> stand-alone
+    batch-norm -> 1x1 convolution with fused batch-norm + ReLU (BASELINE configs[4])."""
+    net.conv(32, 3, 2, 1, 1, 1, A.ACT_RELU, "input", "conv0")
+    src = "conv0"
+    cfg = [(64, 1), (128, 2), (128, 1), (256, 2), (256, 1), (512, 2)] + [(512, 1)] * 5 + [(1024, 2), (1024, 1)]
+    for i, (width, stride) in enumerate(cfg, start=1):
+        dw, bn, pw = "b%d_dw" % i, "b%d_bn" % i, "b%d_pw" % i
+        net.depthwise(3, stride, 1, A.ACT_RELU, src, dw)
+        net.batchnorm(dw, bn)
+        net.conv(width, 1, 1, 0, 1, 1, A.ACT_RELU, bn, pw)
+        src = pw
+    net.avgpool(src, "gap")
+    net.fullc(classes, A.ACT_NONE, "gap", "fc")
+    net.softmax("fc", "prob")
+    net.cost("prob", "label", "cost", 1.0)
+
+
 # ---------------------------------------------------------------------------------------------------
 # CPU baseline: the unmodified reference on a bounded sample of the same workload
 # ---------------------------------------------------------------------------------------------------
@@ -79,7 +98,7 @@ def cpu_baseline(workload, sample_n):
             net.conv(64, 3, 1, 1, 1, 0, rb.ACT_NONE, "input", "conv1")
         else:
             net = rb.RefNet(mode=rb.MODE_TRAIN, w=224, h=224, c=3, n=sample_n)
-            build_resnet18(net, rb)
+            (build_mobilenet_v1 if workload == "mobilenet" else build_resnet18)(net, rb)
         net.compile()
         net.L.ref_set_threads(net.net, threads)
         net.data(0)[...] = rs.uniform(-1, 1, net.shape(0)).astype(np.float32)
@@ -110,8 +129,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="resnet18", choices=["resnet18", "conv3x3"])
-    ap.add_argument("--batch", type=int, default=128, help="images per GPU")
+    ap.add_argument("--workload", default="resnet18", choices=["resnet18", "conv3x3", "mobilenet"])
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU (default 128; 256 for mobilenet)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true",
                     help="data-parallel runs: one blocking all-reduce after backward instead of overlapped buckets")
@@ -133,20 +152,20 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world)  # "nccl" IS RCCL on ROCm
     dev = torch.device("cuda", local_rank)
-    n = args.batch
+    n = args.batch if args.batch else (256 if args.workload == "mobilenet" else 128)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)   # every rank owns different images
 
     # launch on an explicit stream of our own; HIP events are recorded on that same stream
     stream = L.bcnn_hip_stream_create()
     L.bcnn_hip_set_stream(stream)
 
-    if args.workload == "resnet18":
+    if args.workload in ("resnet18", "mobilenet"):
         import numpy as np
         net = capi.Net(mode=capi.MODE_TRAIN, w=224, h=224, c=3, n=n)
         import random
         # identical parameters on every rank: the builders draw from libc rand()
         C.CDLL(None).srand(7)
-        build_resnet18(net, capi)
+        (build_resnet18 if args.workload == "resnet18" else build_mobilenet_v1)(net, capi)
         net.compile()
         net.set_sgd(0.01, 0.9, 5e-4)
         net.set_data_parallel(rank, world)
@@ -201,8 +220,12 @@ def main():
                     dist.all_reduce(grads)      # ONE all-reduce of the flat weight/bias-gradient arena (xGMI)
                     torch.cuda.synchronize()
             net.update()
-        desc = ("ResNet-18 224x224 (BASELINE configs[2]), N=%d per GPU, fwd+bwd+SGD through bcnn_net C API; "
-                "CIFAR-example topology + ImageNet stem, fc-1000" % n)
+        if args.workload == "resnet18":
+            desc = ("ResNet-18 224x224 (BASELINE configs[2]), N=%d per GPU, fwd+bwd+SGD through bcnn_net C API; "
+                    "CIFAR-example topology + ImageNet stem, fc-1000" % n)
+        else:
+            desc = ("MobileNet-v1 224x224 (BASELINE configs[4]), N=%d per GPU, fwd+bwd+SGD through bcnn_net C API; "
+                    "depthwise 3x3 -> batch-norm -> 1x1 conv(+BN+ReLU) x13, fc-1000" % n)
         sample_n = 2
     else:
         c, h, w, f, k, s, p = 3, 224, 224, 64, 3, 1, 1

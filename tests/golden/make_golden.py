@@ -87,6 +87,13 @@ CASES = [
     rc.make_dw(82, 2, 3, 8, 8, 3, 1, 1, input_grad=False, name="dw_no_src_grad_skips_dw"),
     rc.make_dw(83, 2, 3, 8, 8, 5, 1, 2, bias_one=True, act=A.ACT_LRELU, name="dw_k5p2_bias_one"),
     rc.make_dw(84, 1, 2, 6, 6, 3, 1, 0, name="dw_k3p0"),
+    # shapes for the 4-outputs-per-thread 3x3 kernels: aligned / ragged rows, tiny planes, both strides
+    rc.make_dw(120, 2, 5, 13, 11, 3, 1, 1, act=A.ACT_RELU, name="dw_vec_13x11_s1"),
+    rc.make_dw(121, 2, 3, 14, 14, 3, 2, 1, act=A.ACT_RELU, name="dw_vec_14x14_s2"),
+    rc.make_dw(122, 3, 4, 7, 7, 3, 1, 1, name="dw_vec_7x7_s1"),
+    rc.make_dw(123, 2, 6, 12, 16, 3, 1, 1, bias_one=True, act=A.ACT_LRELU, name="dw_vec_12x16_s1_bias_one"),
+    rc.make_dw(124, 2, 3, 11, 9, 3, 2, 0, name="dw_vec_11x9_s2p0"),
+    rc.make_dw(125, 1, 2, 16, 16, 3, 3, 1, name="dw_k3s3_fallback"),
     # ---- raw kernels ---------------------------------------------------------------------------
     rc.make_im2col(90, 3, 8, 8, 3, 1, 1, name="im2col_k3s1p1"),
     rc.make_im2col(91, 2, 9, 7, 3, 2, 1, name="im2col_k3s2p1"),

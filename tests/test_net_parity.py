@@ -75,7 +75,9 @@ def depthwise_graph(net):
 GRAPHS = {
     "stack": (stack_graph, dict(w=16, h=12, c=3, n=3), False),
     "resnet_block": (resnet_block_graph, dict(w=16, h=16, c=3, n=4), True),
-    "lenet": (lenet_graph, dict(w=12, h=12, c=1, n=4), True),
+    # n = 16: bn3 normalises fc outputs over the batch only; with 4 samples per channel its statistics amplify
+    # 1e-7 rounding noise (the reference's own results move with heap alignment of its AVX loops) to ~1e-4
+    "lenet": (lenet_graph, dict(w=12, h=12, c=1, n=16), True),
     "mobilenet_unit": (depthwise_graph, dict(w=16, h=16, c=3, n=2), False),
 }
 
