@@ -26,7 +26,8 @@ hipStream_t current_stream();  // runtime.hip
 
 // Optional per-kernel-class timing with HIP events on the launch stream (off by default; bench.py turns it
 // on to report the roofline of the dominant kernel from inside the timed region). runtime.hip.
-enum KClass { K_CONV_FWD = 0, K_CONV_DW, K_CONV_DX, K_BN_FWD, K_BN_BWD, K_POOL, K_ELTWISE_ACT, K_GEMM, K_SGD, K_NUM };
+enum KClass { K_CONV_FWD = 0, K_CONV_DW, K_CONV_DX, K_BN_FWD, K_BN_BWD, K_POOL, K_ELTWISE_ACT, K_GEMM, K_SGD,
+              K_DEPTHWISE_FWD, K_DEPTHWISE_BWD, K_NUM };
 struct KTimer {
     int idx;
     KTimer(int cls, double flops, double bytes);

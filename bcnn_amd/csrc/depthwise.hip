@@ -422,6 +422,7 @@ void bcnn_hip_depthwise_forward(const float* x, const float* w, const float* bia
     DwShape s{n, c, h, wd, (h + 2 * pad - k) / stride + 1, (wd + 2 * pad - k) / stride + 1, k, stride, pad};
     const long long total = (long long)n * c * s.OH * s.OW;
     if (total <= 0) return;
+    KTimer kt(K_DEPTHWISE_FWD, 2.0 * (double)total * k * k, 4.0 * ((double)n * c * h * wd + (double)total));
     const int fused = act_is_cheap(act) ? act : BCNN_HIP_ACT_NONE;
     const unsigned gpr = (unsigned)ceil_div(s.OW, 4);
     const long long groups = (long long)n * c * s.OH * gpr;
@@ -447,6 +448,11 @@ void bcnn_hip_depthwise_backward(const float* x, const float* w, const float* y,
     const int ohow = s.OH * s.OW;
     const long long total_o = (long long)n * c * ohow;
     if (total_o <= 0) return;
+    // algorithmic bytes: activation backward (y, dy r/w), bias gradient (dy), dW (x, dy), dX (dy, dx r/w)
+    KTimer kt(K_DEPTHWISE_BWD, 4.0 * (double)total_o * k * k,
+              4.0 * (((act != BCNN_HIP_ACT_NONE) ? 3.0 : 0.0) * (double)total_o + (double)total_o +
+                     (dx ? ((double)n * c * h * wd + (double)total_o) + ((double)total_o + 2.0 * (double)n * c * h * wd)
+                         : 0.0)));
     bcnn_hip_activation_backward(y, dy, (size_t)total_o, act, nullptr, nullptr, ohow, c);
     bcnn_hip_grad_bias(dbias, dy, n, c, ohow);
     if (!dx) return;  // reference: dW and dX are both skipped when the source has no gradient (:318, :432)

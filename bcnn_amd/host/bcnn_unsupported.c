@@ -19,10 +19,6 @@ bcnn_status bcnn_resize_net(bcnn_net *net, int w, int h, int c, int need_realloc
     (void)w; (void)h; (void)c; (void)need_realloc;
     NOT_BUILT(net, "bcnn_resize_net");
 }
-bcnn_status bcnn_load_net(bcnn_net *net, const char *config_path, const char *model_path) {
-    (void)config_path; (void)model_path;
-    NOT_BUILT(net, "bcnn_load_net (INI graph loader)");
-}
 bcnn_status bcnn_set_data_loader(bcnn_net *net, bcnn_loader_type type, const char *a, const char *b, const char *c,
                                  const char *d) {
     (void)type; (void)a; (void)b; (void)c; (void)d;
