@@ -187,32 +187,27 @@ def main():
             # ~8 MB buckets and each bucket is all-reduced asynchronously on RCCL's stream, ordered after the
             # work queued so far on OUR stream (torch sees it as an ExternalStream). Nothing blocks the host;
             # update() is ordered behind the last bucket by work.wait() on the same stream.
+            from bcnn_amd.dp import BucketedAllReduce
             ext = torch.cuda.ExternalStream(stream, device=dev)
-            bucket_floats = max(1, (8 << 20) // 4)
-            pending = {"lo": gsize, "hi": gsize, "works": []}
-
-            def flush():
-                if pending["lo"] < pending["hi"]:
-                    with torch.cuda.stream(ext):
-                        pending["works"].append(dist.all_reduce(grads[pending["lo"]:pending["hi"]], async_op=True))
-                    pending["hi"] = pending["lo"]
-
-            def on_ready(first, count):
-                pending["lo"] = first
-                if pending["hi"] - pending["lo"] >= bucket_floats:
-                    flush()
-            net.set_gradient_ready_callback(on_ready)
+            bar = BucketedAllReduce(grads, (8 << 20) // 4, lambda: torch.cuda.stream(ext))
+            net.set_gradient_ready_callback(bar.on_ready)
 
         def step():
             net.forward()
-            if overlap:
-                pending["lo"] = pending["hi"] = gsize
+            if overlap and bar.failed is None:
+                bar.begin()
                 net.backward()
-                flush()
-                with torch.cuda.stream(ext):
-                    for w in pending["works"]:
-                        w.wait()            # stream-side wait: update() below is ordered after every bucket
-                pending["works"].clear()
+                left = bar.finish()         # stream-side waits: update() below is ordered after every bucket
+                if bar.failed is not None:
+                    # finish this step correctly ([0, left) has not been reduced); later steps use the blocking path
+                    print("bench.py: overlapped all-reduce failed (%r); falling back to the blocking path"
+                          % (bar.failed,), file=sys.stderr, flush=True)
+                    net.set_gradient_ready_callback(None)
+                    L.bcnn_hip_sync()
+                    torch.cuda.synchronize()
+                    if left > 0:
+                        dist.all_reduce(grads[:left])
+                    torch.cuda.synchronize()
             else:
                 net.backward()
                 if dp:

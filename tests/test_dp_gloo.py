@@ -90,3 +90,58 @@ def test_two_rank_dp_equals_single_process_on_global_batch():
     for name, a, b in (("w", wt, ewt), ("b", bias, ebias), ("dw carry", dw, edw), ("db carry", db, edb)):
         err = np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
         assert err < 1e-5, (name, err)
+
+
+# ---- the bucketed, overlapped all-reduce used by bench.py (bcnn_amd/dp.py) over gloo ----------------------------
+def _bucket_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bcnn_amd.dp import BucketedAllReduce
+    rs = np.random.RandomState(100 + rank)
+    size = 10_000
+    arena = torch.from_numpy(rs.uniform(-1, 1, size).astype(np.float32))
+    mine = arena.clone()
+    bar = BucketedAllReduce(arena, 2048)
+    # tail ranges as bcnn_backward reports them: uneven node sizes, last node first
+    cuts = [size, 9_990, 9_000, 8_999, 6_000, 5_000, 1_500, 100, 0]
+    result = {}
+    for step in range(2):                       # begin() must reset the state between steps
+        arena.copy_(mine)
+        bar.begin()
+        for hi, lo in zip(cuts[:-1], cuts[1:]):
+            bar.on_ready(lo, hi - lo)
+        left = bar.finish()
+        assert bar.failed is None and left == 0
+        covered = sorted(bar.buckets)
+        assert covered[0][0] == 0 and covered[-1][1] == size
+        assert all(a[1] == b[0] for a, b in zip(covered[:-1], covered[1:])), covered
+        assert 2 <= len(covered) <= 6 and all(h - l >= 2048 for l, h in covered[1:]), covered
+        result[step] = arena.clone()
+    # a range that does not continue the tail is recorded as a failure, never raised from the callback
+    bar.begin()
+    bar.on_ready(size - 10, 5)
+    assert bar.failed is not None
+    gathered = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    expect = sum(gathered)
+    if rank == 0:
+        q.put((float((result[0] - expect).abs().max()), float((result[1] - expect).abs().max())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_over_gloo_sums_every_range_exactly_once():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    e0, e1 = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert e0 < 1e-6 and e1 < 1e-6, (e0, e1)
