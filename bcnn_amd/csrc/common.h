@@ -22,7 +22,8 @@
 
 namespace bcnn_hip {
 
-hipStream_t current_stream();  // runtime.hip
+hipStream_t current_stream();
+void set_current_stream(hipStream_t st);  // runtime.hip
 
 // Optional per-kernel-class timing with HIP events on the launch stream (off by default; bench.py turns it
 // on to report the roofline of the dominant kernel from inside the timed region). runtime.hip.

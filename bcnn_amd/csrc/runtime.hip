@@ -9,6 +9,7 @@
 namespace bcnn_hip {
 static thread_local hipStream_t g_stream = nullptr;  // nullptr = null stream (PyTorch-ROCm default)
 hipStream_t current_stream() { return g_stream; }
+void set_current_stream(hipStream_t st) { g_stream = st; }  // internal: side-stream sections (conv.hip)
 
 // ---- per-kernel-class event timing ---------------------------------------------------------------
 struct KRecord { int cls; hipEvent_t a, b; double flops, bytes; };
