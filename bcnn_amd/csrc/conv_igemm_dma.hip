@@ -18,6 +18,8 @@
 // unit turns into 0.0 in LDS), and the row only moves the wave-uniform soffset by j * plane size.
 // At is the weight tensor re-packed per call to [tap][j (padded to 16)][m (padded to 128)] with zero
 // padding, so ragged M / J need no predicates (a zero A row cancels whatever finite B row was fetched).
+#include <type_traits>
+
 #include "conv_common.h"
 #include "lds_dma.h"
 
@@ -213,25 +215,31 @@ __global__ __launch_bounds__(256, ABL_LB) void conv_igemm_dma_kernel(const DmaAr
         if (p < ntiles) request_next(p);
     if (NS == 3 && ntiles > 1) dma_wait_n<LOADS_PER_TILE>(); else dma_wait();
     __syncthreads();
-    int cur = 0, fill = NS - 1;  // stage being multiplied / stage to refill
-    for (int it = 0; it < ntiles; ++it) {
+    // One K-tile: request tile it + NS - 1, multiply tile it, make tile it + 1 visible. CURT can carry the LDS
+    // stage as a compile-time constant (loop unrolled by the ring depth: fragment reads become base register +
+    // immediate offset, saving 5 VALU per tile) -- see DMA_UNROLL_STAGES below for why that is not the default.
+    int cur = 0, fill = NS - 1;  // run-time stage being multiplied / refilled (generic ring depth only)
+    auto tile_body = [&](int it, auto CURT) {
+        constexpr int CUR = decltype(CURT)::value;
+        const int c = CUR >= 0 ? CUR : cur;
+        const int f = CUR >= 0 ? (CUR + NS - 1) % NS : fill;
 #ifndef ABL_NODMA
-        if (it + NS - 1 < ntiles) request_next(fill);  // DMA in flight under the MFMAs
+        if (it + NS - 1 < ntiles) request_next(f);  // DMA in flight under the MFMAs
 #endif
         // fragments of k-step ks+1 are fetched from LDS before the MFMAs of k-step ks are issued
         float af[2][TM], bf[2][TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[0][i] = As[cur][lhi][(wm * TM + i) * 32 + l31];
+        for (int i = 0; i < TM; ++i) af[0][i] = As[c][lhi][(wm * TM + i) * 32 + l31];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bf[0][j] = Bs[cur][lhi][(wn * TN + j) * 32 + l31];
+        for (int j = 0; j < TN; ++j) bf[0][j] = Bs[c][lhi][(wn * TN + j) * 32 + l31];
 #pragma unroll
         for (int ks = 0; ks < BK / 2; ++ks) {
             const int fc = ks & 1, fn = fc ^ 1;
             if (ks + 1 < BK / 2) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) af[fn][i] = As[cur][2 * ks + 2 + lhi][(wm * TM + i) * 32 + l31];
+                for (int i = 0; i < TM; ++i) af[fn][i] = As[c][2 * ks + 2 + lhi][(wm * TM + i) * 32 + l31];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bf[fn][j] = Bs[cur][2 * ks + 2 + lhi][(wn * TN + j) * 32 + l31];
+                for (int j = 0; j < TN; ++j) bf[fn][j] = Bs[c][2 * ks + 2 + lhi][(wn * TN + j) * 32 + l31];
             }
             __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMAs (the scheduler sinks it otherwise)
 #pragma unroll
@@ -244,8 +252,23 @@ __global__ __launch_bounds__(256, ABL_LB) void conv_igemm_dma_kernel(const DmaAr
         if (NS == 3 && it + 2 < ntiles) dma_wait_n<LOADS_PER_TILE>(); else dma_wait();
         __syncthreads();
 #endif
-        cur = (cur + 1 == NS) ? 0 : cur + 1;
-        fill = (fill + 1 == NS) ? 0 : fill + 1;
+        if (CUR < 0) {
+            cur = (cur + 1 == NS) ? 0 : cur + 1;
+            fill = (fill + 1 == NS) ? 0 : fill + 1;
+        }
+    };
+#ifndef DMA_UNROLL_STAGES
+#define DMA_UNROLL_STAGES 0  // measured: the unrolled form is 1-5 % SLOWER on the ResNet shapes despite the fewer VALU
+#endif
+    if (NS == 2 && DMA_UNROLL_STAGES) {
+        int it = 0;
+        for (; it + 1 < ntiles; it += 2) {
+            tile_body(it, std::integral_constant<int, 0>{});
+            tile_body(it + 1, std::integral_constant<int, 1>{});
+        }
+        if (it < ntiles) tile_body(it, std::integral_constant<int, 0>{});
+    } else {
+        for (int it = 0; it < ntiles; ++it) tile_body(it, std::integral_constant<int, -1>{});
     }
 
     // ---- batch-norm statistics of this tile (fused: saves the separate read of the whole output) -----
@@ -297,7 +320,12 @@ __global__ __launch_bounds__(256, ABL_LB) void conv_igemm_dma_kernel(const DmaAr
     }
 
     // ---- epilogue ------------------------------------------------------------------------------------
+    // 32-bit element offsets against the output base (tensors are < 2 GiB here), the 16 rows of an
+    // accumulator at compile-time multiples of the wave-uniform row stride, and no per-value predicate or
+    // bias / activation code when the tile is full and the store is plain (dX, and the raw forward that
+    // feeds a batch-norm): epilogue VALU competes with the other resident waves' MFMAs.
     const unsigned o_row_stride = fwd ? (unsigned)s.OHOW : (s.pointwise ? (unsigned)s.OHOW : (unsigned)s.HW);
+    const bool plain = !fwd || (!a.add_bias && a.act == BCNN_HIP_ACT_NONE);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         unsigned pbx, ob;
@@ -308,20 +336,24 @@ __global__ __launch_bounds__(256, ABL_LB) void conv_igemm_dma_kernel(const DmaAr
             float v[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r];
+            const int row0 = (wm * TM + i) * 32 + 4 * lhi;          // row of accumulator register 0, tile-relative
+            const bool full = m0 + (wm * TM + i) * 32 + 32 <= a.M;  // wave-uniform
+            const unsigned off0 = ob + (unsigned)(m0 + row0) * o_row_stride;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + (wm * TM + i) * 32 + mfma_row(r, lane);
-                if (m >= a.M) continue;
+                constexpr int kRowOf[16] = {0, 1, 2, 3, 8, 9, 10, 11, 16, 17, 18, 19, 24, 25, 26, 27};
+                const int mr = kRowOf[r];
+                if (!full && m0 + row0 + mr >= a.M) continue;
                 float o = v[r];
-                if (fwd) {
-                    const float b = s_bias[m - m0];
+                if (!plain) {
+                    const float b = s_bias[row0 + mr];
                     if (b != 0.0f) o += b;
-                    if (a.act != BCNN_HIP_ACT_NONE) o = act_fwd_cheap(o, a.act, s_slope[m - m0]);
+                    if (a.act != BCNN_HIP_ACT_NONE) o = act_fwd_cheap(o, a.act, s_slope[row0 + mr]);
                 }
 #ifdef ABL_NOSTORE
                 if (o == 123.456f)
 #endif
-                a.out[(size_t)ob + (size_t)m * o_row_stride] = o;
+                a.out[off0 + (unsigned)mr * o_row_stride] = o;
             }
         }
     }
