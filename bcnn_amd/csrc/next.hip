@@ -28,6 +28,70 @@ __global__ __launch_bounds__(256) void add_rowvec_kernel(float* __restrict__ y, 
     for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gs) y[t] += v[t % (unsigned)cols];
 }
 
+// eltwise node, same-shape path, one pass each way (16-byte accesses on the aligned body)
+__global__ __launch_bounds__(256) void eltwise_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                          float* __restrict__ y, size_t n, size_t b_count, int act) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 4 <= n) {
+            float4 v = *reinterpret_cast<const float4*>(a + i);
+            if (i + 4 <= b_count) {
+                const float4 w = *reinterpret_cast<const float4*>(b + i);
+                v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+            } else if (i < b_count) {
+                if (i < b_count) v.x += b[i];
+                if (i + 1 < b_count) v.y += b[i + 1];
+                if (i + 2 < b_count) v.z += b[i + 2];
+            }
+            v.x = act_fwd_cheap(v.x, act, 0.f); v.y = act_fwd_cheap(v.y, act, 0.f);
+            v.z = act_fwd_cheap(v.z, act, 0.f); v.w = act_fwd_cheap(v.w, act, 0.f);
+            *reinterpret_cast<float4*>(y + i) = v;
+        } else {
+            for (size_t k = i; k < n; ++k) y[k] = act_fwd_cheap(a[k] + (k < b_count ? b[k] : 0.f), act, 0.f);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void eltwise_bwd_kernel(const float* __restrict__ y, float* __restrict__ dy,
+                                                          float* __restrict__ da, float* __restrict__ db, size_t n,
+                                                          size_t b_count, int act) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 4 <= n) {
+            float4 g = *reinterpret_cast<const float4*>(dy + i);
+            if (act != BCNN_HIP_ACT_NONE) {
+                const float4 yv = *reinterpret_cast<const float4*>(y + i);
+                g.x *= act_bwd_cheap(yv.x, act, 0.f); g.y *= act_bwd_cheap(yv.y, act, 0.f);
+                g.z *= act_bwd_cheap(yv.z, act, 0.f); g.w *= act_bwd_cheap(yv.w, act, 0.f);
+                *reinterpret_cast<float4*>(dy + i) = g;
+            }
+            if (da) {
+                float4 t = *reinterpret_cast<const float4*>(da + i);
+                t.x += g.x; t.y += g.y; t.z += g.z; t.w += g.w;
+                *reinterpret_cast<float4*>(da + i) = t;
+            }
+            if (db && i < b_count) {
+                if (i + 4 <= b_count) {
+                    float4 t = *reinterpret_cast<const float4*>(db + i);
+                    t.x += g.x; t.y += g.y; t.z += g.z; t.w += g.w;
+                    *reinterpret_cast<float4*>(db + i) = t;
+                } else {
+                    db[i] += g.x;
+                    if (i + 1 < b_count) db[i + 1] += g.y;
+                    if (i + 2 < b_count) db[i + 2] += g.z;
+                }
+            }
+        } else {
+            for (size_t k = i; k < n; ++k) {
+                float gk = dy[k];
+                if (act != BCNN_HIP_ACT_NONE) { gk *= act_bwd_cheap(y[k], act, 0.f); dy[k] = gk; }
+                if (da) da[k] += gk;
+                if (db && k < b_count) db[k] += gk;
+            }
+        }
+    }
+}
+
 // one wave per (n, spatial position): max, log-sum-exp, exp(x - lse); exp/log in double like the reference
 // (src/layers/bcnn_softmax_layer.c:95-123). The reference adds the exponentials sequentially in float; here
 // the 64 lane partials are accumulated in double and rounded once, which differs from it by a few float ulps.
@@ -79,6 +143,32 @@ void bcnn_hip_softmax_forward(const float* x, float* y, int n, int c, int hw) {
     const long long total = (long long)n * hw;
     if (total <= 0) return;
     softmax_kernel<<<stream_grid((size_t)total * 64, 256), 256, 0, current_stream()>>>(x, y, c, hw, (unsigned)total);
+    KERNEL_CHECK();
+}
+
+static bool aligned16(const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+void bcnn_hip_eltwise_forward(const float* a, const float* b, float* y, size_t n, size_t b_count, int act) {
+    if (!n) return;
+    if (!act_is_cheap(act) || !aligned16(a) || !aligned16(b) || !aligned16(y)) {  // three-pass form of the reference
+        bcnn_hip_copy_f32(n, a, y);
+        bcnn_hip_axpy(b_count, 1.0f, b, y);
+        bcnn_hip_activation_forward(y, n, act, nullptr, 1, 1);
+        return;
+    }
+    eltwise_fwd_kernel<<<stream_grid(n / 4 + 1, 256), 256, 0, current_stream()>>>(a, b, y, n, b_count, act);
+    KERNEL_CHECK();
+}
+
+void bcnn_hip_eltwise_backward(const float* y, float* dy, float* da, float* db, size_t n, size_t b_count, int act) {
+    if (!n) return;
+    if (!act_bwd_is_cheap(act) || !aligned16(y) || !aligned16(dy) || !aligned16(da) || !aligned16(db)) {
+        bcnn_hip_activation_backward(y, dy, n, act, nullptr, nullptr, 1, 1);
+        if (da) bcnn_hip_axpy(n, 1.0f, dy, da);
+        if (db) bcnn_hip_axpy(b_count, 1.0f, dy, db);
+        return;
+    }
+    eltwise_bwd_kernel<<<stream_grid(n / 4 + 1, 256), 256, 0, current_stream()>>>(y, dy, da, db, n, b_count, act);
     KERNEL_CHECK();
 }
 

@@ -68,10 +68,13 @@ void bcnn_forward_eltwise_layer(bcnn_net *net, bcnn_node *node) {
     bcnn_eltwise_param *p = (bcnn_eltwise_param *)node->param;
     bcnn_tensor *a = &net->tensors[node->src[0]], *b = &net->tensors[node->src[1]], *y = &net->tensors[node->dst[0]];
     const size_t sz = (size_t)bcnn_tensor_size(y);
+    if (p->stride[0] == 1 && p->stride[1] == 1) { /* one fused pass; the second operand reaches image 0 only (quirk 5) */
+        bcnn_hip_eltwise_forward(a->data_gpu, b->data_gpu, y->data_gpu, sz, (size_t)p->min_dim[0] * y->h * y->w,
+                                 (int)p->activation);
+        return;
+    }
     bcnn_hip_copy_f32(sz, a->data_gpu, y->data_gpu);
-    if (p->stride[0] == 1 && p->stride[1] == 1) {
-        bcnn_hip_axpy((size_t)p->min_dim[0] * y->h * y->w, 1.0f, b->data_gpu, y->data_gpu); /* image 0 only */
-    } else {
+    {
         bcnn_hip_axpy_strided(a->n, 1.0f, b->data_gpu, y->data_gpu, p->stride[0], p->stride[1], b->c, b->h, b->w, y->c,
                               y->h, y->w, p->min_dim[0], p->min_dim[1], p->min_dim[2]);
     }
@@ -82,12 +85,15 @@ void bcnn_backward_eltwise_layer(bcnn_net *net, bcnn_node *node) {
     bcnn_eltwise_param *p = (bcnn_eltwise_param *)node->param;
     bcnn_tensor *a = &net->tensors[node->src[0]], *b = &net->tensors[node->src[1]], *y = &net->tensors[node->dst[0]];
     const size_t sz = (size_t)bcnn_tensor_size(y);
+    if (p->stride[0] == 1 && p->stride[1] == 1) {
+        bcnn_hip_eltwise_backward(y->data_gpu, y->grad_data_gpu, a->grad_data_gpu, b->grad_data_gpu, sz,
+                                  (size_t)p->min_dim[0] * y->h * y->w, (int)p->activation);
+        return;
+    }
     bcnn_hip_activation_backward(y->data_gpu, y->grad_data_gpu, sz, (int)p->activation, NULL, NULL, y->w * y->h, y->c);
     if (a->grad_data_gpu) bcnn_hip_axpy(sz, 1.0f, y->grad_data_gpu, a->grad_data_gpu);
     if (!b->grad_data_gpu) return;
-    if (p->stride[0] == 1 && p->stride[1] == 1) {
-        bcnn_hip_axpy((size_t)p->min_dim[0] * y->h * y->w, 1.0f, y->grad_data_gpu, b->grad_data_gpu);
-    } else {
+    {
         bcnn_hip_axpy_strided(a->n, 1.0f, y->grad_data_gpu, b->grad_data_gpu, p->stride[1], p->stride[0], y->c, y->h,
                               y->w, b->c, b->h, b->w, p->min_dim[0], p->min_dim[1], p->min_dim[2]);
     }

@@ -237,7 +237,16 @@ void bcnn_hip_sgd_update_chunks(const bcnn_hip_sgd_chunk *chunks_d, int num_chun
  *                  bcnn_fc_layer.c:170-172; plain axpy, no 0/1 quirk).
  *   softmax      : bcnn_forward_softmax_layer_cpu (bcnn_softmax_layer.c:88-155), log-sum-exp form,
  *                  over c for every (n, spatial position).
+ *   eltwise_*    : the same-shape path of the eltwise node in one pass each way
+ *                  (bcnn_eltwise_layer.c:112-121 copy + axpy + activation; :136-147 activation backward +
+ *                  two axpys): y = act(a + b) where b only covers the first b_count elements (the
+ *                  reference's stride-1 path adds the second operand to IMAGE 0 only -- quirk 5);
+ *                  backward: g = dy * act'(y) stored over dy, da += g, db[i] += g[i] for i < b_count.
+ *                  da_d / db_d may be NULL.
  * ------------------------------------------------------------------------------------------- */
+void bcnn_hip_eltwise_forward(const float *a_d, const float *b_d, float *y_d, size_t n, size_t b_count, int act);
+void bcnn_hip_eltwise_backward(const float *y_d, float *dy_d, float *da_d, float *db_d, size_t n, size_t b_count,
+                               int act);
 void bcnn_hip_axpy_strided(int num_batches, float a, const float *x_d, float *y_d, int stride_y,
                            int stride_x, int x_c, int x_h, int x_w, int y_c, int y_h, int y_w, int min_c,
                            int min_h, int min_w);
