@@ -312,7 +312,7 @@ def main():
                                    "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None,
                                    "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} for k, v in prof.items()},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported by the single-GPU run only
             out["cpu_baseline"] = cpu_baseline(args.workload, sample_n)
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
