@@ -60,11 +60,17 @@ struct DmaArgs {
 #define ABL_LB 1
 #endif
 template <int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(256, ABL_LB) void conv_igemm_dma_kernel(const DmaArgs a) {
+__global__ __launch_bounds__(64 * WM * WN, ABL_LB) void conv_igemm_dma_kernel(const DmaArgs a) {
     constexpr int BK = 16;
+    constexpr int NW = WM * WN;         // waves per workgroup (4, or 2 for the 64 x 32 tile)
+    constexpr int NT = 64 * NW;         // threads
+    constexpr int RPW = BK / NW;        // K rows each wave stages per tile
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int AH = BM / 64, BH = BN / 64;
-    static_assert(WM * WN == 4, "4 waves");
+    // BN == 32: a B row is only half a DMA slab, so one DMA instruction fills TWO consecutive K rows (lanes
+    // 0-31 row j, lanes 32-63 row j + 1: the second row's plane offset rides in the lane offset)
+    constexpr bool HALF = (BN == 32);
+    constexpr int AH = BM / 64, BH = HALF ? 1 : BN / 64;
+    static_assert((NW == 4 || NW == 2) && BM % 64 == 0 && (BN % 64 == 0 || BN == 32), "tile");
     // one block of LDS: As[NS][BK][BM] | Bs[NS][BK][BN]; after the K loop the same bytes hold one 32x32
     // transposition pad per wave for the fused statistics
 #ifndef DMA_NSTAGE
@@ -75,7 +81,7 @@ __global__ __launch_bounds__(256, ABL_LB) void conv_igemm_dma_kernel(const DmaAr
     // resident workgroups per CU) -- with 8 waves per SIMD the DMA latency is already hidden.
     constexpr int NS = DMA_NSTAGE;
     constexpr int SMEM = NS * BK * (BM + BN);
-    static_assert(SMEM >= 4 * 1024, "statistics pads");
+    static_assert(SMEM >= NW * 1024, "statistics pads");
     __shared__ float smem[SMEM];
     float (*As)[BK][BM] = reinterpret_cast<float (*)[BK][BM]>(smem);
     float (*Bs)[BK][BN] = reinterpret_cast<float (*)[BK][BN]>(smem + NS * BK * BM);
@@ -146,7 +152,8 @@ __global__ __launch_bounds__(256, ABL_LB) void conv_igemm_dma_kernel(const DmaAr
 #pragma unroll
     for (int h = 0; h < BH; ++h) {
         unsigned ob;
-        decode(p0 + h * 64 + lane, pb[h], cy[h], cx[h], ob);
+        decode(p0 + (HALF ? (lane & 31) : h * 64 + lane), pb[h], cy[h], cx[h], ob);
+        if (HALF) pb[h] += (unsigned)(lane >> 5) * (unsigned)a.b_major_stride;  // upper half: the next K row
     }
     unsigned voff[BH];
     const int c_nkx = ci.nkx, c_sgn = ci.sgn;
@@ -170,17 +177,20 @@ __global__ __launch_bounds__(256, ABL_LB) void conv_igemm_dma_kernel(const DmaAr
     const int ntiles = ci.ntaps * JB;
     const unsigned a_tile0 = ((unsigned)(g * a.kk2 + ci.tap0) * (unsigned)a.Jpad) * (unsigned)a.Mpad + (unsigned)m0;
 
-    // wave `wid` stages rows 4*wid .. 4*wid+3 of both tiles
+    // wave `wid` stages rows RPW*wid .. RPW*wid + RPW - 1 of both tiles
     auto stage = [&](int t, int jb, int buf) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 4 * wid + r;
+        for (int r = 0; r < RPW; ++r) {
+            const int row = RPW * wid + r;
             const int j = jb * BK + row;
-            const int jc = j < a.J ? j : a.J - 1;  // padded rows meet a zero A row: fetch any legal row
-            const unsigned sb = (unsigned)jc * (unsigned)a.b_major_stride * 4u;
             const unsigned sa = (a_tile0 + (unsigned)(t * a.Jpad + j) * (unsigned)a.Mpad) * 4u;
+            if (!HALF || (r & 1) == 0) {  // HALF: rows (row, row + 1) travel together (J is even: launch precondition)
+                const int jc = j < a.J ? j : a.J - (HALF ? 2 : 1);  // padded rows meet a zero A row: any legal row(s)
+                const unsigned sb = (unsigned)jc * (unsigned)a.b_major_stride * 4u;
 #pragma unroll
-            for (int h = 0; h < BH; ++h) dma_row(rs_b, lds_b0 + (unsigned)(((buf * BK + row) * BN + h * 64) * 4), voff[h], sb);
+                for (int h = 0; h < BH; ++h)
+                    dma_row(rs_b, lds_b0 + (unsigned)(((buf * BK + row) * BN + h * 64) * 4), voff[h], sb);
+            }
 #pragma unroll
             for (int h = 0; h < AH; ++h) dma_row(rs_a, lds_a0 + (unsigned)(((buf * BK + row) * BM + h * 64) * 4), a_voff[h], sa);
         }
@@ -198,7 +208,7 @@ __global__ __launch_bounds__(256, ABL_LB) void conv_igemm_dma_kernel(const DmaAr
     // ---- K loop: ring of NS LDS stages. Tile it + NS - 1 is requested before the MFMAs of tile it; at the
     // end of the iteration only tile it + 1 has to have landed, i.e. the wave waits until at most the loads
     // of the NS - 2 younger tiles are still in flight (vmcnt is in-order) and then meets the barrier.
-    constexpr int LOADS_PER_TILE = 4 * (AH + BH);  // DMA instructions one wave issues per tile
+    constexpr int LOADS_PER_TILE = RPW * AH + (HALF ? RPW / 2 : RPW * BH);  // DMA instructions one wave issues per tile
     int t_next = 0, jb_next = 0, issued = 0;       // (tap, major block) of the next tile to request
     auto request_next = [&](int buf) {
         if (issued > 0 && ++jb_next == JB) {
@@ -226,6 +236,9 @@ __global__ __launch_bounds__(256, ABL_LB) void conv_igemm_dma_kernel(const DmaAr
 #ifndef ABL_NODMA
         if (it + NS - 1 < ntiles) request_next(f);  // DMA in flight under the MFMAs
 #endif
+#ifdef ABL_SETPRIO
+        __builtin_amdgcn_s_setprio(ABL_SETPRIO);
+#endif
         // fragments of k-step ks+1 are fetched from LDS before the MFMAs of k-step ks are issued
         float af[2][TM], bf[2][TN];
 #pragma unroll
@@ -248,6 +261,9 @@ __global__ __launch_bounds__(256, ABL_LB) void conv_igemm_dma_kernel(const DmaAr
                 for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(af[fc][i], bf[fc][j], acc[i][j]);
             __builtin_amdgcn_sched_barrier(0);
         }
+#ifdef ABL_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
 #ifndef ABL_NOBAR
         if (NS == 3 && it + 2 < ntiles) dma_wait_n<LOADS_PER_TILE>(); else dma_wait();
         __syncthreads();
@@ -426,14 +442,16 @@ static bool dma_supported(const ConvShape& s, int M, int J, size_t b_elems) {
 //   128ch 28x28 3x3      82/85    82/85    91/93    92/95   98/100
 //   256ch 14x14 3x3      89/91    87/90    90/91    89/91   99/100
 //   512ch  7x7  3x3      69/71    65/66    84/86    85/87   88/90
+// A 64x32 tile (two waves, B rows as half slabs: config 5) quantises better still on the 7x7 layers but is
+// 5-15 % slower everywhere (85/88, 90/91, 89/90, 72/84): the A tile is then re-fetched for half as many columns.
 // The 64x64 tile (four waves of one 32x32 accumulator) wins everywhere: it keeps 8+ waves per SIMD resident
 // (16 accumulator registers, 16 KB of LDS) so DMA latency, barriers and epilogues of one workgroup hide under
 // the MFMAs of the others, and N*OH*OW = 2^k * 49 quantises onto the 256 CUs far better in small tiles (a
 // 128x128 grid lands on 3.06 / 1.53 workgroups per CU: a quarter of the chip idles in the last round).
 static int pick_dma_tile(const DmaArgs& a, int max_cols) {
     static const char* forced = getenv("BCNN_HIP_IGEMM_TILE");  // experiments: 0..4
-    if (forced && forced[0] >= '0' && forced[0] <= '4') return forced[0] - '0';
-    (void)a; (void)max_cols;
+    if (forced && forced[0] >= '0' && forced[0] <= '5' && (forced[0] != '5' || (a.J & 1) == 0)) return forced[0] - '0';
+    (void)max_cols;
     return 4;
 }
 
@@ -443,7 +461,7 @@ static void launch_dma_cfg(DmaArgs& a, int max_cols) {
     a.mtiles = ceil_div(a.M, BM);
     a.stats_splits = ceil_div(max_cols, BN);
     dim3 grid((unsigned)(a.mtiles * a.stats_splits), (unsigned)a.s.groups, (unsigned)a.nclass);
-    conv_igemm_dma_kernel<WM, WN, TM, TN><<<grid, 256, 0, current_stream()>>>(a);
+    conv_igemm_dma_kernel<WM, WN, TM, TN><<<grid, 64 * WM * WN, 0, current_stream()>>>(a);
     KERNEL_CHECK();
 }
 
@@ -453,6 +471,7 @@ static void launch_dma(DmaArgs& a, int max_cols) {
         case 1: launch_dma_cfg<1, 4, 2, 2>(a, max_cols); break;  //  64 x 256
         case 2: launch_dma_cfg<2, 2, 2, 1>(a, max_cols); break;  // 128 x  64
         case 3: launch_dma_cfg<1, 4, 2, 1>(a, max_cols); break;  //  64 x 128
+        case 5: launch_dma_cfg<2, 1, 1, 1>(a, max_cols); break;  //  64 x  32 (two waves, half-slab B rows)
         default: launch_dma_cfg<2, 2, 1, 1>(a, max_cols); break; //  64 x  64
     }
 }
