@@ -40,6 +40,47 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
     }
 }
 
+// Stride-2 windows of size 2 or 3 (the ResNet / LeNet pools): one thread per TWO consecutive outputs of a row.
+// Their windows span source columns 4q .. 4q+3 (+1 for size 3): one aligned 16-byte load (+ one scalar) per
+// window row instead of 2 x SIZE scalar loads, one pair of divisions per two outputs. Scan order, strict
+// `>` and the flat int32 index are those of the generic kernel (bit-exact).
+template <int SIZE>
+__global__ __launch_bounds__(256) void maxpool_fwd_s2_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                             int* __restrict__ idx, int H, int W, int OH, int OW,
+                                                             unsigned total_pairs) {
+    const unsigned t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= total_pairs) return;
+    const unsigned ppr = (unsigned)(OW + 1) >> 1;  // output pairs per row
+    const unsigned rowid = t / ppr, q = t - rowid * ppr;
+    const unsigned plane = rowid / (unsigned)OH, i = rowid - plane * (unsigned)OH;
+    const int base = (int)plane * H * W;
+    const int w0 = (int)q * 4;  // first source column of the pair (W % 4 == 0 => the 16-byte load is in range)
+    float best[2] = {-FLT_MAX, -FLT_MAX};
+    int bi[2] = {-1, -1};
+#pragma unroll
+    for (int r = 0; r < SIZE; ++r) {
+        const int hh = (int)i * 2 + r;
+        if (hh >= H) continue;  // bottom padding: every tap of the row reads as -FLT_MAX and never wins
+        const int rb = base + hh * W + w0;
+        const float4 v4 = *reinterpret_cast<const float4*>(x + rb);
+        const float v[5] = {v4.x, v4.y, v4.z, v4.w, (SIZE == 3 && w0 + 4 < W) ? x[rb + 4] : -FLT_MAX};
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int c = 0; c < SIZE; ++c) {
+                const float val = v[2 * o + c];
+                if (val > best[o]) { best[o] = val; bi[o] = rb + 2 * o + c; }
+            }
+    }
+    const unsigned out = rowid * (unsigned)OW + q * 2;
+    y[out] = best[0];
+    idx[out] = bi[0];
+    if ((int)(q * 2 + 1) < OW) {
+        y[out + 1] = best[1];
+        idx[out + 1] = bi[1];
+    }
+}
+
 // Gather form of `dx[idx[o]] += dy[o]`: one thread per SOURCE element visits the (at most
 // ceil(size/stride)^2) outputs whose window covers it, in ascending output order, and adds those
 // that selected it. Same per-element addition order as the reference's ascending-o loop, no atomics.
@@ -133,6 +174,16 @@ void bcnn_hip_maxpool_forward(const float* x, float* y, int* indexes, int n, int
                               int out_w, int size, int stride) {
     const long long total = (long long)n * c * out_h * out_w;
     if (!total) return;
+    // two outputs per thread need both windows inside the 16-byte load: out_w = ceil(w / 2) covers it when w % 4 == 0
+    if (stride == 2 && (size == 2 || size == 3) && (w & 3) == 0 && out_w * 2 <= w + 1 &&
+        (long long)n * c * h * w < 0x7fffffffLL && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+        const long long pairs = (long long)n * c * out_h * ((out_w + 1) / 2);
+        const unsigned blocks = (unsigned)((pairs + 255) / 256);
+        if (size == 2) maxpool_fwd_s2_kernel<2><<<blocks, 256, 0, current_stream()>>>(x, y, indexes, h, w, out_h, out_w, (unsigned)pairs);
+        else maxpool_fwd_s2_kernel<3><<<blocks, 256, 0, current_stream()>>>(x, y, indexes, h, w, out_h, out_w, (unsigned)pairs);
+        KERNEL_CHECK();
+        return;
+    }
     maxpool_fwd_kernel<<<stream_grid((size_t)total, 256), 256, 0, current_stream()>>>(
         x, y, indexes, n * c, h, w, out_h, out_w, size, stride, (unsigned)total);
     KERNEL_CHECK();

@@ -75,6 +75,11 @@ CASES = [
     rc.make_maxpool(44, 2, 4, 8, 8, 3, 1, A.PADDING_SAME, ties=True, name="maxpool_3x3s1_ties_nan"),
     rc.make_maxpool(45, 1, 2, 5, 5, 2, 1, A.PADDING_VALID, ties=True, name="maxpool_2x2s1_ties"),
     rc.make_maxpool(46, 2, 8, 14, 14, 3, 2, A.PADDING_SAME, name="maxpool_resnet_stem_like"),
+    # rows of 4k columns: the two-outputs-per-thread stride-2 kernels (16-byte loads), ties / NaN / -FLT_MAX included
+    rc.make_maxpool(130, 2, 3, 12, 16, 3, 2, A.PADDING_SAME, ties=True, name="maxpool_vec_3x3s2_same_12x16_ties"),
+    rc.make_maxpool(131, 2, 3, 11, 16, 3, 2, A.PADDING_VALID, name="maxpool_vec_3x3s2_valid_11x16"),
+    rc.make_maxpool(132, 2, 2, 9, 12, 3, 2, A.PADDING_CAFFE, ties=True, name="maxpool_vec_3x3s2_caffe_9x12_ties"),
+    rc.make_maxpool(133, 3, 2, 10, 20, 2, 2, A.PADDING_SAME, ties=True, name="maxpool_vec_2x2s2_10x20_ties"),
     # ---- avgpool -------------------------------------------------------------------------------
     rc.make_avgpool(50, 2, 3, 7, 7, name="avgpool_7x7"),
     rc.make_avgpool(51, 3, 5, 1, 1, name="avgpool_1x1"),
