@@ -1,0 +1,70 @@
+"""Edge cases of the C-ABI that no fixture can carry: empty batches (every entry point must return without
+touching memory) and a convolution whose tensors are large enough to use every kernel tier of the dispatcher
+against a plain fp32 restatement in torch (cross-check independent of the oracle)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_empty_batch_is_a_no_op():
+    import torch
+    from bcnn_amd import ops
+    dev = "cuda:0"
+    x = torch.empty((0, 4, 8, 8), device=dev)
+    wt = torch.ones((6, 4, 3, 3), device=dev)
+    b = torch.zeros(6, device=dev)
+    y = torch.empty((0, 6, 8, 8), device=dev)
+    dy = torch.empty_like(y)
+    dx = torch.empty_like(x)
+    dw = torch.full_like(wt, 2.0)
+    db = torch.full_like(b, 3.0)
+    ws = torch.zeros(16, device=dev)
+    ops.conv_forward(x, wt, b, y, 3, 1, 1, 1, 2)
+    ops.conv_backward(x, wt, y, dy, dx, dw, db, 3, 1, 1, 1, 2, ws)
+    idx = torch.empty((0, 4, 4, 4), dtype=torch.int32, device=dev)
+    p = torch.empty((0, 4, 4, 4), device=dev)
+    ops.maxpool_forward(x, p, idx, 2, 2)
+    ops.maxpool_backward(p, idx, dx, 2, 2)
+    ops.depthwise_forward(x, torch.ones((4, 3, 3), device=dev), torch.zeros(4, device=dev), torch.empty_like(x), 3, 1, 1, 2)
+    torch.cuda.synchronize()
+    assert float(dw.min()) == 2.0 and float(db.max()) == 3.0  # gradients untouched
+
+
+@pytest.mark.parametrize("shape", [
+    dict(n=5, c=72, h=19, w=17, f=136, k=3, s=1, p=1),    # ragged M / J / columns on the LDS-DMA GEMMs
+    dict(n=3, c=96, h=15, w=15, f=64, k=3, s=2, p=1),     # stride-parity classes of unequal size
+    dict(n=4, c=64, h=9, w=9, f=192, k=1, s=1, p=0),      # pointwise
+])
+def test_conv_against_torch_fp32(shape):
+    import torch
+    import torch.nn.functional as F
+    from bcnn_amd import ops
+    dev = "cuda:0"
+    n, c, h, w, f, k, s, p = (shape[q] for q in "nchwfksp")
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.rand((n, c, h, w), device=dev, generator=g) * 2 - 1
+    wt = (torch.rand((f, c, k, k), device=dev, generator=g) * 2 - 1) * (3.0 / (c * k * k)) ** 0.5
+    b = torch.rand(f, device=dev, generator=g) - 0.5
+    oh, ow = ops.conv_out_hw(h, w, k, s, p)
+    y = torch.empty((n, f, oh, ow), device=dev)
+    ops.conv_forward(x, wt, b, y, k, s, p, 1, 0)
+    xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    torch.backends.cudnn.allow_tf32 = False
+    yr = F.conv2d(xr.double(), wr.double(), b.double(), stride=s, padding=p)
+    dy = (torch.rand(y.shape, device=dev, generator=g) * 2 - 1) * 0.1
+    yr.backward(dy.double())
+    dx = torch.empty_like(x)
+    dw = torch.zeros_like(wt)
+    db = torch.zeros_like(b)
+    ws = torch.zeros(max(1, ops.conv_workspace_size(n, c, h, w, f, k, s, p, 1)), device=dev)
+    dyc = dy.clone()
+    ops.conv_backward(x, wt, y, dyc, dx, dw, db, k, s, p, 1, 0, ws)
+    torch.cuda.synchronize()
+
+    def rel(a, r):
+        return float((a.double() - r).abs().max() / r.abs().max())
+    assert rel(y, yr.detach()) < 1e-5, rel(y, yr.detach())
+    assert rel(dx, xr.grad.double()) < 1e-5
+    assert rel(dw, wr.grad.double()) < 1e-5
+    assert rel(db, dy.double().sum((0, 2, 3))) < 1e-5
