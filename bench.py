@@ -4,8 +4,11 @@
 Contract: `python bench.py --gpus N --steps K --warmup W` (for N > 1 launched under
 torch.distributed.run, one rank per GPU, RCCL all-reduce of the weight-gradient arena after backward).
 Rank 0 prints ONE JSON line: whole-job throughput, the roofline of the dominant kernel class (durations
-measured live with HIP events on the launch stream, inside the timed region) and a CPU baseline
-(the unmodified reference, oracle/_ref, timed on this host on a bounded sample).
+measured live with HIP events on the launch stream, inside the timed region: every 4th timed step carries the
+per-class event timers -- `profiled_steps` in the output -- because ~200 event records per step cost 4 % of a
+ResNet step; BENCH_PROFILE_EVERY=1 times every step) and a CPU baseline (the unmodified reference,
+oracle/_ref, timed on this host on a bounded sample; single-GPU runs only).
+Data-parallel runs overlap the gradient all-reduce with backward (bcnn_amd/dp.py); --no-overlap disables it.
 
 Workloads (BASELINE.json configs):
   resnet18  configs[2]/[3] (the configuration the metric is quoted on): ResNet-18, 224x224, N=128 per GPU,
@@ -14,6 +17,7 @@ Workloads (BASELINE.json configs):
             projections) behind an ImageNet stem (7x7 s2 p3 + maxpool 3/2 SAME; the reference ships only
             the CIFAR stem), avgpool, fc-1000, softmax, cost. A step = bcnn_forward + bcnn_backward
             (+ all-reduce) + bcnn_update (SGD), i.e. one full training step on synthetic data.
+  mobilenet configs[4]: MobileNet-v1 224x224, N=256 per GPU (depthwise 3x3 -> batch-norm -> 1x1 conv+BN+ReLU, x13).
   conv3x3   configs[1]: one 3x3 s1 p1 conv, N=128 x 3 x 224 x 224 -> 64; step = forward + backward(dW, dbias)
             straight through the C-ABI (the layer is the net input: no dX, bcnn_net.c:283).
 """
@@ -257,11 +261,18 @@ def main():
     L.bcnn_hip_sync()
     torch.cuda.synchronize()
     L.bcnn_hip_profile_reset()
-    L.bcnn_hip_profile_enable(1)
+    # The per-class HIP-event timers cost ~3.5 us of GPU pipeline per event (~200 events per ResNet step = 4 % of
+    # the step), so inside the timed region they sample every PROFILE_EVERY-th step instead of all of them; the
+    # averages they give are per profiled launch, the throughput is over all steps.
+    profile_every = max(1, int(os.environ.get("BENCH_PROFILE_EVERY", "4")))
+    profiled_steps = 0
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for it in range(args.steps):
+        prof_on = (it % profile_every) == 0
+        L.bcnn_hip_profile_enable(1 if prof_on else 0)
+        profiled_steps += 1 if prof_on else 0
         step()
     L.bcnn_hip_sync()
     torch.cuda.synchronize()
@@ -308,7 +319,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "batch_per_gpu": n, "global_batch": n * world, "parallelism": "dp%d" % world},
             "roofline": roof,
-            "kernel_classes": {k: {"ms_per_step": round(v["ms"] / args.steps, 4), "launches_per_step": v["launches"] // args.steps,
+            "profiled_steps": profiled_steps,
+            "kernel_classes": {k: {"ms_per_step": round(v["ms"] / profiled_steps, 4), "launches_per_step": v["launches"] // profiled_steps,
                                    "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None,
                                    "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} for k, v in prof.items()},
         }
