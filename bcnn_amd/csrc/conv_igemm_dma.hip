@@ -173,6 +173,12 @@ __global__ __launch_bounds__(64 * WM * WN, ABL_LB) void conv_igemm_dma_kernel(co
     unsigned a_voff[AH];
 #pragma unroll
     for (int h = 0; h < AH; ++h) a_voff[h] = (unsigned)(h * 64 + lane) * 4u;
+    // BM == 64: four consecutive A^T rows are one 16-byte-per-lane DMA (lane -> row lane / 16, columns 4 * (lane % 16) ..)
+#ifndef DMA_A_X4
+#define DMA_A_X4 1
+#endif
+    constexpr bool AX4 = DMA_A_X4 && (AH == 1) && (RPW % 4 == 0);
+    const unsigned a_voff4 = ((unsigned)(lane >> 4) * (unsigned)a.Mpad + (unsigned)(lane & 15) * 4u) * 4u;
     const int JB = a.Jpad / BK;
     const int ntiles = ci.ntaps * JB;
     const unsigned a_tile0 = ((unsigned)(g * a.kk2 + ci.tap0) * (unsigned)a.Jpad) * (unsigned)a.Mpad + (unsigned)m0;
@@ -191,8 +197,13 @@ __global__ __launch_bounds__(64 * WM * WN, ABL_LB) void conv_igemm_dma_kernel(co
                 for (int h = 0; h < BH; ++h)
                     dma_row(rs_b, lds_b0 + (unsigned)(((buf * BK + row) * BN + h * 64) * 4), voff[h], sb);
             }
+            if (AX4) {
+                if ((r & 3) == 0) dma_row_x4(rs_a, lds_a0 + (unsigned)(((buf * BK + row) * BM) * 4), a_voff4, sa);
+            } else {
 #pragma unroll
-            for (int h = 0; h < AH; ++h) dma_row(rs_a, lds_a0 + (unsigned)(((buf * BK + row) * BM + h * 64) * 4), a_voff[h], sa);
+                for (int h = 0; h < AH; ++h)
+                    dma_row(rs_a, lds_a0 + (unsigned)(((buf * BK + row) * BM + h * 64) * 4), a_voff[h], sa);
+            }
         }
     };
 
@@ -208,7 +219,7 @@ __global__ __launch_bounds__(64 * WM * WN, ABL_LB) void conv_igemm_dma_kernel(co
     // ---- K loop: ring of NS LDS stages. Tile it + NS - 1 is requested before the MFMAs of tile it; at the
     // end of the iteration only tile it + 1 has to have landed, i.e. the wave waits until at most the loads
     // of the NS - 2 younger tiles are still in flight (vmcnt is in-order) and then meets the barrier.
-    constexpr int LOADS_PER_TILE = RPW * AH + (HALF ? RPW / 2 : RPW * BH);  // DMA instructions one wave issues per tile
+    constexpr int LOADS_PER_TILE = (AX4 ? RPW / 4 : RPW * AH) + (HALF ? RPW / 2 : RPW * BH);  // DMA instructions per wave and tile
     int t_next = 0, jb_next = 0, issued = 0;       // (tap, major block) of the next tile to request
     auto request_next = [&](int buf) {
         if (issued > 0 && ++jb_next == JB) {

@@ -30,6 +30,13 @@ __device__ __forceinline__ void dma_row(rsrc_i4 rs, unsigned lds_base, unsigned 
                  : "s"(lds_base), "v"(voff), "s"(rs), "s"(soff)
                  : "memory", "m0");
 }
+// 16 bytes per lane: 64 lanes x 16 B = 1 KiB of LDS at lds_base + 16*lane (gfx950 `buffer_load_dwordx4 ... lds`).
+__device__ __forceinline__ void dma_row_x4(rsrc_i4 rs, unsigned lds_base, unsigned voff, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :
+                 : "s"(lds_base), "v"(voff), "s"(rs), "s"(soff)
+                 : "memory", "m0");
+}
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // wait until at most N of this wave's loads are outstanding (vmcnt retires in order: the N youngest may fly)
 template <int N>
