@@ -136,6 +136,8 @@ def main():
     ap.add_argument("--workload", default="resnet18", choices=["resnet18", "conv3x3", "mobilenet"])
     ap.add_argument("--batch", type=int, default=None, help="images per GPU (default 128; 256 for mobilenet)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--input-grad", action="store_true",
+                    help="conv3x3 only: give the source a gradient so that backward also runs dX (SURVEY.md 8d, config #2 variant)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="data-parallel runs: one blocking all-reduce after backward instead of overlapped buckets")
     args = ap.parse_args()
@@ -243,17 +245,19 @@ def main():
         y = torch.empty((n, f, oh, ow), device=dev)
         dy = (torch.rand((n, f, oh, ow), device=dev, generator=gen) * 2 - 1) * 1e-2
         ws = torch.zeros(max(1, ops.conv_workspace_size(n, c, h, w, f, k, s, p, 1)), device=dev)
+        dxg = torch.empty_like(x) if args.input_grad else None
         torch.cuda.synchronize()
 
         def step():
             ops.conv_forward(x, wt, bias, y, k, s, p, 1, 0)
-            ops.conv_backward(x, wt, y, dy, None, dw, db, k, s, p, 1, 0, ws)
+            ops.conv_backward(x, wt, y, dy, dxg, dw, db, k, s, p, 1, 0, ws)
             if world > 1:
                 L.bcnn_hip_sync()
                 dist.all_reduce(grads)
                 torch.cuda.synchronize()
-        desc = ("conv3x3 s1 p1, N=%d x 3 x 224 x 224 -> 64 (BASELINE configs[1]), fwd + bwd(dW, dbias); "
-                "no dX: the layer's source is the net input" % n)
+        desc = ("conv3x3 s1 p1, N=%d x 3 x 224 x 224 -> 64 (BASELINE configs[1]), fwd + bwd(dW, dbias%s)"
+                % (n, ", dX: variant with a gradient-carrying source" if args.input_grad else
+                   "); no dX: the layer's source is the net input"))
         sample_n = 16
 
     for _ in range(args.warmup):
