@@ -155,11 +155,15 @@ __global__ void dw_weight_accumulate_kernel(const float* __restrict__ partials, 
 // out-of-image tap amounts to) and reused by the four outputs; outputs leave as one 16-byte store when the
 // row allows it. Same tap order as the reference (kh outer, kw inner, separate multiply and add).
 // ================================================================================================
+#ifndef DW_VR
+#define DW_VR 2  // output rows per thread of the 3x3 forward / weight-gradient kernels
+#endif
 struct Dw3Args {
     DwShape s;
     unsigned groups_per_row;   // ceil(OW / 4)
-    unsigned gpr_magic, oh_magic;
-    unsigned total_groups;     // planes * OH * groups_per_row
+    unsigned row_groups;       // ceil(OH / VR): output rows are handled VR at a time
+    unsigned gpr_magic, oh_magic;  // magic of groups_per_row / row_groups
+    unsigned total_groups;     // planes * row_groups * groups_per_row
 };
 __device__ __forceinline__ unsigned dw_div(unsigned n, unsigned d, unsigned magic) {
     // magic = ceil(2^32 / d); one correction step makes it exact for every n < 2^32 / 2
@@ -203,64 +207,81 @@ __device__ __forceinline__ void dw_window(const float* row, int iw0, int W, bool
     }
 }
 
-template <int S>
+template <int S, int VR>  // VR output rows per thread: the (VR - 1) * S + 3 input rows are fetched once
 __global__ __launch_bounds__(256) void dw3_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                       const float* __restrict__ bias, float* __restrict__ y,
                                                       const Dw3Args a, int act) {
     constexpr int WIN = 3 * S + 3;  // input columns feeding 4 outputs
+    constexpr int NR = (VR - 1) * S + 3;
     const DwShape& s = a.s;
-    const unsigned t = blockIdx.x * 256u + threadIdx.x;
-    if (t >= a.total_groups) return;
+    for (unsigned t = blockIdx.x * 256u + threadIdx.x; t < a.total_groups; t += gridDim.x * 256u) {
     const unsigned rowid = dw_div(t, a.groups_per_row, a.gpr_magic), q = t - rowid * a.groups_per_row;
-    const unsigned plane = dw_div(rowid, (unsigned)s.OH, a.oh_magic), oh = rowid - plane * (unsigned)s.OH;
+    const unsigned plane = dw_div(rowid, a.row_groups, a.oh_magic), og = rowid - plane * a.row_groups;
     const int c = (int)(plane % (unsigned)s.C);
     const float* src = x + (size_t)plane * s.H * s.W;
     const float* wk = w + c * 9;
     float wv[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) wv[i] = wk[i];
-    const int ow0 = (int)q * 4, ih0 = (int)oh * S - s.pad, iw0 = ow0 * S - s.pad;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const int oh0 = (int)og * VR, ow0 = (int)q * 4, ih0 = oh0 * S - s.pad, iw0 = ow0 * S - s.pad;
+    float acc[VR][4];
+#pragma unroll
+    for (int r = 0; r < VR; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[r][j] = 0.f;
     const bool fast = s.pad == 1 && (s.W & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-        const int ih = ih0 + kh;
+    for (int i = 0; i < NR; ++i) {
+        const int ih = ih0 + i;
         const bool rv = (unsigned)ih < (unsigned)s.H;
         float xv[WIN];
         dw_window<WIN>(rv ? src + ih * s.W : nullptr, iw0, s.W, fast, xv);
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw)
+        for (int r = 0; r < VR; ++r) {
+            const int kh = i - r * S;  // compile-time after unrolling; ascending i == ascending kh per output row
+            if (kh < 0 || kh > 2) continue;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = __fadd_rn(acc[j], __fmul_rn(wv[kh * 3 + kw], xv[j * S + kw]));
+            for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[r][j] = __fadd_rn(acc[r][j], __fmul_rn(wv[kh * 3 + kw], xv[j * S + kw]));
+        }
     }
     const float b = bias[c];
-    float* dst = y + ((size_t)plane * s.OH + oh) * s.OW + ow0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if (b != 0.0f && b != 1.0f) acc[j] += b;
-        acc[j] = act_fwd_cheap(acc[j], act, 0.f);
+    for (int r = 0; r < VR; ++r) {
+        const int oh = oh0 + r;
+        if (oh >= s.OH) break;
+        float* dst = y + ((size_t)plane * s.OH + oh) * s.OW + ow0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (b != 0.0f && b != 1.0f) acc[r][j] += b;
+            acc[r][j] = act_fwd_cheap(acc[r][j], act, 0.f);
+        }
+        if (ow0 + 4 <= s.OW && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+            *reinterpret_cast<float4*>(dst) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (ow0 + j < s.OW) dst[j] = acc[r][j];
+        }
     }
-    if (ow0 + 4 <= s.OW && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
-        *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (ow0 + j < s.OW) dst[j] = acc[j];
     }
 }
 
 // dw partial sums: grid-stride over the same 4-column groups, restricted to ONE channel per workgroup row
 // (blockIdx.y = channel) so the nine accumulators reduce without atomics; blockIdx.x = split of the channel's
 // (image, row, group) space.
-template <int S>
+template <int S, int VR>
 __global__ __launch_bounds__(256) void dw3_bwd_weight_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                              const Dw3Args a, int splits,
                                                              float* __restrict__ partials) {
     constexpr int WIN = 3 * S + 3;
+    constexpr int NR = (VR - 1) * S + 3;
     __shared__ float red[4][9];
     const DwShape& s = a.s;
     const int c = blockIdx.y, sp = blockIdx.x;
-    const unsigned per_img = (unsigned)s.OH * a.groups_per_row;       // groups per (image, channel) plane
+    const unsigned per_img = a.row_groups * a.groups_per_row;          // thread items per (image, channel) plane
     const unsigned M = (unsigned)s.N * per_img;
     const unsigned per = (M + splits - 1) / splits;
     const unsigned lo = sp * per;
@@ -272,24 +293,33 @@ __global__ __launch_bounds__(256) void dw3_bwd_weight_kernel(const float* __rest
     const bool fast = s.pad == 1 && (s.W & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
     for (unsigned idx = lo + threadIdx.x; idx < hi; idx += 256) {
         const unsigned rowid = dw_div(idx, a.groups_per_row, a.gpr_magic), q = idx - rowid * a.groups_per_row;
-        const unsigned n = dw_div(rowid, (unsigned)s.OH, a.oh_magic), oh = rowid - n * (unsigned)s.OH;
+        const unsigned n = dw_div(rowid, a.row_groups, a.oh_magic), og = rowid - n * a.row_groups;
         const size_t plane = (size_t)n * s.C + c;
         const float* src = x + plane * s.H * s.W;
-        const float* gp = g + (plane * s.OH + oh) * s.OW;
-        const int ow0 = (int)q * 4, ih0 = (int)oh * S - s.pad, iw0 = ow0 * S - s.pad;
-        float gv[4];
+        const int oh0 = (int)og * VR, ow0 = (int)q * 4, ih0 = oh0 * S - s.pad, iw0 = ow0 * S - s.pad;
+        float gv[VR][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) gv[j] = (ow0 + j < s.OW) ? gp[ow0 + j] : 0.f;
+        for (int r = 0; r < VR; ++r) {
+            const float* gp = g + (plane * s.OH + oh0 + r) * s.OW;
+            const bool rok = oh0 + r < s.OH;
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            const int ih = ih0 + kh;
+            for (int j = 0; j < 4; ++j) gv[r][j] = (rok && ow0 + j < s.OW) ? gp[ow0 + j] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int ih = ih0 + i;
             const bool rv = (unsigned)ih < (unsigned)s.H;
             float xv[WIN];
             dw_window<WIN>(rv ? src + ih * s.W : nullptr, iw0, s.W, fast, xv);
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw)
+            for (int r = 0; r < VR; ++r) {
+                const int kh = i - r * S;
+                if (kh < 0 || kh > 2) continue;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[kh * 3 + kw] += xv[j * S + kw] * gv[j];
+                for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[kh * 3 + kw] += xv[j * S + kw] * gv[r][j];
+            }
         }
     }
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -309,8 +339,9 @@ __global__ __launch_bounds__(256) void dw3_bwd_weight_kernel(const float* __rest
 struct Dw3DxArgs {
     DwShape s;
     unsigned groups_per_row;   // ceil(W / 4)
-    unsigned gpr_magic, h_magic;
-    unsigned total_groups;     // planes * H * groups_per_row
+    unsigned row_groups;       // input rows (stride-1 kernel: ceil(H / VR) row groups)
+    unsigned gpr_magic, h_magic;  // magic of groups_per_row / row_groups
+    unsigned total_groups;     // planes * row_groups * groups_per_row
 };
 template <int S>  // S = compile-time stride (1, 2), 0 = runtime stride
 __global__ __launch_bounds__(256) void dw3_bwd_data_kernel(const float* __restrict__ g, const float* __restrict__ w,
@@ -319,7 +350,7 @@ __global__ __launch_bounds__(256) void dw3_bwd_data_kernel(const float* __restri
     const unsigned t = blockIdx.x * 256u + threadIdx.x;
     if (t >= a.total_groups) return;
     const unsigned rowid = dw_div(t, a.groups_per_row, a.gpr_magic), q = t - rowid * a.groups_per_row;
-    const unsigned plane = dw_div(rowid, (unsigned)s.H, a.h_magic), ih = rowid - plane * (unsigned)s.H;
+    const unsigned plane = dw_div(rowid, a.row_groups, a.h_magic), ih = rowid - plane * a.row_groups;
     const int c = (int)(plane % (unsigned)s.C);
     const float* gp = g + (size_t)plane * s.OH * s.OW;
     const float* wk = w + c * 9;
@@ -409,6 +440,72 @@ __global__ __launch_bounds__(256) void dw3_bwd_data_kernel(const float* __restri
     }
 }
 
+// stride 1: VR consecutive input rows per thread; the VR + 2 dy rows they meet are fetched once each
+// (16-byte window loads when the rows allow). Per pixel the taps still arrive in descending kh, kw.
+template <int VR>
+__global__ __launch_bounds__(256) void dw3_bwd_data_s1_kernel(const float* __restrict__ g, const float* __restrict__ w,
+                                                              float* __restrict__ dx, const Dw3DxArgs a) {
+    const DwShape& s = a.s;
+    const unsigned t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= a.total_groups) return;
+    const unsigned rowid = dw_div(t, a.groups_per_row, a.gpr_magic), q = t - rowid * a.groups_per_row;
+    const unsigned plane = dw_div(rowid, a.row_groups, a.h_magic), rg = rowid - plane * a.row_groups;
+    const int c = (int)(plane % (unsigned)s.C);
+    const float* gp = g + (size_t)plane * s.OH * s.OW;
+    const float* wk = w + c * 9;
+    float wv[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) wv[i] = wk[i];
+    const int ih0 = (int)rg * VR, iw0 = (int)q * 4;
+    float* dst0 = dx + ((size_t)plane * s.H + ih0) * s.W + iw0;
+    const bool vec = iw0 + 4 <= s.W && (s.W & 3) == 0 && ((reinterpret_cast<uintptr_t>(dx) & 15) == 0);
+    float acc[VR][4];
+#pragma unroll
+    for (int r = 0; r < VR; ++r) {
+        if (ih0 + r < s.H) {
+            if (vec) {
+                const float4 v = *reinterpret_cast<const float4*>(dst0 + r * s.W);
+                acc[r][0] = v.x; acc[r][1] = v.y; acc[r][2] = v.z; acc[r][3] = v.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[r][j] = (iw0 + j < s.W) ? dst0[r * s.W + j] : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[r][j] = 0.f;
+        }
+    }
+    const int wbase = iw0 + s.pad - 2;  // first dy column the four pixels can meet
+    const bool fast = s.pad == 1 && (s.OW & 3) == 0 && (reinterpret_cast<uintptr_t>(g) & 15) == 0;
+#pragma unroll
+    for (int tt = 0; tt < VR + 2; ++tt) {
+        const int oh = ih0 + s.pad - 2 + tt;
+        float gw[6];
+        dw_window<6>((unsigned)oh < (unsigned)s.OH ? gp + oh * s.OW : nullptr, wbase, s.OW, fast, gw);
+#pragma unroll
+        for (int r = 0; r < VR; ++r) {
+            const int kh = r + 2 - tt;  // oh = ih + pad - kh; ascending tt == descending kh per input row
+            if (kh < 0 || kh > 2) continue;
+#pragma unroll
+            for (int kw = 2; kw >= 0; --kw)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[r][j] = __fadd_rn(acc[r][j], __fmul_rn(wv[kh * 3 + kw], gw[j + 2 - kw]));
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < VR; ++r) {
+        if (ih0 + r >= s.H) break;
+        if (vec) {
+            *reinterpret_cast<float4*>(dst0 + r * s.W) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (iw0 + j < s.W) dst0[r * s.W + j] = acc[r][j];
+        }
+    }
+}
+
 static unsigned dw_magic(unsigned d) { return d > 1 ? (unsigned)((0x100000000ULL + d - 1) / d) : 0u; }
 
 }  // namespace bcnn_hip
@@ -425,14 +522,19 @@ void bcnn_hip_depthwise_forward(const float* x, const float* w, const float* bia
     KTimer kt(K_DEPTHWISE_FWD, 2.0 * (double)total * k * k, 4.0 * ((double)n * c * h * wd + (double)total));
     const int fused = act_is_cheap(act) ? act : BCNN_HIP_ACT_NONE;
     const unsigned gpr = (unsigned)ceil_div(s.OW, 4);
-    const long long groups = (long long)n * c * s.OH * gpr;
+    constexpr int VR = DW_VR;
+    const unsigned rgs = (unsigned)ceil_div(s.OH, VR);
+    const long long groups = (long long)n * c * rgs * gpr;
     if (k == 3 && (stride == 1 || stride == 2) && groups < 0x7fffffffLL) {
         Dw3Args a;
-        a.s = s; a.groups_per_row = gpr; a.gpr_magic = dw_magic(gpr); a.oh_magic = dw_magic((unsigned)s.OH);
+        a.s = s; a.groups_per_row = gpr; a.row_groups = rgs; a.gpr_magic = dw_magic(gpr); a.oh_magic = dw_magic(rgs);
         a.total_groups = (unsigned)groups;
-        const unsigned blocks = (unsigned)((groups + 255) / 256);
-        if (stride == 1) dw3_fwd_kernel<1><<<blocks, 256, 0, current_stream()>>>(x, w, bias, y, a, fused);
-        else dw3_fwd_kernel<2><<<blocks, 256, 0, current_stream()>>>(x, w, bias, y, a, fused);
+        unsigned blocks = (unsigned)((groups + 255) / 256);
+#ifdef DW_PERSIST
+        if (blocks > (unsigned)(kCUs * DW_PERSIST)) blocks = (unsigned)(kCUs * DW_PERSIST);
+#endif
+        if (stride == 1) dw3_fwd_kernel<1, VR><<<blocks, 256, 0, current_stream()>>>(x, w, bias, y, a, fused);
+        else dw3_fwd_kernel<2, VR><<<blocks, 256, 0, current_stream()>>>(x, w, bias, y, a, fused);
     } else {
         dw_fwd_kernel<<<stream_grid((size_t)total, 256), 256, 0, current_stream()>>>(x, w, bias, y, s, fused,
                                                                                    (unsigned)total);
@@ -462,13 +564,15 @@ void bcnn_hip_depthwise_backward(const float* x, const float* w, const float* y,
     float* part = reduce_scratch((size_t)c * splits * NT);
     dim3 grid((unsigned)c, (unsigned)splits);
     const unsigned gpr = (unsigned)ceil_div(s.OW, 4);
-    if (k == 3 && (stride == 1 || stride == 2) && (long long)n * s.OH * gpr < 0x7fffffffLL && c <= 65535) {
+    constexpr int VR = DW_VR;
+    const unsigned rgs = (unsigned)ceil_div(s.OH, VR);
+    if (k == 3 && (stride == 1 || stride == 2) && (long long)n * rgs * gpr < 0x7fffffffLL && c <= 65535) {
         Dw3Args a;
-        a.s = s; a.groups_per_row = gpr; a.gpr_magic = dw_magic(gpr); a.oh_magic = dw_magic((unsigned)s.OH);
+        a.s = s; a.groups_per_row = gpr; a.row_groups = rgs; a.gpr_magic = dw_magic(gpr); a.oh_magic = dw_magic(rgs);
         a.total_groups = 0;
         dim3 g2((unsigned)splits, (unsigned)c);
-        if (stride == 1) dw3_bwd_weight_kernel<1><<<g2, 256, 0, current_stream()>>>(x, dy, a, splits, part);
-        else dw3_bwd_weight_kernel<2><<<g2, 256, 0, current_stream()>>>(x, dy, a, splits, part);
+        if (stride == 1) dw3_bwd_weight_kernel<1, VR><<<g2, 256, 0, current_stream()>>>(x, dy, a, splits, part);
+        else dw3_bwd_weight_kernel<2, VR><<<g2, 256, 0, current_stream()>>>(x, dy, a, splits, part);
     } else if (k == 3) dw_bwd_weight_kernel<3><<<grid, 256, 0, current_stream()>>>(x, dy, s, splits, part);
     else if (k == 5) dw_bwd_weight_kernel<5><<<grid, 256, 0, current_stream()>>>(x, dy, s, splits, part);
     else {
@@ -480,13 +584,15 @@ void bcnn_hip_depthwise_backward(const float* x, const float* w, const float* y,
     KERNEL_CHECK();
     const long long total_i = (long long)n * c * h * wd;
     const unsigned gpr_i = (unsigned)ceil_div(wd, 4);
-    const long long groups_i = (long long)n * c * h * gpr_i;
+    constexpr int VRX = DW_VR;
+    const unsigned rgs_i = stride == 1 ? (unsigned)ceil_div(h, VRX) : (unsigned)h;
+    const long long groups_i = (long long)n * c * rgs_i * gpr_i;
     if (k == 3 && groups_i < 0x7fffffffLL) {
         Dw3DxArgs a;
-        a.s = s; a.groups_per_row = gpr_i; a.gpr_magic = dw_magic(gpr_i); a.h_magic = dw_magic((unsigned)h);
+        a.s = s; a.groups_per_row = gpr_i; a.row_groups = rgs_i; a.gpr_magic = dw_magic(gpr_i); a.h_magic = dw_magic(rgs_i);
         a.total_groups = (unsigned)groups_i;
         const unsigned blocks = (unsigned)((groups_i + 255) / 256);
-        if (stride == 1) dw3_bwd_data_kernel<1><<<blocks, 256, 0, current_stream()>>>(dy, w, dx, a);
+        if (stride == 1) dw3_bwd_data_s1_kernel<VRX><<<blocks, 256, 0, current_stream()>>>(dy, w, dx, a);
         else if (stride == 2) dw3_bwd_data_kernel<2><<<blocks, 256, 0, current_stream()>>>(dy, w, dx, a);
         else dw3_bwd_data_kernel<0><<<blocks, 256, 0, current_stream()>>>(dy, w, dx, a);
     } else {
