@@ -25,6 +25,10 @@
 
 namespace bcnn_hip {
 
+#ifndef DMA_BK
+#define DMA_BK 16
+#endif
+constexpr int kDmaBK = DMA_BK;   // reduction rows per K-tile (one barrier per tile)
 constexpr int kDmaMaxTaps = 49;
 constexpr int kDmaMaxClasses = 4;
 
@@ -61,7 +65,7 @@ struct DmaArgs {
 #endif
 template <int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(64 * WM * WN, ABL_LB) void conv_igemm_dma_kernel(const DmaArgs a) {
-    constexpr int BK = 16;
+    constexpr int BK = kDmaBK;
     constexpr int NW = WM * WN;         // waves per workgroup (4, or 2 for the 64 x 32 tile)
     constexpr int NT = 64 * NW;         // threads
     constexpr int RPW = BK / NW;        // K rows each wave stages per tile
@@ -441,7 +445,7 @@ static bool dma_supported(const ConvShape& s, int M, int J, size_t b_elems) {
     if (M <= 32 || J < 8) return false;                       // tiny GEMM-M / reduction: padding waste
     if (b_elems * 4 >= 0x7ffffff0ull) return false;           // buffer range / OOB marker
     const int kk2 = s.pointwise ? 1 : s.ksz * s.ksz;
-    const size_t at = (size_t)s.groups * kk2 * round_up(J, 16) * round_up(M, 128) * 4;
+    const size_t at = (size_t)s.groups * kk2 * round_up(J, kDmaBK) * round_up(M, 128) * 4;
     if (at >= 0x7ffffff0ull) return false;
     if ((long long)s.N * (s.OHOW > s.HW ? s.OHOW : s.HW) >= 0x7fffffffLL) return false;
     return true;
@@ -509,7 +513,7 @@ bool conv_forward_dma(const float* x, const float* w, const float* bias, const f
     DmaArgs a;
     a.b_base = x; a.out = y; a.bias = bias; a.slopes = slopes; a.s = s;
     a.mode = 0; a.act = raw ? BCNN_HIP_ACT_NONE : act; a.add_bias = raw ? 0 : 1;
-    a.M = s.Mg; a.J = s.Cg; a.Jpad = round_up(a.J, 16); a.Mpad = round_up(a.M, 128); a.kk2 = kk2;
+    a.M = s.Mg; a.J = s.Cg; a.Jpad = round_up(a.J, kDmaBK); a.Mpad = round_up(a.M, 128); a.kk2 = kk2;
     const size_t at_floats = (size_t)s.groups * kk2 * a.Jpad * a.Mpad;
     float* at = dma_scratch(at_floats);
     a.at = at; a.at_bytes = (unsigned)(at_floats * 4);
@@ -534,7 +538,7 @@ bool conv_backward_data_dma(const float* w, const float* dy, float* dx, const Co
     DmaArgs a;
     a.b_base = dy; a.out = dx; a.bias = nullptr; a.slopes = nullptr; a.s = s;
     a.mode = 1; a.act = BCNN_HIP_ACT_NONE; a.add_bias = 0; a.stats = nullptr; a.stats_splits = 0;
-    a.M = s.Cg; a.J = s.Mg; a.Jpad = round_up(a.J, 16); a.Mpad = round_up(a.M, 128); a.kk2 = kk2;
+    a.M = s.Cg; a.J = s.Mg; a.Jpad = round_up(a.J, kDmaBK); a.Mpad = round_up(a.M, 128); a.kk2 = kk2;
     const size_t at_floats = (size_t)s.groups * kk2 * a.Jpad * a.Mpad;
     float* at = dma_scratch(at_floats);
     a.at = at; a.at_bytes = (unsigned)(at_floats * 4);
