@@ -32,6 +32,14 @@ constexpr int kDmaBK = DMA_BK;   // reduction rows per K-tile (one barrier per t
 constexpr int kDmaMaxTaps = 49;
 constexpr int kDmaMaxClasses = 4;
 
+#ifdef ABL_CLOCK
+__device__ unsigned long long g_dma_clk[2];
+extern "C" void bcnn_hip_debug_read_clock(unsigned long long* out) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dma_clk), 16);
+}
+#endif
+
 struct DmaClass {
     int ih0, iw0, Hc, Wc;  // dX: first row/col and extent of the stride-parity class (forward: 0,0,OH,OW)
     int ntaps, tap0;       // taps of the class, index of its first tap in the packed At
@@ -95,6 +103,9 @@ __global__ __launch_bounds__(64 * WM * WN, ABL_LB) void conv_igemm_dma_kernel(co
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid / WN, wn = wid % WN;
     const int g = blockIdx.y;
+#ifdef ABL_CLOCK
+    const unsigned long long clk_c0 = clock64(), clk_t0 = wall_clock64();
+#endif
     const DmaClass& ci = a.cls[blockIdx.z];
     const int lb = xcd_remap(blockIdx.x, gridDim.x);
     const int mt = lb % a.mtiles, pt = lb / a.mtiles;
@@ -350,6 +361,12 @@ __global__ __launch_bounds__(64 * WM * WN, ABL_LB) void conv_igemm_dma_kernel(co
         }
     }
 
+#ifdef ABL_CLOCK
+    if (blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) {
+        g_dma_clk[0] = clock64() - clk_c0;        // shader cycles over this workgroup's K loop
+        g_dma_clk[1] = wall_clock64() - clk_t0;   // 100 MHz ticks
+    }
+#endif
     // ---- epilogue ------------------------------------------------------------------------------------
     // 32-bit element offsets against the output base (tensors are < 2 GiB here), the 16 rows of an
     // accumulator at compile-time multiples of the wave-uniform row stride, and no per-value predicate or
