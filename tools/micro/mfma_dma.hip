@@ -3,6 +3,7 @@
 // shader clock (s_memtime cycles / wall_clock64 ticks at 100 MHz) to separate issue limits from clock limits.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include "../../bcnn_amd/csrc/lds_dma.h"
 using namespace bcnn_hip;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -73,7 +74,17 @@ int main() {
     const unsigned src_bytes = 64u << 20;
     (void)hipMalloc(&out, 256 * 8192 * sizeof(float));
     (void)hipMalloc(&src, src_bytes);
-    (void)hipMemset(src, 0, src_bytes);
+    {   // operand data matters for power: zeros keep the clock at 2.4 GHz, random fp32 does not
+        const char* z = getenv("MFMA_DMA_ZERO");
+        if (z) (void)hipMemset(src, 0, src_bytes);
+        else {
+            float* h = (float*)malloc(src_bytes);
+            unsigned st = 12345u;
+            for (size_t i = 0; i < src_bytes / 4; ++i) { st = st * 1664525u + 1013904223u; h[i] = ((st >> 8) & 0xffff) / 32768.0f - 1.0f; }
+            (void)hipMemcpy(src, h, src_bytes, hipMemcpyHostToDevice);
+            free(h);
+        }
+    }
     (void)hipMalloc(&clk_d, 16);
     for (int pass = 0; pass < 2; ++pass)
         for (int occ = 2; occ <= 8; occ *= 2) {
