@@ -68,3 +68,43 @@ def test_conv_against_torch_fp32(shape):
     assert rel(dx, xr.grad.double()) < 1e-5
     assert rel(dw, wr.grad.double()) < 1e-5
     assert rel(db, dy.double().sum((0, 2, 3))) < 1e-5
+
+
+def test_tensor_above_2gib_takes_the_fallback_kernels_and_agrees_with_the_dma_kernels_on_halves():
+    """Maximum sizes: the LDS-DMA kernels address operands through 32-bit buffer offsets and hand tensors of
+    2 GiB or more to the register-staged kernels. A 2.1 GiB input is convolved whole (fallback path) and as
+    two half batches (DMA path); forward, dX and dW must agree -- a cross-check between the two kernel families
+    at a size no CPU reference finishes in test time."""
+    import torch
+    from bcnn_amd import ops
+    dev = "cuda:0"
+    n, c, h, w, f, k, s, p = 128, 64, 256, 256, 40, 3, 1, 1
+    assert n * c * h * w * 4 >= 2**31
+    g = torch.Generator(device=dev).manual_seed(11)
+    x = torch.rand((n, c, h, w), device=dev, generator=g) * 2 - 1
+    wt = (torch.rand((f, c, k, k), device=dev, generator=g) * 2 - 1) * (3.0 / (c * k * k)) ** 0.5
+    b = torch.rand(f, device=dev, generator=g) - 0.5
+    dy = (torch.rand((n, f, h, w), device=dev, generator=g) * 2 - 1) * 0.1
+
+    def run(xs, dys):
+        nn = xs.shape[0]
+        y = torch.empty((nn, f, h, w), device=dev)
+        ops.conv_forward(xs, wt, b, y, k, s, p, 1, 0)
+        dx = torch.empty_like(xs)
+        dw = torch.zeros_like(wt)
+        db = torch.zeros_like(b)
+        ws = torch.zeros(max(1, ops.conv_workspace_size(nn, c, h, w, f, k, s, p, 1)), device=dev)
+        ops.conv_backward(xs, wt, y, dys.clone(), dx, dw, db, k, s, p, 1, 0, ws)
+        torch.cuda.synchronize()
+        return y, dx, dw, db
+
+    y, dx, dw, db = run(x, dy)
+    half = n // 2
+    parts = [run(x[i:i + half].contiguous(), dy[i:i + half].contiguous()) for i in (0, half)]
+
+    def rel(a, r):
+        return float((a - r).abs().max() / r.abs().max())
+    assert rel(y, torch.cat([q[0] for q in parts])) < 1e-5
+    assert rel(dx, torch.cat([q[1] for q in parts])) < 1e-5
+    assert rel(dw, parts[0][2] + parts[1][2]) < 1e-4
+    assert rel(db, parts[0][3] + parts[1][3]) < 1e-4
