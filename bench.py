@@ -148,6 +148,11 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hook (tests/test_dp_gpu.py): several ranks on ONE GPU over gloo, to exercise the data-parallel step
+    # logic where only a single device exists. Never set by the driver.
+    same_device = os.environ.get("BENCH_TEST_SAME_DEVICE") == "1"
+    if same_device:
+        local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
     torch.cuda.set_device(local_rank)
@@ -156,7 +161,7 @@ def main():
     if world > 1 or os.environ.get("BENCH_FORCE_DP") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world)  # "nccl" IS RCCL on ROCm
+        dist.init_process_group("gloo" if same_device else "nccl", rank=rank, world_size=world)  # "nccl" IS RCCL on ROCm
     dev = torch.device("cuda", local_rank)
     n = args.batch if args.batch else (256 if args.workload == "mobilenet" else 128)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)   # every rank owns different images
@@ -330,6 +335,10 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:  # reported by the single-GPU run only
             out["cpu_baseline"] = cpu_baseline(args.workload, sample_n)
+        if os.environ.get("BENCH_TEST_CHECKSUM") == "1" and args.workload != "conv3x3":
+            pptr, psize = net.parameter_arena()
+            params = torch.as_tensor(capi.DeviceArray(pptr, psize), device=dev)
+            out["param_checksum"] = [float(params.double().sum()), float(params.double().abs().sum())]
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()

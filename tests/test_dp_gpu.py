@@ -111,3 +111,35 @@ def test_gradient_ready_ranges_tile_the_arena():
     net.set_gradient_ready_callback(None)
     net.forward(); net.backward(); net.sync()
     assert len(seen) == 2 * n_first
+
+
+def _run_bench_two_ranks(extra, port):
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_TEST_SAME_DEVICE="1", BENCH_TEST_CHECKSUM="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--batch", "8", "--no-cpu-baseline"] + extra
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    return json.loads(line)
+
+
+def test_bench_two_ranks_overlapped_allreduce_equals_blocking_allreduce():
+    """bench.py's data-parallel step, world_size 2 (both ranks on this one GPU, gloo): the bucketed all-reduce
+    queued from inside bcnn_backward must leave the parameters exactly where one blocking all-reduce after backward
+    leaves them (same summation: two ranks, a + b == b + a)."""
+    import socket
+    ports = []
+    for _ in range(2):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            ports.append(s.getsockname()[1])
+    a = _run_bench_two_ranks([], ports[0])
+    b = _run_bench_two_ranks(["--no-overlap"], ports[1])
+    assert a["n_gpus"] == 2 and a["config"]["global_batch"] == 16
+    assert a["param_checksum"] == b["param_checksum"], (a["param_checksum"], b["param_checksum"])
