@@ -86,6 +86,26 @@ struct SumF {
         acc[0] += (v.x + v.y) + (v.z + v.w);
     }
 };
+// g = dy * act'(y) written back over dy, and summed: the activation backward and the bias gradient of a layer in
+// one sweep (the depthwise node runs them back to back, bcnn_depthwise_conv_layer.c:311-317)
+struct ActBwdSumF {
+    const float* y;
+    float* dy;
+    int act;
+    __device__ void operator()(long long off, int, float (&acc)[1]) const {
+        const float g = dy[off] * act_bwd_cheap(y[off], act, 0.f);
+        dy[off] = g;
+        acc[0] += g;
+    }
+    __device__ void vec4(long long off, int, float (&acc)[1]) const {
+        float4 g = *reinterpret_cast<const float4*>(dy + off);
+        const float4 v = *reinterpret_cast<const float4*>(y + off);
+        g.x *= act_bwd_cheap(v.x, act, 0.f); g.y *= act_bwd_cheap(v.y, act, 0.f);
+        g.z *= act_bwd_cheap(v.z, act, 0.f); g.w *= act_bwd_cheap(v.w, act, 0.f);
+        *reinterpret_cast<float4*>(dy + off) = g;
+        acc[0] += (g.x + g.y) + (g.z + g.w);
+    }
+};
 struct DotF {
     const float* g;
     const float* x;
@@ -178,6 +198,30 @@ void bcnn_hip_grad_bias(float* dbias, const float* g, int n, int c, int hw) {
     chan_accumulate_kernel<<<ceil_div(c, 256), 256, 0, current_stream()>>>(part, c, splits, dbias);
     KERNEL_CHECK();
 }
+
+}  // extern "C"
+
+namespace bcnn_hip {
+// dy *= act'(y) in place and dbias += per-channel sum of the result, one pass (cheap activations, 16-byte aligned
+// tensors); otherwise the two separate passes.
+void activation_backward_grad_bias(const float* y, float* dy, float* dbias, int n, int c, int hw, int act) {
+    const long long M = (long long)n * hw;
+    if (!M || !c) return;
+    const bool al = ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
+    if (act == BCNN_HIP_ACT_NONE || !act_bwd_is_cheap(act) || act == BCNN_HIP_ACT_PRELU || !al) {
+        bcnn_hip_activation_backward(y, dy, (size_t)(M * c), act, nullptr, nullptr, hw, c);
+        bcnn_hip_grad_bias(dbias, dy, n, c, hw);
+        return;
+    }
+    const int splits = chan_splits(c, M);
+    float* part = reduce_scratch((size_t)c * splits);
+    launch_chan_reduce<1>(ActBwdSumF{y, dy, act}, c, hw, M, splits, part);
+    chan_accumulate_kernel<<<ceil_div(c, 256), 256, 0, current_stream()>>>(part, c, splits, dbias);
+    KERNEL_CHECK();
+}
+}  // namespace bcnn_hip
+
+extern "C" {
 
 void bcnn_hip_grad_scales(const float* x_norm, const float* g, int n, int c, int hw, float* dscales) {
     const long long M = (long long)n * hw;

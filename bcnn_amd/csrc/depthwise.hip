@@ -10,6 +10,8 @@
 
 namespace bcnn_hip {
 
+void activation_backward_grad_bias(const float* y, float* dy, float* dbias, int n, int c, int hw, int act);  // blas1.hip
+
 struct DwShape {
     int N, C, H, W, OH, OW, ksz, stride, pad;
 };
@@ -555,8 +557,7 @@ void bcnn_hip_depthwise_backward(const float* x, const float* w, const float* y,
               4.0 * (((act != BCNN_HIP_ACT_NONE) ? 3.0 : 0.0) * (double)total_o + (double)total_o +
                      (dx ? ((double)n * c * h * wd + (double)total_o) + ((double)total_o + 2.0 * (double)n * c * h * wd)
                          : 0.0)));
-    bcnn_hip_activation_backward(y, dy, (size_t)total_o, act, nullptr, nullptr, ohow, c);
-    bcnn_hip_grad_bias(dbias, dy, n, c, ohow);
+    activation_backward_grad_bias(y, dy, dbias, n, c, ohow, act);  // one sweep: dy *= act'(y), dbias += sum
     if (!dx) return;  // reference: dW and dX are both skipped when the source has no gradient (:318, :432)
     const int NT = k * k;
     const long long M = (long long)n * ohow;
