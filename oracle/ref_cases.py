@@ -25,13 +25,15 @@ def conv_out_hw(h, w, k, s, p):
 # conv (+ fused BN, + fused activation)          src/layers/bcnn_conv_layer.c:367-587
 # --------------------------------------------------------------------------------------------
 def make_conv(seed, n, c, h, w, f, k, s, p, g=1, bn=0, act=rb.ACT_NONE, input_grad=True,
-              mode=rb.MODE_TRAIN, bias_one=False, carry=False, name=None):
+              mode=rb.MODE_TRAIN, bias_one=False, carry=False, name=None, via_model_file=False):
     rs = np.random.RandomState(seed)
     oh, ow = conv_out_hw(h, w, k, s, p)
     cg = c // g
     a = np.sqrt(3.0 / (cg * k * k))
     case = dict(op="conv", n=n, c=c, h=h, w=w, f=f, k=k, s=s, p=p, g=g, bn=bn, act=act,
                 input_grad=int(input_grad), mode=mode, name=name or "conv")
+    if via_model_file:
+        case["via_model_file"] = 1
     case["x"] = _u(rs, (n, c, h, w))
     case["wt"] = _u(rs, (f, cg, k, k), -a, a)
     case["bias"] = _u(rs, (f,), -0.5, 0.5)
@@ -68,6 +70,14 @@ def ref_conv(case):
         net.data(i_rm).reshape(-1)[...] = cs["run_mean0"]
         net.data(i_rv).reshape(-1)[...] = cs["run_var0"]
         net.data(i_sc).reshape(-1)[...] = cs["scales"]
+    if cs.get("via_model_file"):
+        # PREDICT-mode 3x3/s1 convolutions of the reference read Winograd-transformed weights that only
+        # bcnn_load_weights prepares (bcnn_net.c:1326-1346): round-trip the parameters through a model file
+        import os
+        import tempfile
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, "m.bcnnmodel")
+            assert net.save_weights(path) == 0 and net.load_weights(path) == 0
     net.forward()
     out["y"] = net.data(i_y).copy()
     f = cs["f"]

@@ -60,6 +60,13 @@ CASES = [
     rc.make_conv(110, 2, 36, 10, 10, 40, 2, 3, 0, name="conv_dma_c36_f40_k2s3_empty_classes"),
     rc.make_conv(111, 6, 64, 8, 8, 64, 3, 1, 1, bn=1, act=A.ACT_RELU, carry=True, name="conv_dma_bn_carry_c64_f64"),
     rc.make_conv(112, 2, 64, 12, 12, 96, 3, 2, 1, bn=1, act=A.ACT_RELU, name="conv_dma_bn_c64_f96_s2"),
+    # PREDICT mode, 3x3 / stride 1 / one group: the reference takes its Winograd F(2x2,3x3) path here
+    # (bcnn_conv_layer.c:388-436, bcnn_mat.c:1403-2138); this build runs the general kernels and has to stay within
+    # the conv tolerance of that result
+    rc.make_conv(140, 2, 16, 10, 12, 32, 3, 1, 1, act=A.ACT_RELU, mode=A.MODE_PREDICT, input_grad=False,
+                 via_model_file=True, name="conv_predict_winograd_ref_c16_f32"),
+    rc.make_conv(141, 2, 64, 9, 11, 72, 3, 1, 1, act=A.ACT_LRELU, mode=A.MODE_PREDICT, input_grad=False,
+                 via_model_file=True, name="conv_predict_winograd_ref_c64_f72"),
     # ---- stand-alone batchnorm -----------------------------------------------------------------
     rc.make_bn(30, 2, 3, 5, 5, name="bn_train"),
     rc.make_bn(31, 4, 8, 7, 9, carry=True, name="bn_train_carry"),
