@@ -106,6 +106,18 @@ def test_predict_mode_folds_batchnorm_like_the_reference(tmp_path):
         net.download(i, False)
         np.testing.assert_allclose(net.data(i), ref.data(i), rtol=0, atol=0,
                                    err_msg=ref.L.ref_tensor_name(ref.net, i).decode())
+    # inference on the loaded model: the reference runs its Winograd 3x3 path and the folded batch-norm here
+    x = np.random.RandomState(2).uniform(-1, 1, (2, 3, 10, 10)).astype(np.float32)
+    ref.data(0)[...] = x
+    net.data(0)[...] = x
+    net.upload(0)
+    ref.forward()
+    net.forward()
+    for name in ("c1", "c2", "dw", "bn", "fc"):
+        i = ref.index(name)
+        net.download(i, False)
+        scale = max(float(np.abs(ref.data(i)).max()), 1e-6)
+        assert float(np.abs(net.data(i) - ref.data(i)).max()) <= 1e-4 * scale, name
 
 
 def test_darknet_layout(tmp_path):
