@@ -23,11 +23,27 @@
 #include "conv_common.h"
 #include "lds_dma.h"
 
+// ---- compile-time tuning knobs (defaults = what is measured best; tools/exp/build_variant.sh DEFS=-D... builds
+// an alternative library for A/B runs). ABL_* macros (ABL_NODMA, ABL_NOBAR, ABL_NOSTORE, ABL_SETPRIO, ABL_CLOCK)
+// are ablation / instrumentation switches that are never defined in the product build.
+#ifndef DMA_BK
+#define DMA_BK 16            // reduction rows per K-tile; 32 halves the barriers at twice the LDS: +-0
+#endif
+#ifndef DMA_NSTAGE
+#define DMA_NSTAGE 2         // LDS ring depth; 3 costs occupancy and is 3-6 % slower on the 14x14 / 7x7 layers
+#endif
+#ifndef DMA_A_X4
+#define DMA_A_X4 1           // A^T rows four at a time with 16-byte-per-lane LDS-DMA (BM == 64 tiles)
+#endif
+#ifndef DMA_UNROLL_STAGES
+#define DMA_UNROLL_STAGES 0  // K loop unrolled by the ring depth: fewer VALU, yet 1-5 % slower on the ResNet shapes
+#endif
+#ifndef ABL_LB
+#define ABL_LB 1             // second argument of __launch_bounds__
+#endif
+
 namespace bcnn_hip {
 
-#ifndef DMA_BK
-#define DMA_BK 16
-#endif
 constexpr int kDmaBK = DMA_BK;   // reduction rows per K-tile (one barrier per tile)
 constexpr int kDmaMaxTaps = 49;
 constexpr int kDmaMaxClasses = 4;
@@ -68,9 +84,6 @@ struct DmaArgs {
     DmaClass cls[kDmaMaxClasses];
 };
 
-#ifndef ABL_LB
-#define ABL_LB 1
-#endif
 template <int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(64 * WM * WN, ABL_LB) void conv_igemm_dma_kernel(const DmaArgs a) {
     constexpr int BK = kDmaBK;
@@ -85,9 +98,6 @@ __global__ __launch_bounds__(64 * WM * WN, ABL_LB) void conv_igemm_dma_kernel(co
     static_assert((NW == 4 || NW == 2) && BM % 64 == 0 && (BN % 64 == 0 || BN == 32), "tile");
     // one block of LDS: As[NS][BK][BM] | Bs[NS][BK][BN]; after the K loop the same bytes hold one 32x32
     // transposition pad per wave for the fused statistics
-#ifndef DMA_NSTAGE
-#define DMA_NSTAGE 2
-#endif
     // LDS ring depth: the DMA runs NS - 1 tiles ahead of the MFMAs. 3 stages measured no faster than 2 on any
     // ResNet shape and 3-6 % slower on the 14x14 / 7x7 layers (24 KB instead of 16 KB of LDS: 6 instead of 8
     // resident workgroups per CU) -- with 8 waves per SIMD the DMA latency is already hidden.
@@ -189,9 +199,6 @@ __global__ __launch_bounds__(64 * WM * WN, ABL_LB) void conv_igemm_dma_kernel(co
 #pragma unroll
     for (int h = 0; h < AH; ++h) a_voff[h] = (unsigned)(h * 64 + lane) * 4u;
     // BM == 64: four consecutive A^T rows are one 16-byte-per-lane DMA (lane -> row lane / 16, columns 4 * (lane % 16) ..)
-#ifndef DMA_A_X4
-#define DMA_A_X4 1
-#endif
     constexpr bool AX4 = DMA_A_X4 && (AH == 1) && (RPW % 4 == 0);
     const unsigned a_voff4 = ((unsigned)(lane >> 4) * (unsigned)a.Mpad + (unsigned)(lane & 15) * 4u) * 4u;
     const int JB = a.Jpad / BK;
@@ -299,9 +306,6 @@ __global__ __launch_bounds__(64 * WM * WN, ABL_LB) void conv_igemm_dma_kernel(co
             fill = (fill + 1 == NS) ? 0 : fill + 1;
         }
     };
-#ifndef DMA_UNROLL_STAGES
-#define DMA_UNROLL_STAGES 0  // measured: the unrolled form is 1-5 % SLOWER on the ResNet shapes despite the fewer VALU
-#endif
     if (NS == 2 && DMA_UNROLL_STAGES) {
         int it = 0;
         for (; it + 1 < ntiles; it += 2) {
