@@ -325,6 +325,7 @@ static void mark_dead_grad_fills(bcnn_net *net) {
     bcnn_hip_context *hc = hctx(net);
     free(hc->grad_fill_dead);
     hc->grad_fill_dead = (unsigned char *)calloc((size_t)net->num_tensors + 1, 1);
+    if (getenv("BCNN_KEEP_ALL_GRAD_FILLS")) return; /* debugging switch: zero every dst gradient like the reference */
     for (int t = 0; t < net->num_tensors; ++t) {
         int first = -1;
         for (int i = 0; i < net->num_nodes && first < 0; ++i)

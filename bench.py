@@ -39,12 +39,14 @@ MFMA_F32_PEAK_TF = 157.3   # fp32-input MFMA dense peak (v_mfma_f32_32x32x2_f32)
 # ---------------------------------------------------------------------------------------------------
 # graph
 # ---------------------------------------------------------------------------------------------------
-def build_resnet18(net, A, classes=1000):
-    """A = module with ACT_* / PADDING_* constants (capi for the device net, ref_bind for the reference)."""
-    net.conv(64, 7, 2, 3, 1, 1, A.ACT_RELU, "input", "conv0")
+def build_resnet18(net, A, classes=1000, base=64):
+    """A = module with ACT_* / PADDING_* constants (capi for the device net, ref_bind for the reference).
+    base = stem width (64 = ResNet-18; tests/test_resnet18_parity.py also builds the half-width graph, the widest
+    one the reference's in-tree gemm computes correctly -- DESIGN.md section 5, quirk 8)."""
+    net.conv(base, 7, 2, 3, 1, 1, A.ACT_RELU, "input", "conv0")
     net.maxpool(3, 2, A.PADDING_SAME, "conv0", "pool0")
     src = "pool0"
-    for stage, width in enumerate((64, 128, 256, 512), start=1):
+    for stage, width in enumerate((base, 2 * base, 4 * base, 8 * base), start=1):
         for blk in (1, 2):
             down = stage > 1 and blk == 1
             a, b, out = "s%db%d_c1" % (stage, blk), "s%db%d_c2" % (stage, blk), "s%db%d" % (stage, blk)

@@ -1,0 +1,108 @@
+"""The benchmark graph itself (bench.py: build_resnet18 -- fused-BN convs, eltwise-ReLU shortcuts incl. quirk 5, 1x1/s2
+projections, maxpool, avgpool, fc, softmax, cost) against the unmodified reference, end to end.
+
+* half width (32..256 channels): one full training step -- every activation, every gradient, the updated
+  parameters. This is the widest ResNet-18 the reference's in-tree gemm gets right (DESIGN.md section 5, quirk 8:
+  its transposed-operand block offsets break for C/g*k*k > 4096 in dW and F/g > 384 in dX;
+  tests/test_reference_gemm_limits.py pins both limits).
+* full width (64..512): forward of every tensor against the reference (its forward gemm is sound at any size);
+  the backward of the 512-channel layers is covered against torch fp64 in test_reference_gemm_limits.py.
+
+Tolerances are looser than the per-operator 1e-4 because ~20 batch-normalised layers amplify rounding differences
+(the last stages normalise over as few as 72 samples per channel here)."""
+import numpy as np
+import pytest
+
+from oracle import ref_bind as rb
+
+pytestmark = pytest.mark.gpu
+
+SHAPE = dict(w=96, h=96, c=3, n=8)
+CLASSES = 10
+
+
+def _pair(base):
+    import bench
+    from bcnn_amd import capi
+    ref = rb.RefNet(mode=rb.MODE_TRAIN, **SHAPE)
+    ref.L.ref_set_threads(ref.net, 8)
+    hip = capi.Net(mode=capi.MODE_TRAIN, **SHAPE)
+    bench.build_resnet18(ref, rb, classes=CLASSES, base=base)
+    bench.build_resnet18(hip, capi, classes=CLASSES, base=base)
+    ref.compile()
+    hip.compile()
+    ref.L.bcnn_set_sgd_optimizer(ref.net, 0.01, 0.9)
+    ref.L.bcnn_set_weight_regularizer(ref.net, 5e-4)
+    hip.set_sgd(0.01, 0.9, 5e-4)
+    nt = ref.L.ref_num_tensors(ref.net)
+    names = [ref.L.ref_tensor_name(ref.net, i).decode() for i in range(nt)]
+    rs = np.random.RandomState(5)
+    for i in range(2, nt):  # same parameters on both sides; non-trivial BN scales and biases
+        d = ref.data(i)
+        if names[i].endswith("_scales"):
+            d[...] = rs.uniform(0.8, 1.2, d.shape)
+        elif names[i].endswith("_b"):
+            d[...] = rs.uniform(-0.1, 0.1, d.shape)
+        assert hip.shape(i) == ref.shape(i), names[i]
+        hip.data(i)[...] = d
+        hip.upload(i)
+    x = rs.uniform(-1, 1, ref.shape(0)).astype(np.float32)
+    lab = np.zeros(ref.shape(1), np.float32)
+    lab[np.arange(SHAPE["n"]), rs.randint(0, CLASSES, SHAPE["n"])] = 1.0
+    for net in (ref, hip):
+        net.data(0)[...] = x
+        net.data(1)[...] = lab
+    hip.upload(0)
+    hip.upload(1)
+    return ref, hip, names
+
+
+def _worst(ref, hip, names, kinds):
+    worst = {k: (0.0, "") for k in kinds}
+    for i, name in enumerate(names):
+        if not ref.tensor(i).data:
+            continue
+        hip.download(i)
+        for kind in kinds:
+            a, b = (hip.data(i), ref.data(i)) if kind == "data" else (hip.grad(i), ref.grad(i))
+            if b is None or (kind == "grad" and i == 1) or np.abs(b).max() <= 1e-6:
+                continue
+            err = float(np.abs(a.astype(np.float64) - b).max() / float(np.abs(b).max()))
+            if err > worst[kind][0]:
+                worst[kind] = (err, name)
+    return worst
+
+
+def test_resnet18_half_width_training_step_matches_reference():
+    if not rb.available():
+        pytest.skip("oracle/_ref not present")
+    ref, hip, names = _pair(base=32)
+    for net in (ref, hip):
+        net.forward()
+        net.backward()
+    worst = _worst(ref, hip, names, ("data", "grad"))
+    assert worst["data"][0] < 2e-3, worst
+    assert worst["grad"][0] < 2e-2, worst
+    ref.L.bcnn_update(ref.net)
+    hip.update()
+    for i, name in enumerate(names):
+        if i >= 2 and (name.endswith("_w") or name.endswith("_b")):
+            hip.download(i, False)
+            err = float(np.abs(hip.data(i) - ref.data(i)).max() / max(float(np.abs(ref.data(i)).max()), 1e-12))
+            assert err < 1e-3, (name, err)
+    print("worst relative deviations:", worst)
+    ref.close()
+    hip.close()
+
+
+def test_resnet18_full_width_forward_matches_reference():
+    if not rb.available():
+        pytest.skip("oracle/_ref not present")
+    ref, hip, names = _pair(base=64)
+    ref.forward()
+    hip.forward()
+    worst = _worst(ref, hip, names, ("data",))
+    assert worst["data"][0] < 2e-3, worst
+    print("worst relative deviation:", worst)
+    ref.close()
+    hip.close()
