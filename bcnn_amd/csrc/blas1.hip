@@ -142,6 +142,27 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ w, float* 
     }
 }
 
+// ---- Adam -----------------------------------------------------------------------------------------
+// the weights half of bcnn_adam_update_cpu (bcnn_learner.c:119-129) in one pass instead of nine BLAS-1 sweeps:
+//   g += (decay*B)*w ; m = (1-b1)*g + b1*m ; v = (1-b2)*g*g + b2*v ; w += (-lr/B*mu) * m / (sqrt(v) + 1e-7) ; g = 0
+// every product and sum rounded separately like the reference's AVX loops (no contraction).
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, size_t n, float wd_b,
+                                                   float one_m_b1, float b1, float one_m_b2, float b2, float step) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float gi = g[i], wi = w[i];
+        gi = __fadd_rn(__fmul_rn(wi, wd_b), gi);
+        const float mi = __fadd_rn(__fmul_rn(one_m_b1, gi), __fmul_rn(b1, m[i]));
+        const float vi = __fadd_rn(__fmul_rn(one_m_b2, __fmul_rn(gi, gi)), __fmul_rn(b2, v[i]));
+        m[i] = mi;
+        v[i] = vi;
+        const float q = __fdiv_rn(mi, __fadd_rn(__fsqrt_rn(vi), 0.0000001f));
+        w[i] = __fadd_rn(__fmul_rn(q, step), wi);
+        g[i] = 0.f;
+    }
+}
+
 // one workgroup per table entry (<= BCNN_HIP_SGD_CHUNK elements of one buffer)
 __global__ __launch_bounds__(256) void sgd_chunks_kernel(const bcnn_hip_sgd_chunk* __restrict__ chunks, float wd_b,
                                                          float neg_lr_b, float momentum) {
@@ -243,6 +264,29 @@ void bcnn_hip_sgd_update(float* w, float* b, float* dw, float* db, size_t w_size
     if (w && dw && w_size) {
         sgd_kernel<<<stream_grid(w_size, 256), 256, 0, current_stream()>>>(w, dw, w_size, decay * batch_size,
                                                                          neg_lr_b, momentum);
+        KERNEL_CHECK();
+    }
+}
+
+void bcnn_hip_adam_update(float* w, float* b, float* dw, float* db, float* adam_m, float* adam_v, size_t w_size,
+                          size_t b_size, int batch_size, int iter, float beta1, float beta2, float lr, float momentum,
+                          float decay) {
+    // bias correction exactly as the reference computes it on the host (bcnn_learner.c:111-112); `iter` is
+    // learner->seen there, i.e. SAMPLES seen, not iterations -- kept
+    const float mu = sqrtf(1.0f - powf(beta2, (float)iter + 1)) / (1.0f - powf(beta1, (float)iter + 1));
+    if (b && db && b_size) {  // biases take the plain momentum step (:113-117)
+        sgd_kernel<<<stream_grid(b_size, 256), 256, 0, current_stream()>>>(b, db, b_size, 0.f, -lr / batch_size,
+                                                                         momentum);
+        KERNEL_CHECK();
+    }
+    if (w && dw && w_size) {
+        if (!adam_m || !adam_v) {
+            fprintf(stderr, "[bcnn_hip] bcnn_hip_adam_update: moment buffers missing\n");
+            exit(1);
+        }
+        adam_kernel<<<stream_grid(w_size, 256), 256, 0, current_stream()>>>(
+            w, dw, adam_m, adam_v, w_size, decay * batch_size, 1.0f - beta1, beta1, 1.0f - beta2, beta2,
+            -lr / batch_size * mu);
         KERNEL_CHECK();
     }
 }

@@ -486,6 +486,11 @@ static void sgd_table_add(bcnn_hip_context *hc, float *w, float *g, size_t n, in
 void bcnn_update(bcnn_net *net) {
     bcnn_hip_context *hc = hctx(net);
     step_learning_rate(net);
+    if (net->learner->optimizer == BCNN_OPTIM_ADAM) { /* per-node launches; no one-launch table */
+        for (int i = 0; i < net->num_nodes; ++i)
+            if (net->nodes[i].update) net->nodes[i].update(net, &net->nodes[i]);
+        return;
+    }
     if (hc->sgd_chunks_gpu == NULL) {
         hc->sgd_collecting = 1;
         hc->num_sgd_chunks = 0;
@@ -521,6 +526,31 @@ void bcnn_node_sgd_step(bcnn_net *net, bcnn_tensor *weights, bcnn_tensor *biases
                         weights ? weights->grad_data_gpu : NULL, biases ? biases->grad_data_gpu : NULL,
                         weights ? (size_t)bcnn_tensor_size(weights) : 0, biases ? (size_t)bcnn_tensor_size(biases) : 0,
                         net->batch_size * world, ln->learning_rate, ln->momentum / (float)world, ln->decay);
+}
+
+/* Adam (reference bcnn_adam_update_cpu, bcnn_learner.c:106-131; reachable only through the INI key
+ * `optimizer=adam`, quirk 6). The moment buffers belong to the node's param block like the reference's
+ * adam_m_gpu / adam_v_gpu; they are created by the first step (the reference creates them in the builder
+ * when the learner already says Adam, and crashes otherwise). Under data parallelism the weight gradient
+ * carries nothing between steps (Adam zeroes it), so the all-reduced sum with the GLOBAL batch is the
+ * single-process step; the bias carry is divided by `world` like in bcnn_node_sgd_step. */
+void bcnn_node_optim_step(bcnn_net *net, bcnn_tensor *weights, bcnn_tensor *biases, float **adam_m_gpu,
+                          float **adam_v_gpu) {
+    const bcnn_learner *ln = net->learner;
+    if (ln->optimizer != BCNN_OPTIM_ADAM || adam_m_gpu == NULL) {
+        bcnn_node_sgd_step(net, weights, biases);
+        return;
+    }
+    const int world = hctx(net)->dp_world;
+    const size_t wsz = (size_t)bcnn_tensor_size(weights);
+    if (*adam_m_gpu == NULL) {
+        *adam_m_gpu = bcnn_hip_malloc_f32(wsz); /* zero-filled */
+        *adam_v_gpu = bcnn_hip_malloc_f32(wsz);
+    }
+    bcnn_hip_adam_update(weights->data_gpu, biases ? biases->data_gpu : NULL, weights->grad_data_gpu,
+                         biases ? biases->grad_data_gpu : NULL, *adam_m_gpu, *adam_v_gpu, wsz,
+                         biases ? (size_t)bcnn_tensor_size(biases) : 0, net->batch_size * world, ln->seen, ln->beta1,
+                         ln->beta2, ln->learning_rate, ln->momentum / (float)world, ln->decay);
 }
 
 static float current_loss(bcnn_net *net) {

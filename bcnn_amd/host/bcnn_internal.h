@@ -220,12 +220,17 @@ typedef struct bcnn_conv_param {
     float *conv_workspace_gpu;  /* = net hip_ctx workspace (dW split-K partials) */
     float *bn_workspace_gpu;    /* pre-normalisation conv output, kept for backward */
     float *x_norm_gpu;          /* NULL: recomputed in backward */
+    float *adam_m_gpu, *adam_v_gpu; /* weight moments, allocated by the first Adam step */
 #endif
 } bcnn_conv_param;
 
 typedef struct bcnn_depthwise_conv_param {
     int size, stride, pad, batch_norm;
     bcnn_activation activation;
+    float *adam_m, *adam_v;
+#ifdef BCNN_USE_HIP
+    float *adam_m_gpu, *adam_v_gpu;
+#endif
 } bcnn_depthwise_conv_param;
 
 typedef struct bcnn_batchnorm_param {
@@ -261,6 +266,9 @@ typedef struct bcnn_eltwise_param {
 typedef struct bcnn_fullc_param {
     bcnn_activation activation;
     float *adam_m, *adam_v;
+#ifdef BCNN_USE_HIP
+    float *adam_m_gpu, *adam_v_gpu;
+#endif
 } bcnn_fullc_param;
 
 typedef struct bcnn_cost_param {
@@ -285,6 +293,7 @@ void bcnn_release_param_conv_layer(bcnn_node *node);
 void bcnn_forward_depthwise_conv_layer(bcnn_net *net, bcnn_node *node);
 void bcnn_backward_depthwise_conv_layer(bcnn_net *net, bcnn_node *node);
 void bcnn_update_depthwise_conv_layer(bcnn_net *net, bcnn_node *node);
+void bcnn_release_param_depthwise_conv_layer(bcnn_node *node);
 void bcnn_forward_batchnorm_layer(bcnn_net *net, bcnn_node *node);
 void bcnn_backward_batchnorm_layer(bcnn_net *net, bcnn_node *node);
 void bcnn_release_param_batchnorm_layer(bcnn_node *node);
@@ -301,6 +310,7 @@ void bcnn_backward_eltwise_layer(bcnn_net *net, bcnn_node *node);
 void bcnn_forward_fullc_layer(bcnn_net *net, bcnn_node *node);
 void bcnn_backward_fullc_layer(bcnn_net *net, bcnn_node *node);
 void bcnn_update_fullc_layer(bcnn_net *net, bcnn_node *node);
+void bcnn_release_param_fullc_layer(bcnn_node *node);
 void bcnn_forward_softmax_layer(bcnn_net *net, bcnn_node *node);
 void bcnn_backward_softmax_layer(bcnn_net *net, bcnn_node *node);
 void bcnn_forward_cost_layer(bcnn_net *net, bcnn_node *node);
@@ -308,6 +318,8 @@ void bcnn_backward_cost_layer(bcnn_net *net, bcnn_node *node);
 
 /* SGD step on one node's parameters (bcnn_learner.c:67-104 in the reference) */
 void bcnn_node_sgd_step(bcnn_net *net, bcnn_tensor *weights, bcnn_tensor *biases);
+void bcnn_node_optim_step(bcnn_net *net, bcnn_tensor *weights, bcnn_tensor *biases, float **adam_m_gpu,
+                          float **adam_v_gpu); /* SGD or Adam according to net->learner->optimizer */
 
 #ifdef __cplusplus
 }

@@ -169,9 +169,9 @@ void bcnn_backward_conv_layer(bcnn_net *net, bcnn_node *node) {
                            p->conv_workspace_gpu, hctx(net)->workspace_size);
 }
 
-void bcnn_update_conv_layer(bcnn_net *net, bcnn_node *node) {
-    if (net->learner->optimizer != BCNN_OPTIM_SGD) return; /* Adam: out of scope (only reachable via INI) */
-    bcnn_node_sgd_step(net, &net->tensors[node->src[1]], &net->tensors[node->src[2]]);
+void bcnn_update_conv_layer(bcnn_net *net, bcnn_node *node) { /* reference bcnn_conv_layer.c:810-855 */
+    bcnn_conv_param *p = (bcnn_conv_param *)node->param;
+    bcnn_node_optim_step(net, &net->tensors[node->src[1]], &net->tensors[node->src[2]], &p->adam_m_gpu, &p->adam_v_gpu);
 }
 
 void bcnn_release_param_conv_layer(bcnn_node *node) {
@@ -180,6 +180,8 @@ void bcnn_release_param_conv_layer(bcnn_node *node) {
     bcnn_tensor_destroy(&p->saved_variance);
     bcnn_hip_free(p->bn_workspace_gpu);
     bcnn_hip_free(p->x_norm_gpu);
+    bcnn_hip_free(p->adam_m_gpu);
+    bcnn_hip_free(p->adam_v_gpu);
 }
 
 /* ================================================================================================
@@ -210,6 +212,7 @@ bcnn_status bcnn_add_depthwise_conv_layer(bcnn_net *net, int size, int stride, i
     node.forward = bcnn_forward_depthwise_conv_layer;
     node.backward = bcnn_backward_depthwise_conv_layer;
     node.update = bcnn_update_depthwise_conv_layer;
+    node.release_param = bcnn_release_param_depthwise_conv_layer;
     const int oh = (s.h + 2 * pad - size) / stride + 1, ow = (s.w + 2 * pad - size) / stride + 1;
     BCNN_CHECK_STATUS(add_output(net, &node, s.n, s.c, oh, ow, dst_id));
     BCNN_CHECK_STATUS(bcnn_net_add_node(net, node));
@@ -235,9 +238,15 @@ void bcnn_backward_depthwise_conv_layer(bcnn_net *net, bcnn_node *node) {
                                 p->pad, (int)p->activation);
 }
 
-void bcnn_update_depthwise_conv_layer(bcnn_net *net, bcnn_node *node) {
-    if (net->learner->optimizer != BCNN_OPTIM_SGD) return;
-    bcnn_node_sgd_step(net, &net->tensors[node->src[1]], &net->tensors[node->src[2]]);
+void bcnn_update_depthwise_conv_layer(bcnn_net *net, bcnn_node *node) { /* bcnn_depthwise_conv_layer.c:565-610 */
+    bcnn_depthwise_conv_param *p = (bcnn_depthwise_conv_param *)node->param;
+    bcnn_node_optim_step(net, &net->tensors[node->src[1]], &net->tensors[node->src[2]], &p->adam_m_gpu, &p->adam_v_gpu);
+}
+
+void bcnn_release_param_depthwise_conv_layer(bcnn_node *node) {
+    bcnn_depthwise_conv_param *p = (bcnn_depthwise_conv_param *)node->param;
+    bcnn_hip_free(p->adam_m_gpu);
+    bcnn_hip_free(p->adam_v_gpu);
 }
 
 /* ================================================================================================

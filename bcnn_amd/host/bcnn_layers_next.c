@@ -139,6 +139,7 @@ bcnn_status bcnn_add_fullc_layer(bcnn_net *net, int output_size, bcnn_filler_typ
     node.forward = bcnn_forward_fullc_layer;
     node.backward = bcnn_backward_fullc_layer;
     node.update = bcnn_update_fullc_layer;
+    node.release_param = bcnn_release_param_fullc_layer;
     BCNN_CHECK_STATUS(bcnn_net_add_node(net, node));
     BCNN_INFO(net->log_ctx, "[Dense] %-8s (%4d x%4d x%4d) -> %-8s (%d)\n", src_id, s.w, s.h, s.c, dst_id, output_size);
     return BCNN_SUCCESS;
@@ -166,9 +167,15 @@ void bcnn_backward_fullc_layer(bcnn_net *net, bcnn_node *node) {
         bcnn_hip_gemm(0, 0, B, S, P, 1.0f, y->grad_data_gpu, P, w->data_gpu, S, 1.0f, x->grad_data_gpu, S); /* dx += dy W */
 }
 
-void bcnn_update_fullc_layer(bcnn_net *net, bcnn_node *node) {
-    if (net->learner->optimizer != BCNN_OPTIM_SGD) return;
-    bcnn_node_sgd_step(net, &net->tensors[node->src[1]], &net->tensors[node->src[2]]);
+void bcnn_update_fullc_layer(bcnn_net *net, bcnn_node *node) { /* reference bcnn_fc_layer.c:303-348 */
+    bcnn_fullc_param *p = (bcnn_fullc_param *)node->param;
+    bcnn_node_optim_step(net, &net->tensors[node->src[1]], &net->tensors[node->src[2]], &p->adam_m_gpu, &p->adam_v_gpu);
+}
+
+void bcnn_release_param_fullc_layer(bcnn_node *node) {
+    bcnn_fullc_param *p = (bcnn_fullc_param *)node->param;
+    bcnn_hip_free(p->adam_m_gpu);
+    bcnn_hip_free(p->adam_v_gpu);
 }
 
 /* ================================================================================================

@@ -147,6 +147,13 @@ def col2im(col, k, pad, stride, im):
     _lib.load().bcnn_hip_col2im(_f32(col), c, h, w, k, pad, stride, _f32(im))
 
 
+def adam_update(w, b, dw, db, adam_m, adam_v, batch_size, it, beta1, beta2, lr, momentum, decay):
+    """bcnn_adam_update_cpu (bcnn_learner.c:106-131)"""
+    _lib.load().bcnn_hip_adam_update(_f32(w), _f32(b), _f32(dw), _f32(db), _f32(adam_m), _f32(adam_v),
+                                     w.numel() if w is not None else 0, b.numel() if b is not None else 0,
+                                     batch_size, it, beta1, beta2, lr, momentum, decay)
+
+
 def sgd_update(w, b, dw, db, batch_size, lr, momentum, decay):
     """bcnn_sgd_update_cpu (bcnn_learner.c:67-83)"""
     _lib.load().bcnn_hip_sgd_update(_f32(w), _f32(b), _f32(dw), _f32(db), w.numel() if w is not None else 0,

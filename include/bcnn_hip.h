@@ -213,6 +213,16 @@ void bcnn_hip_sgd_update(float *w_d, float *b_d, float *dw_d, float *db_d, size_
                          size_t b_size, int batch_size, float learning_rate, float momentum,
                          float decay);
 
+/* Adam step.  Replaces bcnn_adam_update_gpu (bcnn_learner.c:133-163) with the semantics of
+ * bcnn_adam_update_cpu (:106-131): biases take the momentum-SGD step; weights
+ *   dw += (decay*batch)*w; m = (1-b1)*dw + b1*m; v = (1-b2)*dw^2 + b2*v;
+ *   w -= (lr/batch)*mu * m/(sqrt(v)+1e-7); dw = 0,  mu = sqrt(1-b2^(iter+1))/(1-b1^(iter+1)).
+ * `iter` is what the reference passes: learner->seen (samples, not steps). adam_m_d / adam_v_d are
+ * w_size floats each, zero before the first step, owned by the caller. */
+void bcnn_hip_adam_update(float *w_d, float *b_d, float *dw_d, float *db_d, float *adam_m_d,
+                          float *adam_v_d, size_t w_size, size_t b_size, int batch_size, int iter,
+                          float beta1, float beta2, float learning_rate, float momentum, float decay);
+
 /* The same step for MANY buffers in one launch (a net's update loop, bcnn_net.c:316-326, issues one
  * bcnn_sgd_update per node: ~40 tiny launches for ResNet-18). `chunks_d` is a device array of
  * bcnn_hip_sgd_chunk, each at most BCNN_HIP_SGD_CHUNK elements of one buffer; `use_decay` selects the

@@ -590,3 +590,34 @@ void orc_sgd_update(float *weights, float *biases, float *dweights, float *dbias
         scal(wsize, momentum, dweights);
     }
 }
+
+/* Adam: bcnn_learner.c:106-131. The nine BLAS-1 sweeps of the reference written per element with the same
+ * separately rounded operations (bcnn_axpby, bcnn_vmul, bcnn_pow(.,0.5) = powf, bcnn_add_scalar(1e-7),
+ * bcnn_vdiv -- AVX build: a plain division, bcnn_mat.c:293-306). `iter` is learner->seen at the call sites
+ * (bcnn_conv_layer.c:823), i.e. samples seen. */
+void orc_adam_update(float *weights, float *biases, float *dweights, float *dbiases, float *adam_m,
+                     float *adam_v, int wsize, int bsize, int batch, int iter, float beta1, float beta2,
+                     float lr, float momentum, float decay) {
+    const float mu = sqrtf(1.0f - powf(beta2, (float)iter + 1)) / (1.0f - powf(beta1, (float)iter + 1));
+    if (biases && dbiases) {
+        axpy(bsize, -lr / batch, dbiases, biases);
+        scal(bsize, momentum, dbiases);
+    }
+    if (weights && dweights) {
+        const float a1 = 1.0f - beta1, a2 = 1.0f - beta2, step = -lr / batch * mu;
+        axpy(wsize, decay * batch, weights, dweights);
+        for (int i = 0; i < wsize; ++i) {
+            volatile float t0 = a1 * dweights[i], t1 = beta1 * adam_m[i];
+            adam_m[i] = t0 + t1;
+            volatile float g2 = dweights[i] * dweights[i];
+            volatile float t2 = a2 * g2, t3 = beta2 * adam_v[i];
+            adam_v[i] = t2 + t3;
+            volatile float d = powf(adam_v[i], 0.5f);
+            d = d + 0.0000001f;
+            volatile float q = adam_m[i] / d;
+            volatile float upd = step * q;
+            weights[i] = upd + weights[i];
+            dweights[i] = 0.0f;
+        }
+    }
+}

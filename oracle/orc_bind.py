@@ -51,6 +51,7 @@ def lib():
         "orc_dw_forward": [fp, fp, fp, fp, i, i, i, i, i, i, i, i],
         "orc_dw_backward": [fp, fp, fp, fp, fp, fp, fp, i, i, i, i, i, i, i, i],
         "orc_sgd_update": [fp, fp, fp, fp, i, i, i, f, f, f],
+        "orc_adam_update": [fp, fp, fp, fp, fp, fp, i, i, i, i, f, f, f, f, f],
     }
     for name, args in sig.items():
         fn = getattr(L, name)
@@ -226,9 +227,21 @@ def orc_gemm(cs):
     return {"C": Cm}
 
 
+def orc_optim(cs):
+    from oracle.ref_cases import run_optim
+    L = lib()
+
+    def sgd(w, b, dw, db, batch, lr, mom, decay):
+        L.orc_sgd_update(P(w), P(b), P(dw), P(db), w.size, b.size, batch, lr, mom, decay)
+
+    def adam(w, b, dw, db, m, v, batch, it, b1, b2, lr, mom, decay):
+        L.orc_adam_update(P(w), P(b), P(dw), P(db), P(m), P(v), w.size, b.size, batch, it, b1, b2, lr, mom, decay)
+    return run_optim(cs, sgd, adam)
+
+
 def run_oracle(case, golden_out=None):
     op = str(case["op"])
     if op == "maxpool":
         return orc_maxpool(case, None if golden_out is None else golden_out.get("dy"))
     return {"conv": orc_conv, "bn": orc_bn, "avgpool": orc_avgpool, "act": orc_act, "dw": orc_dw,
-            "im2col": orc_im2col, "gemm": orc_gemm}[op](case)
+            "im2col": orc_im2col, "gemm": orc_gemm, "optim": orc_optim}[op](case)

@@ -5,6 +5,8 @@ and returns the arrays the reference produces for it. tests/golden/make_golden.p
 {inputs, outputs} as .npz fixtures; tests/ re-run the same dict through oracle/bcnn_oracle.c and
 through the HIP C-ABI and compare.
 """
+import ctypes as C
+
 import numpy as np
 
 from . import ref_bind as rb
@@ -384,7 +386,66 @@ def ref_gemm(case):
     return {"C": Cm}
 
 
-RUNNERS = {"conv": ref_conv, "bn": ref_bn, "maxpool": ref_maxpool, "avgpool": ref_avgpool,
+# --------------------------------------------------------------------------------------------
+# optimizer steps                                 src/bcnn_learner.c:67-83 (SGD), :106-131 (Adam)
+# --------------------------------------------------------------------------------------------
+def make_optim(seed, kind, wsize, bsize, steps=3, batch=4, lr=0.01, momentum=0.9, decay=5e-4, beta1=0.9,
+               beta2=0.999, name=None):
+    """`steps` updates; before step t the fresh gradients dw_t / db_t are ADDED to the gradient buffers (what a
+    backward pass does), so the momentum carry (SGD, biases) and the zeroing (Adam weights) are both exercised.
+    `iter` follows the call sites: learner->seen = (t+1)*batch."""
+    rs = np.random.RandomState(seed)
+    case = dict(op="optim", kind=kind, wsize=wsize, bsize=bsize, steps=steps, batch=batch, lr=float(lr),
+                momentum=float(momentum), decay=float(decay), beta1=float(beta1), beta2=float(beta2),
+                name=name or "optim_" + kind)
+    case["w0"] = _u(rs, (wsize,))
+    case["b0"] = _u(rs, (bsize,))
+    case["dw_steps"] = _u(rs, (steps, wsize)) * np.float32(batch)
+    case["db_steps"] = _u(rs, (steps, bsize)) * np.float32(batch)
+    # a few exact zeros: Adam's m/(sqrt(v)+1e-7) at v == 0
+    case["dw_steps"][:, :3] = 0.0
+    return case
+
+
+def run_optim(case, sgd, adam):
+    """shared by the reference, the oracle and the HIP runner: sgd/adam are callables on numpy-like buffers"""
+    cs = case
+    n = int(cs["steps"])
+    w, b = cs["w0"].copy(), cs["b0"].copy()
+    dw, db = np.zeros_like(w), np.zeros_like(b)
+    m, v = np.zeros_like(w), np.zeros_like(w)
+    for t in range(n):
+        dw += cs["dw_steps"][t]
+        db += cs["db_steps"][t]
+        if str(cs["kind"]) == "adam":
+            adam(w, b, dw, db, m, v, int(cs["batch"]), (t + 1) * int(cs["batch"]), float(cs["beta1"]),
+                 float(cs["beta2"]), float(cs["lr"]), float(cs["momentum"]), float(cs["decay"]))
+        else:
+            sgd(w, b, dw, db, int(cs["batch"]), float(cs["lr"]), float(cs["momentum"]), float(cs["decay"]))
+    out = {"w": w, "b": b, "dw": dw, "db": db}
+    if str(cs["kind"]) == "adam":
+        out.update(adam_m=m, adam_v=v)
+    return out
+
+
+def ref_optim(case):
+    L = rb.lib()
+    fp, i, f = C.POINTER(C.c_float), C.c_int, C.c_float
+    L.bcnn_sgd_update_cpu.argtypes = [fp, fp, fp, fp, i, i, i, f, f, f]
+    L.bcnn_sgd_update_cpu.restype = None
+    L.bcnn_adam_update_cpu.argtypes = [fp, fp, fp, fp, fp, fp, i, i, i, i, f, f, f, f, f]
+    L.bcnn_adam_update_cpu.restype = None
+
+    def sgd(w, b, dw, db, batch, lr, mom, decay):
+        L.bcnn_sgd_update_cpu(rb.fptr(w), rb.fptr(b), rb.fptr(dw), rb.fptr(db), w.size, b.size, batch, lr, mom, decay)
+
+    def adam(w, b, dw, db, m, v, batch, it, b1, b2, lr, mom, decay):
+        L.bcnn_adam_update_cpu(rb.fptr(w), rb.fptr(b), rb.fptr(dw), rb.fptr(db), rb.fptr(m), rb.fptr(v), w.size,
+                               b.size, batch, it, b1, b2, lr, mom, decay)
+    return run_optim(case, sgd, adam)
+
+
+RUNNERS = {"optim": ref_optim, "conv": ref_conv, "bn": ref_bn, "maxpool": ref_maxpool, "avgpool": ref_avgpool,
            "act": ref_act, "dw": ref_dw, "im2col": ref_im2col, "gemm": ref_gemm}
 
 

@@ -137,11 +137,32 @@ def hip_gemm(cs):
     return {"C": H(Cm)}
 
 
+def hip_optim(cs):
+    """same driver loop as the reference run (oracle/ref_cases.run_optim) on device buffers"""
+    n = int(cs["steps"])
+    w, b = D(cs["w0"]), D(cs["b0"])
+    dw, db = torch.zeros_like(w), torch.zeros_like(b)
+    m, v = torch.zeros_like(w), torch.zeros_like(w)
+    adam = str(cs["kind"]) == "adam"
+    for t in range(n):
+        dw += D(cs["dw_steps"][t])
+        db += D(cs["db_steps"][t])
+        if adam:
+            ops.adam_update(w, b, dw, db, m, v, int(cs["batch"]), (t + 1) * int(cs["batch"]), float(cs["beta1"]),
+                            float(cs["beta2"]), float(cs["lr"]), float(cs["momentum"]), float(cs["decay"]))
+        else:
+            ops.sgd_update(w, b, dw, db, int(cs["batch"]), float(cs["lr"]), float(cs["momentum"]), float(cs["decay"]))
+    out = {"w": H(w), "b": H(b), "dw": H(dw), "db": H(db)}
+    if adam:
+        out.update(adam_m=H(m), adam_v=H(v))
+    return out
+
+
 def run_hip(case, exp=None):
     op = str(case["op"])
     if op == "maxpool":
         return hip_maxpool(case, exp)
     out = {"conv": hip_conv, "bn": hip_bn, "avgpool": hip_avgpool, "act": hip_act, "dw": hip_dw,
-           "im2col": hip_im2col, "gemm": hip_gemm}[op](case)
+           "im2col": hip_im2col, "gemm": hip_gemm, "optim": hip_optim}[op](case)
     torch.cuda.synchronize()
     return out

@@ -116,6 +116,11 @@ CASES = [
     rc.make_gemm(102, 1, 0, 27, 50, 8, beta=0.0, name="gemm_tn_beta0"),
     rc.make_gemm(103, 1, 1, 13, 17, 19, alpha=0.5, beta=2.0, name="gemm_tt"),
     rc.make_gemm(104, 0, 0, 70, 300, 200, name="gemm_nn_multi_panel"),
+    # ---- optimizer steps (next row f-1): three updates with fresh gradients added in between ---------
+    rc.make_optim(150, "sgd", 1000, 37, name="optim_sgd_momentum_decay"),
+    rc.make_optim(151, "sgd", 77, 5, momentum=0.0, decay=0.0, name="optim_sgd_plain"),
+    rc.make_optim(152, "adam", 1000, 37, name="optim_adam"),
+    rc.make_optim(153, "adam", 77, 5, lr=0.001, decay=0.0, beta1=0.8, beta2=0.99, batch=16, name="optim_adam_b16"),
 ]
 
 
