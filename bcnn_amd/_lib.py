@@ -59,7 +59,7 @@ SIGNATURES = {
     "bcnn_hip_conv_forward": (None, [vp, vp, vp, vp] + [i] * 10 + [vp, i, vp, vp, vp, vp, vp, vp, vp, i]),
     "bcnn_hip_conv_backward": (None, [vp] * 8 + [i] * 10 + [vp, vp, i] + [vp] * 8 + [vp, sz]),
     "bcnn_hip_maxpool_forward": (None, [vp, vp, vp] + [i] * 8),
-    "bcnn_hip_maxpool_backward": (None, [vp, vp, vp] + [i] * 8),
+    "bcnn_hip_maxpool_backward": (None, [vp, vp, vp] + [i] * 9),
     "bcnn_hip_avgpool_forward": (None, [vp, vp, i, i, i, i]),
     "bcnn_hip_avgpool_backward": (None, [vp, vp, i, i, i, i]),
     "bcnn_hip_depthwise_forward": (None, [vp, vp, vp, vp] + [i] * 8),
@@ -68,7 +68,7 @@ SIGNATURES = {
     "bcnn_hip_sgd_update_chunks": (None, [vp, i, i, f, f, f]),
     "bcnn_hip_adam_update": (None, [vp, vp, vp, vp, vp, vp, sz, sz, i, i, f, f, f, f, f]),
     "bcnn_hip_eltwise_forward": (None, [vp, vp, vp, sz, sz, i]),
-    "bcnn_hip_eltwise_backward": (None, [vp, vp, vp, vp, sz, sz, i]),
+    "bcnn_hip_eltwise_backward": (None, [vp, vp, vp, vp, sz, sz, i, i]),
     "bcnn_hip_axpy_strided": (None, [i, f, vp, vp] + [i] * 11),
     "bcnn_hip_add_rowvec": (None, [vp, vp, i, i]),
     "bcnn_hip_softmax_forward": (None, [vp, vp, i, i, i]),

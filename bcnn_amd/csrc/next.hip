@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void eltwise_fwd_kernel(const float* __restric
 
 __global__ __launch_bounds__(256) void eltwise_bwd_kernel(const float* __restrict__ y, float* __restrict__ dy,
                                                           float* __restrict__ da, float* __restrict__ db, size_t n,
-                                                          size_t b_count, int act) {
+                                                          size_t b_count, int act, int overwrite_a) {
     const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
     for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
         if (i + 4 <= n) {
@@ -66,7 +66,8 @@ __global__ __launch_bounds__(256) void eltwise_bwd_kernel(const float* __restric
                 *reinterpret_cast<float4*>(dy + i) = g;
             }
             if (da) {
-                float4 t = *reinterpret_cast<const float4*>(da + i);
+                // overwrite_a: da holds zeros semantically (its fill was skipped); 0.f + g keeps the sign of zero
+                float4 t = overwrite_a ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(da + i);
                 t.x += g.x; t.y += g.y; t.z += g.z; t.w += g.w;
                 *reinterpret_cast<float4*>(da + i) = t;
             }
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(256) void eltwise_bwd_kernel(const float* __restric
             for (size_t k = i; k < n; ++k) {
                 float gk = dy[k];
                 if (act != BCNN_HIP_ACT_NONE) { gk *= act_bwd_cheap(y[k], act, 0.f); dy[k] = gk; }
-                if (da) da[k] += gk;
+                if (da) da[k] = (overwrite_a ? 0.f : da[k]) + gk;
                 if (db && k < b_count) db[k] += gk;
             }
         }
@@ -160,15 +161,18 @@ void bcnn_hip_eltwise_forward(const float* a, const float* b, float* y, size_t n
     KERNEL_CHECK();
 }
 
-void bcnn_hip_eltwise_backward(const float* y, float* dy, float* da, float* db, size_t n, size_t b_count, int act) {
+void bcnn_hip_eltwise_backward(const float* y, float* dy, float* da, float* db, size_t n, size_t b_count, int act,
+                               int overwrite_a) {
     if (!n) return;
     if (!act_bwd_is_cheap(act) || !aligned16(y) || !aligned16(dy) || !aligned16(da) || !aligned16(db)) {
         bcnn_hip_activation_backward(y, dy, n, act, nullptr, nullptr, 1, 1);
+        if (da && overwrite_a) bcnn_hip_fill_f32(da, n, 0.f);
         if (da) bcnn_hip_axpy(n, 1.0f, dy, da);
         if (db) bcnn_hip_axpy(b_count, 1.0f, dy, db);
         return;
     }
-    eltwise_bwd_kernel<<<stream_grid(n / 4 + 1, 256), 256, 0, current_stream()>>>(y, dy, da, db, n, b_count, act);
+    eltwise_bwd_kernel<<<stream_grid(n / 4 + 1, 256), 256, 0, current_stream()>>>(y, dy, da, db, n, b_count, act,
+                                                                                   overwrite_a);
     KERNEL_CHECK();
 }
 

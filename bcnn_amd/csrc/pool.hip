@@ -111,6 +111,9 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
 // Same gather, vectorised: one thread per 4 consecutive source pixels of a row (16-byte read-modify-write of
 // dx, one division per 4 elements). The windows covering the 4 pixels are visited
 // in ascending output order, so every dx element still sees its additions in the reference's order.
+// OVERWRITE: dx is known to hold zeros semantically (the executor proved this node is its only writer and skipped
+// the zero fill): start from 0.f instead of loading, store always -- same sums bit for bit, a third of the traffic.
+template <bool OVERWRITE>
 __global__ __launch_bounds__(256) void maxpool_bwd_vec4_kernel(const float* __restrict__ dy, const int* __restrict__ idx,
                                                                float* __restrict__ dx, int H, int W, int OH, int OW,
                                                                int size, int stride) {
@@ -124,8 +127,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_vec4_kernel(const float* __re
     int j0 = (w0 - size + stride) / stride; if (w0 - size + 1 <= 0) j0 = 0;
     int i1 = h / stride; if (i1 > OH - 1) i1 = OH - 1;
     int j1 = (w0 + 3) / stride; if (j1 > OW - 1) j1 = OW - 1;
-    float4 v = *reinterpret_cast<const float4*>(dx + s0);
-    bool hit = false;
+    float4 v = OVERWRITE ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(dx + s0);
+    bool hit = OVERWRITE;
     for (int i = i0; i <= i1; ++i) {
         const int o = (plane * OH + i) * OW;
         for (int j = j0; j <= j1; ++j) {
@@ -190,16 +193,24 @@ void bcnn_hip_maxpool_forward(const float* x, float* y, int* indexes, int n, int
 }
 
 void bcnn_hip_maxpool_backward(const float* dy, const int* indexes, float* dx, int n, int c, int h, int w,
-                               int out_h, int out_w, int size, int stride) {
+                               int out_h, int out_w, int size, int stride, int overwrite) {
     const long long total = (long long)n * c * h * w;
-    if (!total || !(out_h * out_w)) return;
+    if (!total) return;
+    if (!(out_h * out_w)) {
+        if (overwrite) bcnn_hip_fill_f32(dx, (size_t)total, 0.f);
+        return;
+    }
     if ((w & 3) == 0 && total < 0x7fffffffLL && (long long)n * c <= 65535 &&
         (reinterpret_cast<uintptr_t>(dx) & 15) == 0) {
         dim3 grid((unsigned)ceil_div(h * (w / 4), 256), (unsigned)(n * c));
-        maxpool_bwd_vec4_kernel<<<grid, 256, 0, current_stream()>>>(dy, indexes, dx, h, w, out_h, out_w, size, stride);
+        if (overwrite)
+            maxpool_bwd_vec4_kernel<true><<<grid, 256, 0, current_stream()>>>(dy, indexes, dx, h, w, out_h, out_w, size, stride);
+        else
+            maxpool_bwd_vec4_kernel<false><<<grid, 256, 0, current_stream()>>>(dy, indexes, dx, h, w, out_h, out_w, size, stride);
         KERNEL_CHECK();
         return;
     }
+    if (overwrite) bcnn_hip_fill_f32(dx, (size_t)total, 0.f);
     maxpool_bwd_kernel<<<stream_grid((size_t)total, 256), 256, 0, current_stream()>>>(
         dy, indexes, dx, h, w, out_h, out_w, size, stride, (unsigned)total);
     KERNEL_CHECK();

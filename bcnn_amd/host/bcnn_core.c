@@ -327,13 +327,31 @@ static void mark_dead_grad_fills(bcnn_net *net) {
     hc->grad_fill_dead = (unsigned char *)calloc((size_t)net->num_tensors + 1, 1);
     if (getenv("BCNN_KEEP_ALL_GRAD_FILLS")) return; /* debugging switch: zero every dst gradient like the reference */
     for (int t = 0; t < net->num_tensors; ++t) {
-        int first = -1;
-        for (int i = 0; i < net->num_nodes && first < 0; ++i)
+        int first = -1, uses = 0;
+        for (int i = 0; i < net->num_nodes; ++i)
             for (int k = 0; k < net->nodes[i].num_src; ++k)
-                if (net->nodes[i].src[k] == t) { first = i; break; }
+                if (net->nodes[i].src[k] == t) {
+                    if (first < 0) first = i;
+                    ++uses;
+                }
         if (first < 0) continue;
         const bcnn_node *nd = &net->nodes[first];
         if (nd->src[0] != t) continue;
+        /* A gradient with exactly ONE writer that touches every element once per backward pass (max-pooling's
+         * gather; the full-size operand of a same-shape eltwise add) needs no fill either if that writer assigns
+         * `0 + sum` instead of accumulating: mark 2, the node's backward asks bcnn_grad_sole_writer(). Holds for
+         * the forward -> backward order every caller of the reference uses (bcnn_train_on_batch). */
+        if (uses == 1 && nd->type == BCNN_LAYER_MAXPOOL) {
+            hc->grad_fill_dead[t] = 2;
+            continue;
+        }
+        if (uses == 1 && nd->type == BCNN_LAYER_ELTWISE) {
+            const bcnn_eltwise_param *ep = (const bcnn_eltwise_param *)nd->param;
+            if (ep->stride[0] == 1 && ep->stride[1] == 1 &&
+                bcnn_tensor_size(&net->tensors[t]) == bcnn_tensor_size(&net->tensors[nd->dst[0]]))
+                hc->grad_fill_dead[t] = 2;
+            continue;
+        }
         if (nd->type == BCNN_LAYER_BATCHNORM) { /* stand-alone batch-norm writes dx = f(dy, x) everywhere (:292-296) */
             hc->grad_fill_dead[t] = 1;
             continue;
@@ -345,6 +363,11 @@ static void mark_dead_grad_fills(bcnn_net *net) {
         if (p->size == 1 && y->h * y->w != x->h * x->w) continue;
         hc->grad_fill_dead[t] = 1;
     }
+}
+
+int bcnn_grad_sole_writer(bcnn_net *net, int tensor) {
+    const bcnn_hip_context *hc = hctx(net);
+    return hc->grad_fill_dead && tensor >= 0 && tensor < net->num_tensors && hc->grad_fill_dead[tensor] == 2;
 }
 
 bcnn_status bcnn_compile_net(bcnn_net *net) {

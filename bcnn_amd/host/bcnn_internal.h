@@ -317,6 +317,7 @@ void bcnn_forward_cost_layer(bcnn_net *net, bcnn_node *node);
 void bcnn_backward_cost_layer(bcnn_net *net, bcnn_node *node);
 
 /* SGD step on one node's parameters (bcnn_learner.c:67-104 in the reference) */
+int bcnn_grad_sole_writer(bcnn_net *net, int tensor); /* 1: this gradient's zero fill was skipped, assign instead of += */
 void bcnn_node_sgd_step(bcnn_net *net, bcnn_tensor *weights, bcnn_tensor *biases);
 void bcnn_node_optim_step(bcnn_net *net, bcnn_tensor *weights, bcnn_tensor *biases, float **adam_m_gpu,
                           float **adam_v_gpu); /* SGD or Adam according to net->learner->optimizer */

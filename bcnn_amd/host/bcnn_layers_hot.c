@@ -359,7 +359,7 @@ void bcnn_backward_maxpool_layer(bcnn_net *net, bcnn_node *node) {
     bcnn_tensor *x = &net->tensors[node->src[0]], *y = &net->tensors[node->dst[0]];
     if (!x->grad_data_gpu) return;
     bcnn_hip_maxpool_backward(y->grad_data_gpu, p->indexes_gpu, x->grad_data_gpu, x->n, x->c, x->h, x->w, y->h, y->w,
-                              p->size, p->stride);
+                              p->size, p->stride, bcnn_grad_sole_writer(net, node->src[0]));
 }
 
 void bcnn_release_param_maxpool_layer(bcnn_node *node) {

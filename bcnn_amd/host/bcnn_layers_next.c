@@ -87,7 +87,8 @@ void bcnn_backward_eltwise_layer(bcnn_net *net, bcnn_node *node) {
     const size_t sz = (size_t)bcnn_tensor_size(y);
     if (p->stride[0] == 1 && p->stride[1] == 1) {
         bcnn_hip_eltwise_backward(y->data_gpu, y->grad_data_gpu, a->grad_data_gpu, b->grad_data_gpu, sz,
-                                  (size_t)p->min_dim[0] * y->h * y->w, (int)p->activation);
+                                  (size_t)p->min_dim[0] * y->h * y->w, (int)p->activation,
+                                  bcnn_grad_sole_writer(net, node->src[0]));
         return;
     }
     bcnn_hip_activation_backward(y->data_gpu, y->grad_data_gpu, sz, (int)p->activation, NULL, NULL, y->w * y->h, y->c);

@@ -89,11 +89,12 @@ def maxpool_forward(x, y, indexes, size, stride):
                                          size, stride)
 
 
-def maxpool_backward(dy, indexes, dx, size, stride):
-    """bcnn_backward_maxpool_layer_cpu (bcnn_maxpool_layer.c:258-273)"""
+def maxpool_backward(dy, indexes, dx, size, stride, overwrite=False):
+    """bcnn_backward_maxpool_layer_cpu (bcnn_maxpool_layer.c:258-273). overwrite: dx := 0 + sums (the caller skipped
+    the zero fill) instead of dx += sums."""
     n, c, h, w = dx.shape
     _lib.load().bcnn_hip_maxpool_backward(_f32(dy), _p(indexes), _f32(dx), n, c, h, w, dy.shape[2], dy.shape[3],
-                                          size, stride)
+                                          size, stride, 1 if overwrite else 0)
 
 
 def avgpool_forward(x, y):

@@ -181,13 +181,15 @@ void bcnn_hip_conv_backward(const float *x_d, const float *w_d, const float *bia
  *   maxpool: window at (i*stride, j*stride) (bottom/right padding only), rows outer / cols inner,
  *   first strict maximum wins, NaN never wins, indexes = flat int32 offset into the whole source
  *   tensor -- BIT-EXACT with the CPU path. backward: dx[indexes[o]] += dy[o], applied in ascending
- *   output order per source element (deterministic, same order as the CPU loop).
+ *   output order per source element (deterministic, same order as the CPU loop). overwrite != 0:
+ *   the caller guarantees dx is semantically all-zero (it skipped the zero fill of bcnn_net.c:361-375
+ *   because this node is the tensor's only gradient writer): dx is assigned 0 + the same sums.
  *   avgpool: global mean per (n,c); backward dx += dy/(h*w).
  * ------------------------------------------------------------------------------------------- */
 void bcnn_hip_maxpool_forward(const float *x_d, float *y_d, int *indexes_d, int n, int c, int h, int w,
                               int out_h, int out_w, int size, int stride);
 void bcnn_hip_maxpool_backward(const float *dy_d, const int *indexes_d, float *dx_d, int n, int c,
-                               int h, int w, int out_h, int out_w, int size, int stride);
+                               int h, int w, int out_h, int out_w, int size, int stride, int overwrite);
 void bcnn_hip_avgpool_forward(const float *x_d, float *y_d, int n, int c, int h, int w);
 void bcnn_hip_avgpool_backward(const float *dy_d, float *dx_d, int n, int c, int h, int w);
 
@@ -252,11 +254,12 @@ void bcnn_hip_sgd_update_chunks(const bcnn_hip_sgd_chunk *chunks_d, int num_chun
  *                  two axpys): y = act(a + b) where b only covers the first b_count elements (the
  *                  reference's stride-1 path adds the second operand to IMAGE 0 only -- quirk 5);
  *                  backward: g = dy * act'(y) stored over dy, da += g, db[i] += g[i] for i < b_count.
- *                  da_d / db_d may be NULL.
+ *                  da_d / db_d may be NULL. overwrite_a != 0: da is assigned 0 + g instead of da += g
+ *                  (same contract as bcnn_hip_maxpool_backward's overwrite).
  * ------------------------------------------------------------------------------------------- */
 void bcnn_hip_eltwise_forward(const float *a_d, const float *b_d, float *y_d, size_t n, size_t b_count, int act);
 void bcnn_hip_eltwise_backward(const float *y_d, float *dy_d, float *da_d, float *db_d, size_t n, size_t b_count,
-                               int act);
+                               int act, int overwrite_a);
 void bcnn_hip_axpy_strided(int num_batches, float a, const float *x_d, float *y_d, int stride_y,
                            int stride_x, int x_c, int x_h, int x_w, int y_c, int y_h, int y_w, int min_c,
                            int min_h, int min_w);

@@ -168,6 +168,9 @@ def test_resnet18_stem_maxpool_n128_112():
     dx = torch.zeros_like(x)
     ops.maxpool_backward(dy, idx, dx, k, s)
     torch.cuda.synchronize()
+    dx2 = torch.full_like(x, 9.0)  # the executor's no-fill mode: assign 0 + sums over whatever is there
+    ops.maxpool_backward(dy, idx, dx2, k, s, overwrite=True)
+    assert torch.equal(dx2.view(torch.int32), dx.view(torch.int32))  # bitwise, sign of zero included
     assert torch.equal(y, x.flatten()[idx.long().flatten()].view_as(y))  # gather identity, every element
     assert abs(float(dx.double().sum() - dy.double().sum())) <= 1e-6 * float(dy.double().abs().sum())
     for i in (0, 64, 127):  # bit-exact against the oracle: values, rebased indices, scatter order
