@@ -314,11 +314,18 @@ def main():
             else:
                 roof = {"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
+            # HBM bytes per launch of that class from the PMC passes (rocprofv3 cannot run inside this process):
+            # the committed summaries of `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` over this same
+            # command (tools/exp/bench_pmc.sh), corrected as MI355X_MICROARCH.md prescribes
             traffic = None
             if args.workload == "conv3x3" and name == "conv_fwd":
                 pmc = os.path.join(ROOT, "profiles", "r01_conv3x3_pmc.json")
                 if os.path.exists(pmc):
                     traffic = json.load(open(pmc)).get("conv_fwd_hbm_bytes_per_launch")
+            elif args.workload == "resnet18" and n == 128:
+                pmc = os.path.join(ROOT, "profiles", "r01_resnet18_pmc.json")
+                if os.path.exists(pmc):
+                    traffic = (json.load(open(pmc)).get("classes", {}).get(name) or {}).get("hbm_bytes_per_launch")
             roof.update({"traffic": traffic, "launches": d["launches"], "avg_ms": round(avg_ms, 4),
                          "algorithmic_flops_per_launch": d["flops"] / d["launches"],
                          "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
