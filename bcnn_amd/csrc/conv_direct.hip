@@ -17,6 +17,13 @@
 // Reference semantics as in conv_fwd.hip / conv_bwd.hip (bcnn_conv_layer.c:367-587).
 #include "conv_common.h"
 
+// Cache policy of the result stores: 2 = nt (non-temporal). The output of a small-K layer is a stream far larger
+// than L2 + Infinity Cache; written "nt" it does not displace the input taps there (configs[1]: forward -3 %, and the
+// dW pass that follows no longer competes with the write-back of dirty output lines: 0.50 -> 0.46 ms).
+#ifndef STORE_AUX
+#define STORE_AUX 2
+#endif
+
 namespace bcnn_hip {
 
 struct f4u { float x, y, z, w; } __attribute__((packed, aligned(4)));  // 16-byte load, 4-byte aligned
@@ -141,28 +148,45 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_direct_kernel(const ConvDirec
         return qvalid ? m : 0u;
     };
     auto ldx = [&](unsigned off) -> float {
+#ifdef ABL_NOLOAD
+        return __builtin_bit_cast(float, (off & 0x007fffffu) | 0x3f800000u);
+#else
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off, 0, 0));
+#endif
     };
 
-    int t = t_begin + wid;
-    float bfrag[KS];
-    if (t < t_end) {
-        locate(t);
-        const unsigned m = tap_mask();
+    // ---- tile pipeline ---------------------------------------------------------------------------
+    // gfx9-family waves have ONE counter (vmcnt) for loads and stores, and loads may overtake stores: a
+    // wait for operands issued BEFORE a tile's 32 stores has to wait for those stores too (the compiler
+    // emits vmcnt(0)), which parks the wave for a full HBM write round trip per tile. The order below
+    // makes every wait cover only work issued a whole tile earlier:
+    //     wait(all) ; store(t-1) ; load(t+1) ; MFMA(t)
+    // so the stores of tile t-1 and the operand loads of tile t+1 both fly under the MFMAs of tile t.
+    // Two operand buffers alternate (loop unrolled by two to keep them in fixed registers).
+    f32x16 acc[TM];
+    auto load_tile = [&](float (&buf)[KS]) {  // operands of the tile the lane state points at
+        if (__all(interior)) {  // every tap of every lane is inside the image: offset = pixel + tap, nothing else
+                                // (a tap with k >= K carries OOB = 2^31: pixel + 2^31 stays out of range for tensors < 1 GiB)
 #pragma unroll
-        for (int st = 0; st < KS; ++st) {
-            const unsigned tap = (tapbits[st >> 2] >> (8 * (st & 3))) & 0xffu;
-            bfrag[st] = ldx(((m >> tap) & 1u) ? pixb + koffb[st] : OOB);
+            for (int st = 0; st < KS; ++st) buf[st] = ldx(pixb + koffb[st]);
+        } else {                // border tile (or tail): invalid taps get an out-of-range offset => 0
+            const unsigned m = tap_mask();
+            unsigned tb[(KS + 3) / 4];
+#pragma unroll
+            for (int i = 0; i < (KS + 3) / 4; ++i) {
+                tb[i] = tapbits[i];
+                asm volatile("" : "+v"(tb[i]));  // keep the 4-per-register packing (no hoisted unpacked copies)
+            }
+#pragma unroll
+            for (int st = 0; st < KS; ++st) {
+                const unsigned tap = (tb[st >> 2] >> (8 * (st & 3))) & 0xffu;
+                buf[st] = ldx(((m >> tap) & 1u) ? pixb + koffb[st] : OOB);
+            }
         }
-    }
-    for (; t < t_end; t += 4) {
-        const unsigned ycur = ybyte;
-        const bool more = (t + 4 < t_end);  // wave-uniform
-        if (more) advance(t + 4);
-        const bool fast = __all(interior);
+    };
+    auto compute_tile = [&](const float (&buf)[KS]) {
         // the accumulators start from the bias (4 consecutive channels per 16-byte LDS read), so the
         // bias add costs no VALU: row(r) = (r&3) + 8*(r>>2) + 4*hi
-        f32x16 acc[TM];
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -173,35 +197,21 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_direct_kernel(const ConvDirec
                 acc[tm][rq * 4 + 2] = b4.z;
                 acc[tm][rq * 4 + 3] = b4.w;
             }
-        // MFMA step st consumes bfrag[st]; the same register is then refilled with the NEXT tile's
-        // operand, so the loads of the next tile fly under the MFMAs and stores of this one.
-        if (fast) {  // every tap of every lane is inside the image: offset = pixel + tap, nothing else
-                     // (a tap with k >= K carries OOB = 2^31: pixel + 2^31 stays out of range for tensors < 1 GiB)
 #pragma unroll
-            for (int st = 0; st < KS; ++st) {
+        for (int st = 0; st < KS; ++st)
 #pragma unroll
-                for (int tm = 0; tm < TM; ++tm) acc[tm] = mfma32(areg[tm][st], bfrag[st], acc[tm]);
-                bfrag[st] = ldx(pixb + koffb[st]);
+            for (int tm = 0; tm < TM; ++tm) {
+#ifdef ABL_NOMFMA
+                if (st == 0) acc[tm] = mfma32(areg[tm][st], buf[st], acc[tm]);
+                else acc[tm][st & 15] += areg[tm][st] * buf[st];
+#else
+                acc[tm] = mfma32(areg[tm][st], buf[st], acc[tm]);
+#endif
             }
-        } else {     // border tile (or tail): invalid taps get an out-of-range offset => 0
-            const unsigned m = more ? tap_mask() : 0u;
-            unsigned tb[(KS + 3) / 4];
-#pragma unroll
-            for (int i = 0; i < (KS + 3) / 4; ++i) {
-                tb[i] = tapbits[i];
-                asm volatile("" : "+v"(tb[i]));  // keep the 4-per-register packing (no hoisted unpacked copies)
-            }
-#pragma unroll
-            for (int st = 0; st < KS; ++st) {
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm) acc[tm] = mfma32(areg[tm][st], bfrag[st], acc[tm]);
-                const unsigned tap = (tb[st >> 2] >> (8 * (st & 3))) & 0xffu;
-                bfrag[st] = ldx(((m >> tap) & 1u) ? pixb + koffb[st] : OOB);
-            }
-        }
-
-        // epilogue on the accumulators: + bias, activation, one store per element.
-        // y[n][g*Mg + f][pix], f = tm*32 + (r&3) + 8*(r>>2) + 4*hi: registers r..r+3 are 4 consecutive channels
+    };
+    // epilogue on the accumulators: activation, one store per element.
+    // y[n][g*Mg + f][pix], f = tm*32 + (r&3) + 8*(r>>2) + 4*hi: registers r..r+3 are 4 consecutive channels
+    auto store_tile = [&](unsigned ycur) {
         unsigned fs = fstride;
         asm volatile("" : "+s"(fs));  // recompute the 32 scalar channel offsets per tile instead of pinning 32 SGPRs
 #pragma unroll
@@ -226,7 +236,7 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_direct_kernel(const ConvDirec
                 for (int r = 0; r < 16; ++r) {
                     const int fr = tm * 32 + (r & 3) + 8 * (r >> 2);  // + 4*hi is folded into ycur
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), ry, ycur,
-                                                          (unsigned)fr * fs, 0);
+                                                          (unsigned)fr * fs, STORE_AUX);
                 }
             } else {
 #pragma unroll
@@ -234,11 +244,68 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_direct_kernel(const ConvDirec
                     const int fr = tm * 32 + (r & 3) + 8 * (r >> 2);
                     const unsigned off = (fr + 4 * hi < s.Mg) ? ycur : OOB;  // rows beyond F/groups are dropped
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), ry, off,
-                                                          (unsigned)fr * fs, 0);
+                                                          (unsigned)fr * fs, STORE_AUX);
                 }
             }
         }
+    };
+
+    int t = t_begin + wid;
+    if (t >= t_end) return;
+    float bufA[KS], bufB[KS];
+    locate(t);
+    load_tile(bufA);
+    unsigned yprev = OOB;
+    bool have_prev = false;
+    // ablation switches for tools/exp (normal builds define none of them)
+#ifdef ABL_NOWAIT
+#define DIRECT_WAIT()
+#else
+#define DIRECT_WAIT() __builtin_amdgcn_s_waitcnt(0x0f70)
+#endif
+#ifdef ABL_NOSTORE
+#define DIRECT_STORE(y) do { if (a.act == 12345) store_tile(y); } while (0)
+#else
+#define DIRECT_STORE(y) store_tile(y)
+#endif
+    // one pipeline stage: `cur` holds tile t's operands (issued one stage ago), `nxt` receives tile t+4's
+#define DIRECT_STAGE(cur, nxt)                                                                          \
+    {                                                                                                   \
+        const unsigned ycur = ybyte;                                                                    \
+        const bool more = (t + 4 < t_end); /* wave-uniform */                                           \
+        DIRECT_WAIT();   /* vmcnt(0): operands of tile t, stores of tile t-8 */                          \
+        if (have_prev) DIRECT_STORE(yprev);                                                             \
+        if (more) {                                                                                     \
+            advance(t + 4);                                                                             \
+            load_tile(nxt);                                                                             \
+        }                                                                                               \
+        compute_tile(cur);                                                                              \
+        yprev = ycur;                                                                                   \
+        have_prev = true;                                                                               \
+        if (!more) break;                                                                               \
+        t += 4;                                                                                         \
     }
+    for (;;) {
+        DIRECT_STAGE(bufA, bufB)
+        DIRECT_STAGE(bufB, bufA)
+    }
+#undef DIRECT_STAGE
+    DIRECT_STORE(yprev);
+#undef DIRECT_STORE
+#undef DIRECT_WAIT
+}
+
+// Pulls a small tensor into the memory-side Infinity Cache (256 MB) ahead of a kernel that streams a much larger
+// result. Measured on configs[1]: with the 77 MB input resident there and the 1.6 GB output written with
+// non-temporal stores, HBM sees a pure write stream instead of writes finely interleaved with reads (bus
+// turnarounds) -- forward 0.45 -> 0.39 ms including this pass (15 us).
+__global__ __launch_bounds__(256) void cache_prefetch_kernel(const float4* __restrict__ p, size_t n4, float* sink) {
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 v = p[i];
+        acc += v.x + v.y + v.z + v.w;
+    }
+    if (acc == 123456.789f) *sink = acc;  // never true for finite data; keeps the loads alive
 }
 
 bool conv_forward_direct(const float* x, const float* w, const float* bias, const float* slopes, float* y,
@@ -261,6 +328,12 @@ bool conv_forward_direct(const float* x, const float* w, const float* bias, cons
     const int tm = (s.Mg <= 32) ? 1 : 2;
     KTimer kt(K_CONV_FWD, 2.0 * (double)s.total_q * s.Mg * s.K * s.groups,
               4.0 * ((double)s.N * s.C * s.HW + (double)s.F * s.K + (double)s.N * s.F * s.OHOW));
+    {   // input small enough for the Infinity Cache and dwarfed by the output: make the kernel's HBM traffic write-only
+        const size_t xb = (size_t)s.N * s.C * s.HW * 4, yb = (size_t)s.N * s.F * s.OHOW * 4;
+        static const bool pf_on = [] { const char* e = getenv("BCNN_HIP_NO_PREFETCH"); return !(e && e[0] == '1'); }();
+        if (pf_on && xb <= (128u << 20) && yb >= 4 * xb && yb >= (256u << 20) && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
+            cache_prefetch_kernel<<<kCUs * 8, 256, 0, current_stream()>>>(reinterpret_cast<const float4*>(x), xb / 16, y);
+    }
     const int actm = (a.act == BCNN_HIP_ACT_NONE) ? 0 : (a.act == BCNN_HIP_ACT_RELU ? 1 : 2);
 #define LAUNCH(TMv, KSv, KZ)                                                                            \
     do {                                                                                                \
