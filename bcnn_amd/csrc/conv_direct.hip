@@ -425,6 +425,10 @@ __device__ __forceinline__ DwFrag<TM> dw_load_window(const ConvDirectDwArgs& a, 
 template <int TM>
 __global__ __launch_bounds__(256) void conv_dw_direct_kernel(const ConvDirectDwArgs a) {
     __shared__ float red[3][TM * 32][33];
+#ifdef ABL_DW_LDSPAD   // occupancy experiment: extra LDS per workgroup
+    __shared__ float ldspad[ABL_DW_LDSPAD / 4];
+    if (a.nwin == -12345) ldspad[threadIdx.x] = 1.f, red[0][0][0] = ldspad[threadIdx.x ^ 1];
+#endif
     const ConvShape& s = a.s;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
