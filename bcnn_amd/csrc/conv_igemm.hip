@@ -344,6 +344,100 @@ void conv_forward_dispatch(const float* x, const float* w, const float* bias, co
     dispatch_igemm(a, s.total_q);
 }
 
+// ------------------------------------------------------------------------------------------------
+// dX for layers with very few input channels (K = C/g*k*k <= 32, e.g. the RGB layer of configs[1] when its source
+// carries a gradient). As an implicit GEMM the output has only C/g rows, so a 32-row MFMA tile idles 29 of them
+// (measured 6.9 TFLOP/s, 3.2 ms at configs[1]). The reference's own factorisation fits these shapes instead
+// (bcnn_conv_layer.c:563-577): col[K][q] = W^T[K x F] * dy[F][q] -- a GEMM with M = K <= 32 rows, all useful --
+// followed by col2im. col is produced for a chunk of images small enough to stay in the Infinity Cache and is
+// consumed at once by a gather-form col2im (each dx element sums its <= k*k contributions in ascending (kr,kc)
+// order, the order bcnn_col2im applies them in, bcnn_mat.c:935-970), so it never travels to HBM and back.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_weights_kernel(const float* __restrict__ w, float* __restrict__ wt,
+                                                                int F, int K) {
+    const int i = blockIdx.x * 256 + threadIdx.x;  // wt[k][f] = w[f][k]
+    if (i < F * K) wt[(i % K) * F + (i / K)] = w[i];
+}
+
+__global__ __launch_bounds__(256) void col2im_batch_kernel(const float* __restrict__ col, float* __restrict__ dx,
+                                                           int C, int H, int W, int ksz, int pad, int stride, int OH,
+                                                           int OW, unsigned total) {
+    const unsigned gs = gridDim.x * blockDim.x;
+    const int K = C * ksz * ksz, OHOW = OH * OW;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gs) {
+        const int iw = (int)(i % (unsigned)W);
+        unsigned t = i / (unsigned)W;
+        const int ih = (int)(t % (unsigned)H);
+        t /= (unsigned)H;
+        const int c = (int)(t % (unsigned)C), n = (int)(t / (unsigned)C);
+        const float* cn = col + ((size_t)n * K + (size_t)c * ksz * ksz) * OHOW;
+        float acc = 0.f;
+        for (int kr = 0; kr < ksz; ++kr) {
+            const int th = ih + pad - kr;
+            if (th < 0 || th % stride) continue;
+            const int oh = th / stride;
+            if (oh >= OH) continue;
+            for (int kc = 0; kc < ksz; ++kc) {
+                const int tw = iw + pad - kc;
+                if (tw < 0 || tw % stride) continue;
+                const int ow = tw / stride;
+                if (ow >= OW) continue;
+                acc += cn[(size_t)(kr * ksz + kc) * OHOW + oh * OW + ow];
+            }
+        }
+        dx[i] = acc;
+    }
+}
+
+struct ColScratch {
+    float* p = nullptr;
+    size_t cap = 0;
+    int dev = -1;
+};
+static thread_local ColScratch g_col_scratch;
+
+static float* col_scratch(size_t floats) {
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    ColScratch& sc = g_col_scratch;
+    if (sc.p == nullptr || sc.cap < floats || sc.dev != dev) {
+        if (sc.p && sc.dev == dev) HIP_CHECK(hipFree(sc.p));  // hipFree synchronises the device
+        HIP_CHECK(hipMalloc((void**)&sc.p, floats * sizeof(float)));
+        sc.cap = floats; sc.dev = dev;
+    }
+    return sc.p;
+}
+
+static bool conv_backward_data_small_c(const float* w, const float* dy, float* dx, const ConvShape& s) {
+    static const bool off = getenv("BCNN_HIP_NO_SMALLC_DX") != nullptr;
+    if (off || s.pointwise || s.groups != 1 || s.K > 32 || s.Mg < 32) return false;
+    if ((long long)s.N * s.C * s.HW >= (1LL << 31)) return false;
+    const size_t per_image = (size_t)s.K * s.OHOW;                      // col floats per image
+    int chunk = (int)(((size_t)96 << 20) / (per_image * sizeof(float)));  // <= 96 MB of col in flight
+    if (chunk < 1) chunk = 1;
+    if (chunk > s.N) chunk = s.N;
+    float* scratch = col_scratch((size_t)chunk * per_image + (size_t)s.K * s.Mg);
+    float* wt = scratch + (size_t)chunk * per_image;
+    transpose_weights_kernel<<<ceil_div(s.Mg * s.K, 256), 256, 0, current_stream()>>>(w, wt, s.Mg, s.K);
+    KERNEL_CHECK();
+    for (int n0 = 0; n0 < s.N; n0 += chunk) {
+        const int nb = (s.N - n0 < chunk) ? s.N - n0 : chunk;
+        // col = Wt * dy as a bare 1x1 "forward" over the chunk: source dy [nb][F][OH*OW], K output rows
+        const ConvShape g = make_conv_shape(nb, s.F, s.OH, s.OW, s.K, 1, 1, 0, 1);
+        IgemmArgs a;
+        a.a_base = wt; a.b_base = dy + (size_t)n0 * s.F * s.OHOW; a.out = scratch; a.bias = nullptr; a.slopes = nullptr;
+        a.s = g; a.mode = 0; a.act = BCNN_HIP_ACT_NONE; a.add_bias = 0;
+        a.M = g.Mg; a.KR = g.K; a.a_row_stride = g.K; a.a_group_stride = (long long)g.Mg * g.K;
+        a.ntaps = 1; a.ntaps_magic = magic_of(1); a.ksz_magic = magic_of(1); a.nclass = 1;
+        dispatch_igemm(a, g.total_q);
+        const long long total = (long long)nb * s.C * s.HW;
+        col2im_batch_kernel<<<stream_grid((size_t)total, 256), 256, 0, current_stream()>>>(
+            scratch, dx + (size_t)n0 * s.C * s.HW, s.C, s.H, s.W, s.ksz, s.pad, s.stride, s.OH, s.OW, (unsigned)total);
+        KERNEL_CHECK();
+    }
+    return true;
+}
+
 void conv_backward_data(const float* w, const float* dy, float* dx, const ConvShape& s) {
     if (s.total_p == 0 || s.Cg == 0) return;
     if (s.ksz > 7 && !s.pointwise) {
@@ -352,6 +446,7 @@ void conv_backward_data(const float* w, const float* dy, float* dx, const ConvSh
     }
     KTimer kt(K_CONV_DX, 2.0 * (double)s.total_q * s.Mg * s.K * s.groups,
               4.0 * ((double)s.N * s.C * s.HW + (double)s.F * s.K + (double)s.N * s.F * s.OHOW));
+    if (conv_backward_data_small_c(w, dy, dx, s)) return;
     if (dma_enabled() && conv_backward_data_dma(w, dy, dx, s)) return;
     IgemmArgs a;
     a.a_base = w; a.b_base = dy; a.out = dx; a.bias = nullptr; a.slopes = nullptr; a.s = s;

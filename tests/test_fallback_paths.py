@@ -12,8 +12,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{"BCNN_HIP_NO_DMA": "1"}, {"BCNN_HIP_NO_FUSED_STATS": "1"}],
-                         ids=["register_staged_kernels", "unfused_bn_statistics"])
+@pytest.mark.parametrize("env", [{"BCNN_HIP_NO_DMA": "1"}, {"BCNN_HIP_NO_FUSED_STATS": "1"},
+                                 {"BCNN_HIP_NO_SMALLC_DX": "1", "BCNN_HIP_NO_PREFETCH": "1"}],
+                         ids=["register_staged_kernels", "unfused_bn_statistics", "implicit_gemm_dx_for_small_c"])
 def test_golden_suite_on_the_other_code_path(env):
     e = dict(os.environ)
     e.update(env)
