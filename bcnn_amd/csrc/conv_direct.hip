@@ -168,7 +168,12 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_direct_kernel(const ConvDirec
         if (__all(interior)) {  // every tap of every lane is inside the image: offset = pixel + tap, nothing else
                                 // (a tap with k >= K carries OOB = 2^31: pixel + 2^31 stays out of range for tensors < 1 GiB)
 #pragma unroll
-            for (int st = 0; st < KS; ++st) buf[st] = ldx(pixb + koffb[st]);
+            for (int st = 0; st < KS; ++st) {
+#ifdef ABL_FEWGATHER   // timing experiment: only every ABL_FEWGATHER-th gather is real
+                if (st % ABL_FEWGATHER != 0) { buf[st] = buf[st - st % ABL_FEWGATHER]; continue; }
+#endif
+                buf[st] = ldx(pixb + koffb[st]);
+            }
         } else {                // border tile (or tail): invalid taps get an out-of-range offset => 0
             const unsigned m = tap_mask();
             unsigned tb[(KS + 3) / 4];
