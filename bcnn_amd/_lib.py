@@ -69,6 +69,7 @@ SIGNATURES = {
     "bcnn_hip_adam_update": (None, [vp, vp, vp, vp, vp, vp, sz, sz, i, i, f, f, f, f, f]),
     "bcnn_hip_eltwise_forward": (None, [vp, vp, vp, sz, sz, i]),
     "bcnn_hip_eltwise_backward": (None, [vp, vp, vp, vp, sz, sz, i, i]),
+    "bcnn_hip_cost_metric": (None, [i, vp, vp, vp, i, i, vp]),
     "bcnn_hip_axpy_strided": (None, [i, f, vp, vp] + [i] * 11),
     "bcnn_hip_add_rowvec": (None, [vp, vp, i, i]),
     "bcnn_hip_softmax_forward": (None, [vp, vp, i, i, i]),

@@ -292,11 +292,22 @@ void bcnn_forward_cost_layer(bcnn_net *net, bcnn_node *node) {
         bcnn_hip_axpy(sz, -1.0f, label->data_gpu, dst->grad_data_gpu);
     }
     if (net->mode == BCNN_MODE_PREDICT) return;
-    /* scalar metric on the host from read-back copies, like the reference's CUDA build */
-    if (dst->grad_data_gpu) bcnn_hip_memcpy_d2h(dst->grad_data, dst->grad_data_gpu, sz * sizeof(float));
-    bcnn_hip_memcpy_d2h(pred->data, pred->data_gpu, sz * sizeof(float));
-    dst->data[0] = host_metric(p, pred, label, dst);
-    bcnn_hip_memcpy_h2d(dst->data_gpu, dst->data, sizeof(float)); /* keep the mirror coherent for bcnn_get_tensor_* */
+    /* The scalar metric: the reference's CUDA build reads prediction, label and gradient back and loops on the
+     * host (bcnn_cost_layer.c:142-244); here one small kernel computes it from the device copies (the label's
+     * device copy is what the loader uploaded, bcnn_data.c:413-425) and only the 4-byte result is read back, so
+     * dst->data[0] is valid when bcnn_forward returns, as it is there. BCNN_HOST_COST_METRIC=1 keeps the host loop. */
+    static int host_loop = -1;
+    if (host_loop < 0) host_loop = getenv("BCNN_HOST_COST_METRIC") != NULL;
+    if (host_loop || !label->data_gpu || !dst->grad_data_gpu) {
+        if (dst->grad_data_gpu) bcnn_hip_memcpy_d2h(dst->grad_data, dst->grad_data_gpu, sz * sizeof(float));
+        bcnn_hip_memcpy_d2h(pred->data, pred->data_gpu, sz * sizeof(float));
+        dst->data[0] = host_metric(p, pred, label, dst);
+        bcnn_hip_memcpy_h2d(dst->data_gpu, dst->data, sizeof(float)); /* keep the mirror coherent */
+        return;
+    }
+    bcnn_hip_cost_metric((int)p->loss_metric, pred->data_gpu, label->data_gpu, dst->grad_data_gpu, pred->n,
+                         pred->w * pred->h * pred->c, dst->data_gpu);
+    bcnn_hip_memcpy_d2h(dst->data, dst->data_gpu, sizeof(float));
 }
 
 void bcnn_backward_cost_layer(bcnn_net *net, bcnn_node *node) {

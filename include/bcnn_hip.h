@@ -260,6 +260,11 @@ void bcnn_hip_sgd_update_chunks(const bcnn_hip_sgd_chunk *chunks_d, int num_chun
 void bcnn_hip_eltwise_forward(const float *a_d, const float *b_d, float *y_d, size_t n, size_t b_count, int act);
 void bcnn_hip_eltwise_backward(const float *y_d, float *dy_d, float *da_d, float *db_d, size_t n, size_t b_count,
                                int act, int overwrite_a);
+/* The cost node's scalar metric computed on the device (bcnn_compute_error, bcnn_cost_layer.c:142-244, which
+ * reads whole tensors back to the host): metric = bcnn_loss_metric value (0 error rate, 1 logloss, 2 SSE, 3 MSE,
+ * 4 CRPS, 5 dice); pred_d / label_d / grad_d are [batch][per]; the result is written to out_d[0]. */
+void bcnn_hip_cost_metric(int metric, const float *pred_d, const float *label_d, const float *grad_d, int batch,
+                          int per, float *out_d);
 void bcnn_hip_axpy_strided(int num_batches, float a, const float *x_d, float *y_d, int stride_y,
                            int stride_x, int x_c, int x_h, int x_w, int y_c, int y_h, int y_w, int min_c,
                            int min_h, int min_w);
