@@ -98,6 +98,10 @@ def test_net_matches_reference(gname):
     from bcnn_amd import capi
     build, shp, has_cost = GRAPHS[gname]
     rs = np.random.RandomState(7)
+    # the builders of BOTH libraries draw their Xavier weights from libc rand(): seed it, so the parameters (copied
+    # from the reference below) are the same in every run instead of depending on what else called rand() before
+    import ctypes
+    ctypes.CDLL(None).srand(20240607)
     ref = rb.RefNet(mode=rb.MODE_TRAIN, **shp)
     ref.L.ref_set_threads(ref.net, 4)  # the reference oversubscribes badly with one OpenMP thread per core
     hip = capi.Net(mode=capi.MODE_TRAIN, **shp)

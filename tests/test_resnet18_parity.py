@@ -24,6 +24,8 @@ CLASSES = 10
 def _pair(base):
     import bench
     from bcnn_amd import capi
+    import ctypes
+    ctypes.CDLL(None).srand(20240607)  # both builders draw from libc rand(): same parameters in every run
     ref = rb.RefNet(mode=rb.MODE_TRAIN, **SHAPE)
     ref.L.ref_set_threads(ref.net, 8)
     hip = capi.Net(mode=capi.MODE_TRAIN, **SHAPE)
