@@ -4,6 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/full; rm -rf $O; mkdir -p $O
 cd $R; SECONDS=0; python3 bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -2 $O/bench_default.err
 echo "default bench took $SECONDS s"; python3 bench.py --workload conv3x3 > $O/bench_conv3x3.json 2> $O/bench_conv3x3.err
+python3 bench.py --workload mobilenet --no-cpu-baseline > $O/bench_mobilenet.json 2> $O/bench_mobilenet.err
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --no-cpu-baseline > $O/bench_rocprof.json 2> $O/bench_rocprof.err
 cp $(find $O/kt -name "*kernel_stats.csv" | head -1) $O/resnet18_kernel_stats.csv
