@@ -193,14 +193,16 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_dw_dma_kernel(const DwDmaAr
 }
 
 // dW[g][f][c][tap] += sum_qs partials[qs][g][tap][f][c]   (fixed order => deterministic)
-// 64 outputs x 16 interleaved sub-sums per workgroup; threads run along c so the (qsplits x larger) partial
-// reads are coalesced and only the single dW read-modify-write is strided by the tap count. Each thread keeps
-// four independent loads in flight: with up to 64 splits 1 MB apart a single dependent chain per output is a
-// latency chain (measured 1.3 TB/s on MobileNet's pointwise layers before, 52 us per launch).
-__global__ __launch_bounds__(1024) void conv_dw_dma_finalize_kernel(const float* __restrict__ partials, int qsplits,
-                                                                    int groups, int Mg, int Cg, int kk2, int Mpad,
-                                                                    int Npad, float* __restrict__ dw) {
-    __shared__ float red[16][64];
+// 64 outputs x NSUB interleaved sub-sums per workgroup; threads run along c so the (qsplits x larger) partial
+// reads are coalesced and only the single dW read-modify-write is strided by the tap count. NSUB = 4 for the
+// 3x3 layers (7-8 splits); NSUB = 16 with four independent loads in flight per thread for the pointwise layers,
+// whose 32-64 splits lie 1 MB apart (a single dependent chain per output ran at 1.3 TB/s: 52 -> 26 us per launch).
+template <int NSUB>
+__global__ __launch_bounds__(64 * NSUB) void conv_dw_dma_finalize_kernel(const float* __restrict__ partials,
+                                                                        int qsplits, int groups, int Mg, int Cg,
+                                                                        int kk2, int Mpad, int Npad,
+                                                                        float* __restrict__ dw) {
+    __shared__ float red[NSUB][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const size_t total = (size_t)groups * kk2 * Mg * Cg;
     const size_t i = (size_t)blockIdx.x * 64 + tx;
@@ -217,12 +219,12 @@ __global__ __launch_bounds__(1024) void conv_dw_dma_finalize_kernel(const float*
         const float* p = partials + ((size_t)g * kk2 + tap) * plane + (size_t)f * Npad + c;
         int qs = ty;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        for (; qs + 48 < qsplits; qs += 64) {
-            const float v0 = p[(size_t)qs * qstride], v1 = p[(size_t)(qs + 16) * qstride];
-            const float v2 = p[(size_t)(qs + 32) * qstride], v3 = p[(size_t)(qs + 48) * qstride];
+        for (; qs + 3 * NSUB < qsplits; qs += 4 * NSUB) {
+            const float v0 = p[(size_t)qs * qstride], v1 = p[(size_t)(qs + NSUB) * qstride];
+            const float v2 = p[(size_t)(qs + 2 * NSUB) * qstride], v3 = p[(size_t)(qs + 3 * NSUB) * qstride];
             s0 += v0; s1 += v1; s2 += v2; s3 += v3;
         }
-        for (; qs < qsplits; qs += 16) s0 += p[(size_t)qs * qstride];
+        for (; qs < qsplits; qs += NSUB) s0 += p[(size_t)qs * qstride];
         sum = (s0 + s1) + (s2 + s3);
         o = (((size_t)g * Mg + f) * Cg + c) * kk2 + tap;
     }
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(1024) void conv_dw_dma_finalize_kernel(const float*
     if (ty == 0 && i < total) {
         float tot = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) tot += red[r][tx];
+        for (int r = 0; r < NSUB; ++r) tot += red[r][tx];
         dw[o] += tot;
     }
 }
@@ -320,8 +322,12 @@ bool conv_backward_weights_dma(const float* x, const float* dy, float* dw, const
     }
     KERNEL_CHECK();
     const size_t total = (size_t)s.groups * s.Mg * s.Cg * p.kk2;
-    conv_dw_dma_finalize_kernel<<<(unsigned)((total + 63) / 64), 1024, 0, current_stream()>>>(
-        workspace, p.qsplits, s.groups, s.Mg, s.Cg, p.kk2, p.Mpad, p.Npad, dw);
+    if (p.qsplits > 16)
+        conv_dw_dma_finalize_kernel<16><<<(unsigned)((total + 63) / 64), 1024, 0, current_stream()>>>(
+            workspace, p.qsplits, s.groups, s.Mg, s.Cg, p.kk2, p.Mpad, p.Npad, dw);
+    else
+        conv_dw_dma_finalize_kernel<4><<<(unsigned)((total + 63) / 64), 256, 0, current_stream()>>>(
+            workspace, p.qsplits, s.groups, s.Mg, s.Cg, p.kk2, p.Mpad, p.Npad, dw);
     KERNEL_CHECK();
     return true;
 }
