@@ -143,6 +143,53 @@ __global__ __launch_bounds__(256) void maxpool_bwd_vec4_kernel(const float* __re
     if (hit) *reinterpret_cast<float4*>(dx + s0) = v;
 }
 
+// 3x3 / stride 2 (the ResNet stem pool): at most 2 window rows x 3 window columns cover a group of 4 pixels.
+// All six (index, gradient) pairs are loaded up front from clamped addresses -- twelve independent loads in flight
+// instead of a load -> compare -> load chain per window -- and applied in the same (row, column) order as above,
+// so the sums are bit-identical.
+template <bool OVERWRITE>
+__global__ __launch_bounds__(256) void maxpool_bwd_vec4_k3s2_kernel(const float* __restrict__ dy,
+                                                                    const int* __restrict__ idx,
+                                                                    float* __restrict__ dx, int H, int W, int OH,
+                                                                    int OW) {
+    const int W4 = W >> 2;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int plane = blockIdx.y;
+    if (t >= H * W4) return;
+    const int h = t / W4, w0 = (t - h * W4) * 4;
+    const int s0 = (plane * H + h) * W + w0;
+    const int i0 = h >= 2 ? (h - 1) >> 1 : 0, j0 = w0 >= 2 ? (w0 - 1) >> 1 : 0;
+    int i1 = h >> 1; if (i1 > OH - 1) i1 = OH - 1;
+    int j1 = (w0 + 3) >> 1; if (j1 > OW - 1) j1 = OW - 1;
+    int id[2][3];
+    float g[2][3];
+    bool ok[2][3];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const int i = i0 + a, j = j0 + b;
+            ok[a][b] = i <= i1 && j <= j1;
+            const int o = (plane * OH + (i <= i1 ? i : i1)) * OW + (j <= j1 ? j : j1);
+            id[a][b] = idx[o];
+            g[a][b] = dy[o];
+        }
+    float4 v = OVERWRITE ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(dx + s0);
+    bool hit = OVERWRITE;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const unsigned d = (unsigned)(id[a][b] - s0);
+            if (ok[a][b] && d < 4u) {
+                const float gg = g[a][b];
+                if (d == 0) v.x += gg; else if (d == 1) v.y += gg; else if (d == 2) v.z += gg; else v.w += gg;
+                hit = true;
+            }
+        }
+    if (hit) *reinterpret_cast<float4*>(dx + s0) = v;
+}
+
 // Global average pooling: one wave64 per (n,c) plane, shuffle reduction, then / (H*W).
 __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                           int planes, int HW) {
@@ -203,7 +250,10 @@ void bcnn_hip_maxpool_backward(const float* dy, const int* indexes, float* dx, i
     if ((w & 3) == 0 && total < 0x7fffffffLL && (long long)n * c <= 65535 &&
         (reinterpret_cast<uintptr_t>(dx) & 15) == 0) {
         dim3 grid((unsigned)ceil_div(h * (w / 4), 256), (unsigned)(n * c));
-        if (overwrite)
+        if (size == 3 && stride == 2) {
+            if (overwrite) maxpool_bwd_vec4_k3s2_kernel<true><<<grid, 256, 0, current_stream()>>>(dy, indexes, dx, h, w, out_h, out_w);
+            else maxpool_bwd_vec4_k3s2_kernel<false><<<grid, 256, 0, current_stream()>>>(dy, indexes, dx, h, w, out_h, out_w);
+        } else if (overwrite)
             maxpool_bwd_vec4_kernel<true><<<grid, 256, 0, current_stream()>>>(dy, indexes, dx, h, w, out_h, out_w, size, stride);
         else
             maxpool_bwd_vec4_kernel<false><<<grid, 256, 0, current_stream()>>>(dy, indexes, dx, h, w, out_h, out_w, size, stride);
