@@ -318,12 +318,8 @@ def main():
             # the committed summaries of `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` over this same
             # command (tools/exp/bench_pmc.sh), corrected as MI355X_MICROARCH.md prescribes
             traffic = None
-            if args.workload == "conv3x3" and name == "conv_fwd":
-                pmc = os.path.join(ROOT, "profiles", "r01_conv3x3_pmc.json")
-                if os.path.exists(pmc):
-                    traffic = json.load(open(pmc)).get("conv_fwd_hbm_bytes_per_launch")
-            elif args.workload == "resnet18" and n == 128:
-                pmc = os.path.join(ROOT, "profiles", "r01_resnet18_pmc.json")
+            if args.workload in ("conv3x3", "resnet18") and n == 128 and not args.input_grad:
+                pmc = os.path.join(ROOT, "profiles", "r01_%s_pmc.json" % args.workload)
                 if os.path.exists(pmc):
                     traffic = (json.load(open(pmc)).get("classes", {}).get(name) or {}).get("hbm_bytes_per_launch")
             roof.update({"traffic": traffic, "launches": d["launches"], "avg_ms": round(avg_ms, 4),

@@ -29,7 +29,7 @@ for k in acc:
                "hbm_bytes_per_launch": (2 * f_raw + w) / n, "hbm_bytes_per_step": (2 * f_raw + w) / STEPS}
 def cls(pred):
     ks = [k for k in rows if pred(k)]
-    main = [k for k in ks if "finalize" not in k]
+    main = [k for k in ks if "finalize" not in k and "cache_prefetch" not in k]
     launches = sum(rows[k]["launches_per_step"] for k in main)
     tot = sum(rows[k]["hbm_bytes_per_step"] for k in ks)
     return {"kernels": sorted(ks), "launches_per_step": launches, "hbm_bytes_per_step": tot,
@@ -39,6 +39,7 @@ out = {
  "correction": "hbm_bytes = 2 x FETCH_SIZE + WRITE_SIZE: gfx950 FETCH_SIZE reports 1/2 of wide coalesced reads (MI355X_MICROARCH.md, HBM section); the dword LDS-DMA gathers of the conv kernels are not separately calibrated, WRITE_SIZE as reported; both counters are in KiB",
  "classes": {
    "conv_dw": cls(lambda k: "conv_dw" in k),
+   "conv_fwd": cls(lambda k: "conv_fwd_direct" in k or "cache_prefetch" in k),  # configs[1] only: the LDS-DMA GEMM serves forward AND dX
    "conv_igemm_fwd_and_dx": cls(lambda k: "conv_igemm" in k),
    "batchnorm": cls(lambda k: "Bn" in k or "bn_" in k or "chan_reduce" in k),
  },
