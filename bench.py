@@ -144,6 +144,12 @@ def main():
                     help="data-parallel runs: one blocking all-reduce after backward instead of overlapped buckets")
     args = ap.parse_args()
 
+    # stdout carries exactly one line, the result: everything else that writes to file descriptor 1 while the job
+    # runs (RCCL's version banner comes through C stdio, from whichever rank initialises first) goes to stderr
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from bcnn_amd import _lib, capi, ops
@@ -193,7 +199,7 @@ def main():
         gptr, gsize = net.gradient_arena()
         dp = world > 1 or os.environ.get("BENCH_FORCE_DP") == "1"   # the env switch exercises the DP plumbing on 1 GPU
         grads = torch.as_tensor(capi.DeviceArray(gptr, gsize), device=dev) if dp else None
-        overlap = dp and not args.no_overlap
+        overlap = dp and not args.no_overlap and os.environ.get("BENCH_NO_OVERLAP") != "1"
         if overlap:
             # Gradient all-reduce overlapped with backward: the C executor reports growing tail ranges of the
             # gradient arena as their nodes finish (bcnn_set_gradient_ready_callback); ranges are gathered into
@@ -344,10 +350,18 @@ def main():
             pptr, psize = net.parameter_arena()
             params = torch.as_tensor(capi.DeviceArray(pptr, psize), device=dev)
             out["param_checksum"] = [float(params.double().sum()), float(params.double().abs().sum())]
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out)
+    else:
+        line = None
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    C.CDLL(None).fflush(None)   # C stdio is block-buffered on a pipe: push the banner out while fd 1 still is stderr
+    os.dup2(saved_stdout, 1)
+    os.close(saved_stdout)
+    if line is not None:
+        print(line, flush=True)
 
 
 if __name__ == "__main__":

@@ -143,3 +143,35 @@ def test_bench_two_ranks_overlapped_allreduce_equals_blocking_allreduce():
     b = _run_bench_two_ranks(["--no-overlap"], ports[1])
     assert a["n_gpus"] == 2 and a["config"]["global_batch"] == 16
     assert a["param_checksum"] == b["param_checksum"], (a["param_checksum"], b["param_checksum"])
+
+
+def test_bench_rccl_path_on_one_gpu_prints_one_line_and_leaves_the_same_parameters():
+    """BENCH_FORCE_DP=1 runs bench.py's data-parallel step with a real RCCL communicator of world size 1: the
+    gradient-ready callback, the bucketed asynchronous all-reduce on RCCL's stream ordered against the library's
+    own HIP stream, and the stream-side waits before the update. A one-rank sum is the identity, so the parameters
+    must end up bit-identical to the plain single-GPU run; and stdout must carry the JSON line only (RCCL prints a
+    version banner through C stdio)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(extra_env):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        env = dict(os.environ, BENCH_TEST_CHECKSUM="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), **extra_env)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1",
+                            "--batch", "16", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True,
+                           timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1, r.stdout[-2000:]
+        return json.loads(lines[0])
+    plain = run({})
+    forced = run({"BENCH_FORCE_DP": "1"})
+    blocking = run({"BENCH_FORCE_DP": "1", "BENCH_NO_OVERLAP": "1"})
+    assert forced["param_checksum"] == plain["param_checksum"]
+    assert blocking["param_checksum"] == plain["param_checksum"]
