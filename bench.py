@@ -169,7 +169,10 @@ def main():
     if world > 1 or os.environ.get("BENCH_FORCE_DP") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("gloo" if same_device else "nccl", rank=rank, world_size=world)  # "nccl" IS RCCL on ROCm
+        if same_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:  # "nccl" IS RCCL on ROCm; device_id binds the communicator to this rank's GPU up front
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
     n = args.batch if args.batch else (256 if args.workload == "mobilenet" else 128)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)   # every rank owns different images
