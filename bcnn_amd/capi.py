@@ -67,6 +67,7 @@ def lib():
         "bcnn_get_gradient_arena": (vp, [vp, C.POINTER(sz)]), "bcnn_get_parameter_arena": (vp, [vp, C.POINTER(sz)]),
         "bcnn_synchronize": (None, [vp]), "bcnn_peek_tensor": (tp, [vp, i]), "bcnn_get_num_nodes": (i, [vp]),
         "bcnn_get_node_tensor": (i, [vp, i, i, i]), "bcnn_get_node_state": (vp, [vp, i, i]),
+        "bcnn_forward_node": (i, [vp, i]), "bcnn_backward_node": (i, [vp, i]),
         "bcnn_load_net": (i, [vp, cp, cp]), "bcnn_save_weights": (i, [vp, cp]), "bcnn_load_weights": (i, [vp, cp]),
     }
     for name, (res, args) in sig.items():
@@ -184,6 +185,12 @@ class Net:
 
     def update(self):
         self.L.bcnn_update(self.net)
+
+    def forward_node(self, node):
+        assert self.L.bcnn_forward_node(self.net, node) == 0
+
+    def backward_node(self, node):
+        assert self.L.bcnn_backward_node(self.net, node) == 0
 
     def sync(self):
         self.L.bcnn_synchronize(self.net)

@@ -20,6 +20,15 @@
 
 #define KERNEL_CHECK() HIP_CHECK(hipGetLastError())
 
+// A/B switches for kernel experiments (alternative tiles, forcing the fallback kernels, ...) exist only in the
+// EXPERIMENT build of the library (make exp -> ../lib/libbcnn_hip_exp.so, -DBCNN_HIP_EXPERIMENT; used by tools/exp
+// and by tests/test_fallback_paths.py through BCNN_HIP_LIB). The product build reads no environment variable.
+#ifdef BCNN_HIP_EXPERIMENT
+#define BCNN_EXP_ENV(name) getenv(name)
+#else
+#define BCNN_EXP_ENV(name) ((const char*)nullptr)
+#endif
+
 namespace bcnn_hip {
 
 hipStream_t current_stream();

@@ -95,7 +95,7 @@ void bcnn_hip_conv_forward(const float* x, const float* w, const float* bias, fl
     // TRAIN: the convolution epilogue also emits the per-channel sum / sum of squares of what it stores
     ConvStats st;
     st.partials = nullptr; st.splits = 0;
-    static const int fuse_stats = getenv("BCNN_HIP_NO_FUSED_STATS") ? 0 : 1;  // A/B switch for profiling
+    static const int fuse_stats = BCNN_EXP_ENV("BCNN_HIP_NO_FUSED_STATS") ? 0 : 1;  // A/B switch for profiling
     if (fuse_stats && mode == BCNN_HIP_MODE_TRAIN && s.total_q < 0x7fffffffLL)
         st.partials = reduce_scratch((size_t)f * (size_t)ceil_div(s.total_q, 64) * 2);
     conv_fwd_any(x, w, nullptr, nullptr, raw, s, BCNN_HIP_ACT_NONE, /*raw=*/1, st.partials ? &st : nullptr);
@@ -135,7 +135,7 @@ void bcnn_hip_conv_backward(const float* x, const float* w, const float* bias, c
     // this function returns). Measured on ResNet-18 N=128 it is 1.7 % SLOWER than running them back to back
     // (18.15 vs 17.86 ms/step): both GEMMs are MFMA-bound and evict each other's L2 working set. Kept as an
     // opt-in experiment (BCNN_HIP_SIDE_STREAM=1), off by default.
-    static const int side_on = getenv("BCNN_HIP_SIDE_STREAM") ? 1 : 0;
+    static const int side_on = BCNN_EXP_ENV("BCNN_HIP_SIDE_STREAM") ? 1 : 0;
     SideStream* side = (side_on && dx) ? side_stream() : nullptr;
     hipStream_t main_stream = current_stream();
     if (side) {
@@ -144,7 +144,7 @@ void bcnn_hip_conv_backward(const float* x, const float* w, const float* bias, c
         set_current_stream(side->stream);
     }
     bool bias_done;
-    static const int dma_on = getenv("BCNN_HIP_NO_DMA") ? 0 : 1;  // A/B switch for profiling
+    static const int dma_on = BCNN_EXP_ENV("BCNN_HIP_NO_DMA") ? 0 : 1;  // A/B switch for profiling
     if (conv_backward_weights_direct(x, dy, dw, batch_norm ? nullptr : dbias, s, workspace, workspace_elems))
         bias_done = true;
     else if (dma_on && conv_backward_weights_dma_timed(x, dy, dw, s, workspace, workspace_elems))

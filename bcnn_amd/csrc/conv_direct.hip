@@ -335,7 +335,7 @@ bool conv_forward_direct(const float* x, const float* w, const float* bias, cons
               4.0 * ((double)s.N * s.C * s.HW + (double)s.F * s.K + (double)s.N * s.F * s.OHOW));
     {   // input small enough for the Infinity Cache and dwarfed by the output: make the kernel's HBM traffic write-only
         const size_t xb = (size_t)s.N * s.C * s.HW * 4, yb = (size_t)s.N * s.F * s.OHOW * 4;
-        static const bool pf_on = [] { const char* e = getenv("BCNN_HIP_NO_PREFETCH"); return !(e && e[0] == '1'); }();
+        static const bool pf_on = [] { const char* e = BCNN_EXP_ENV("BCNN_HIP_NO_PREFETCH"); return !(e && e[0] == '1'); }();
         if (pf_on && xb <= (128u << 20) && yb >= 4 * xb && yb >= (256u << 20) && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
             cache_prefetch_kernel<<<kCUs * 8, 256, 0, current_stream()>>>(reinterpret_cast<const float4*>(x), xb / 16, y);
     }

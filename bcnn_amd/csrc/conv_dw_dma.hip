@@ -267,9 +267,9 @@ static DwDmaPlan plan_dw_dma(const ConvShape& s) {
     if ((size_t)s.N * s.C * s.HW * 4 >= 0x7ffffff0ull || (size_t)s.N * s.F * s.OHOW * 4 >= 0x7ffffff0ull) return p;
     p.kk2 = s.pointwise ? 1 : s.ksz * s.ksz;
     p.cfg = s.Mg > 64 ? 1 : 0;
-    static const char* forced = getenv("BCNN_HIP_DW_TILE");  // experiments: index into kDwTiles
+    static const char* forced = BCNN_EXP_ENV("BCNN_HIP_DW_TILE");  // experiments: index into kDwTiles
     if (forced && forced[0] >= '0' && forced[0] < '0' + kNumDwTiles) p.cfg = forced[0] - '0';
-    static const char* wantenv = getenv("BCNN_HIP_DW_WANT");
+    static const char* wantenv = BCNN_EXP_ENV("BCNN_HIP_DW_WANT");
     const int want_per_cu = wantenv ? atoi(wantenv) : 8;
     const int BM = kDwTiles[p.cfg].bm, BN = kDwTiles[p.cfg].bn;
     p.mtiles = ceil_div(s.Mg, BM); p.ntiles = ceil_div(s.Cg, BN);

@@ -315,7 +315,7 @@ bool conv_forward_dma(const float* x, const float* w, const float* bias, const f
 bool conv_backward_data_dma(const float* w, const float* dy, float* dx, const ConvShape& s);
 
 static bool dma_enabled() {
-    static const int on = getenv("BCNN_HIP_NO_DMA") ? 0 : 1;  // A/B switch for profiling
+    static const int on = BCNN_EXP_ENV("BCNN_HIP_NO_DMA") ? 0 : 1;  // A/B switch for profiling
     return on != 0;
 }
 
@@ -409,7 +409,7 @@ static float* col_scratch(size_t floats) {
 }
 
 static bool conv_backward_data_small_c(const float* w, const float* dy, float* dx, const ConvShape& s) {
-    static const bool off = getenv("BCNN_HIP_NO_SMALLC_DX") != nullptr;
+    static const bool off = BCNN_EXP_ENV("BCNN_HIP_NO_SMALLC_DX") != nullptr;
     if (off || s.pointwise || s.groups != 1 || s.K > 32 || s.Mg < 32) return false;
     if ((long long)s.N * s.C * s.HW >= (1LL << 31)) return false;
     const size_t per_image = (size_t)s.K * s.OHOW;                      // col floats per image

@@ -160,11 +160,29 @@ bcnn_status bcnn_net_add_tensor(bcnn_net *net, bcnn_tensor tensor) {
     return BCNN_SUCCESS;
 }
 
+/* The cached SGD table (bcnn_update) names device buffers: any change of the node list or a re-pack of the
+ * arenas makes it stale. */
+static void invalidate_sgd_table(bcnn_net *net) {
+    bcnn_hip_context *hc = hctx(net);
+    if (!hc) return;
+    if (hc->sgd_chunks_gpu) {
+        bcnn_hip_sync();
+        bcnn_hip_free(hc->sgd_chunks_gpu);
+        hc->sgd_chunks_gpu = NULL;
+    }
+    hc->num_sgd_chunks = 0;
+}
+
 bcnn_status bcnn_net_add_node(bcnn_net *net, bcnn_node node) {
     bcnn_node *p = (bcnn_node *)realloc(net->nodes, (size_t)(net->num_nodes + 1) * sizeof(bcnn_node));
     if (!p) return BCNN_FAILED_ALLOC;
     net->nodes = p;
     net->nodes[net->num_nodes++] = node;
+    invalidate_sgd_table(net); /* the new node's parameters are not in the cached one-launch table */
+    if (hctx(net)) { /* per-node arena offsets are rebuilt by the next bcnn_compile_net; until then one final range */
+        free(hctx(net)->node_grad_first);
+        hctx(net)->node_grad_first = NULL;
+    }
     return BCNN_SUCCESS;
 }
 
@@ -228,7 +246,7 @@ void bcnn_end_net(bcnn_net **pnet) {
     bcnn_hip_context *hc = hctx(net);
     /* arena members do not own their device buffers */
     if (hc->compiled) {
-        for (int i = 0; i < hc->num_params; ++i) {
+        for (int i = 0; i < hc->arena_members; ++i) { /* parameters added after the last compile still own theirs */
             bcnn_tensor *t = &net->tensors[hc->param_ids[i]];
             t->data_gpu = NULL;
             t->grad_data_gpu = NULL;
@@ -286,32 +304,42 @@ bcnn_status bcnn_add_input(bcnn_net *net, int width, int height, int channels, c
  * compile: input tensor, shared conv workspace, parameter / gradient arenas
  * ---------------------------------------------------------------------------------------------- */
 static void build_arenas(bcnn_net *net) {
+    /* (Re)pack every registered parameter and its gradient into two contiguous device arenas. Runs at the first
+     * compile and again whenever parameters were registered since (nodes added to a compiled net): members that
+     * already live in the old arenas are copied across, the others give up their own allocation. */
     bcnn_hip_context *hc = hctx(net);
     size_t total = 0;
     for (int i = 0; i < hc->num_params; ++i) {
         /* keep every member 16-byte aligned for the vectorised kernels */
         total += ((size_t)bcnn_tensor_size(&net->tensors[hc->param_ids[i]]) + 3) & ~(size_t)3;
     }
-    hc->arena_size = total;
     if (total == 0) return;
-    hc->param_arena_gpu = bcnn_hip_malloc_f32(total);
-    hc->grad_arena_gpu = (net->mode != BCNN_MODE_PREDICT) ? bcnn_hip_malloc_f32(total) : NULL;
+    float *old_p = hc->param_arena_gpu, *old_g = hc->grad_arena_gpu;
+    float *new_p = bcnn_hip_malloc_f32(total);
+    float *new_g = (net->mode != BCNN_MODE_PREDICT) ? bcnn_hip_malloc_f32(total) : NULL;
     size_t off = 0;
     for (int i = 0; i < hc->num_params; ++i) {
         bcnn_tensor *t = &net->tensors[hc->param_ids[i]];
         const size_t sz = (size_t)bcnn_tensor_size(t);
-        bcnn_hip_memcpy_d2d(hc->param_arena_gpu + off, t->data_gpu, sz * sizeof(float));
+        const int member = i < hc->arena_members;
+        bcnn_hip_memcpy_d2d(new_p + off, t->data_gpu, sz * sizeof(float));
         bcnn_hip_sync();
-        bcnn_hip_free(t->data_gpu);
-        t->data_gpu = hc->param_arena_gpu + off;
-        if (hc->grad_arena_gpu && t->grad_data_gpu) {
-            bcnn_hip_memcpy_d2d(hc->grad_arena_gpu + off, t->grad_data_gpu, sz * sizeof(float));
+        if (!member) bcnn_hip_free(t->data_gpu);
+        t->data_gpu = new_p + off;
+        if (new_g && t->grad_data_gpu) {
+            bcnn_hip_memcpy_d2d(new_g + off, t->grad_data_gpu, sz * sizeof(float));
             bcnn_hip_sync();
-            bcnn_hip_free(t->grad_data_gpu);
-            t->grad_data_gpu = hc->grad_arena_gpu + off;
+            if (!member) bcnn_hip_free(t->grad_data_gpu);
+            t->grad_data_gpu = new_g + off;
         }
         off += (sz + 3) & ~(size_t)3;
     }
+    bcnn_hip_free(old_p);
+    bcnn_hip_free(old_g);
+    hc->param_arena_gpu = new_p;
+    hc->grad_arena_gpu = new_g;
+    hc->arena_size = total;
+    hc->arena_members = hc->num_params;
 }
 
 /* The reference zero-fills every dst gradient before the node's forward (bcnn_net.c:361-375) because
@@ -325,7 +353,8 @@ static void mark_dead_grad_fills(bcnn_net *net) {
     bcnn_hip_context *hc = hctx(net);
     free(hc->grad_fill_dead);
     hc->grad_fill_dead = (unsigned char *)calloc((size_t)net->num_tensors + 1, 1);
-    if (getenv("BCNN_KEEP_ALL_GRAD_FILLS")) return; /* debugging switch: zero every dst gradient like the reference */
+    hc->grad_fill_count = net->num_tensors;
+    if (BCNN_EXP_ENV("BCNN_KEEP_ALL_GRAD_FILLS")) return; /* debugging switch: zero every dst gradient like the reference */
     for (int t = 0; t < net->num_tensors; ++t) {
         int first = -1, uses = 0;
         for (int i = 0; i < net->num_nodes; ++i)
@@ -367,7 +396,7 @@ static void mark_dead_grad_fills(bcnn_net *net) {
 
 int bcnn_grad_sole_writer(bcnn_net *net, int tensor) {
     const bcnn_hip_context *hc = hctx(net);
-    return hc->grad_fill_dead && tensor >= 0 && tensor < net->num_tensors && hc->grad_fill_dead[tensor] == 2;
+    return hc->grad_fill_dead && tensor >= 0 && tensor < hc->grad_fill_count && hc->grad_fill_dead[tensor] == 2;
 }
 
 bcnn_status bcnn_compile_net(bcnn_net *net) {
@@ -392,9 +421,13 @@ bcnn_status bcnn_compile_net(bcnn_net *net) {
     for (int i = 0; i < net->num_nodes; ++i)
         if (net->nodes[i].type == BCNN_LAYER_CONV2D)
             ((bcnn_conv_param *)net->nodes[i].param)->conv_workspace_gpu = hc->workspace_gpu;
-    if (!hc->compiled) {
+    if (!hc->compiled || hc->num_params != hc->arena_members) {
+        /* first compile, or nodes were added since the last one: (re)pack the arenas; the gradient-ready offsets
+         * and the cached SGD table refer to the old layout */
+        invalidate_sgd_table(net);
         build_arenas(net);
         hc->compiled = 1;
+        if (hc->grad_ready_fn) bcnn_set_gradient_ready_callback(net, hc->grad_ready_fn, hc->grad_ready_user);
     }
     mark_dead_grad_fills(net);
     bcnn_hip_sync();
@@ -418,7 +451,8 @@ void bcnn_forward(bcnn_net *net) {
             for (int d = 0; d < node->num_dst; ++d) {
                 bcnn_tensor *t = &net->tensors[node->dst[d]];
                 const bcnn_hip_context *hc = hctx(net);
-                if (hc->grad_fill_dead && hc->grad_fill_dead[node->dst[d]]) continue;
+                /* tensors created after the last bcnn_compile_net have no entry: they are filled like the reference does */
+                if (hc->grad_fill_dead && node->dst[d] < hc->grad_fill_count && hc->grad_fill_dead[node->dst[d]]) continue;
                 if (t->grad_data_gpu) bcnn_hip_fill_f32(t->grad_data_gpu, (size_t)bcnn_tensor_size(t), 0.0f);
             }
         }
@@ -465,8 +499,12 @@ void bcnn_set_gradient_ready_callback(bcnn_net *net, bcnn_gradient_ready_fn fn, 
 /* learning-rate schedules, reference bcnn_learner.c:29-65 */
 static void step_learning_rate(bcnn_net *net) {
     bcnn_learner *ln = net->learner;
-    ln->seen += net->batch_size;
-    const int iter = ln->seen / net->batch_size;
+    /* `seen` counts SAMPLES (bcnn_learner.c:31-33) and keys both the schedules and Adam's bias correction
+     * (bcnn_learner.c:111-112): a data-parallel step consumes the global batch, exactly like the single-process
+     * run on that batch which it has to reproduce */
+    const int global_batch = net->batch_size * hctx(net)->dp_world;
+    ln->seen += global_batch;
+    const int iter = ln->seen / global_batch;
     switch (ln->decay_type) {
         case BCNN_LR_DECAY_STEP:
             ln->learning_rate = ln->base_learning_rate * (float)pow(ln->scale, iter / ln->step);
@@ -506,6 +544,12 @@ static void sgd_table_add(bcnn_hip_context *hc, float *w, float *g, size_t n, in
     }
 }
 
+/* update workers whose whole effect is bcnn_node_sgd_step on their own tensors: safe to replay from the table */
+static int update_is_tabled(const bcnn_node *nd) {
+    return nd->update == bcnn_update_conv_layer || nd->update == bcnn_update_depthwise_conv_layer ||
+           nd->update == bcnn_update_fullc_layer;
+}
+
 void bcnn_update(bcnn_net *net) {
     bcnn_hip_context *hc = hctx(net);
     step_learning_rate(net);
@@ -518,17 +562,23 @@ void bcnn_update(bcnn_net *net) {
         hc->sgd_collecting = 1;
         hc->num_sgd_chunks = 0;
         for (int i = 0; i < net->num_nodes; ++i)
-            if (net->nodes[i].update) net->nodes[i].update(net, &net->nodes[i]);
+            if (net->nodes[i].update && update_is_tabled(&net->nodes[i])) net->nodes[i].update(net, &net->nodes[i]);
         hc->sgd_collecting = 0;
-        if (hc->num_sgd_chunks == 0) return;
-        hc->sgd_chunks_gpu = bcnn_hip_malloc_f32(((size_t)hc->num_sgd_chunks * sizeof(bcnn_hip_sgd_chunk) + 3) / 4);
-        bcnn_hip_memcpy_h2d(hc->sgd_chunks_gpu, hc->sgd_chunks_host,
-                            (size_t)hc->num_sgd_chunks * sizeof(bcnn_hip_sgd_chunk));
+        if (hc->num_sgd_chunks > 0) {
+            hc->sgd_chunks_gpu = bcnn_hip_malloc_f32(((size_t)hc->num_sgd_chunks * sizeof(bcnn_hip_sgd_chunk) + 3) / 4);
+            bcnn_hip_memcpy_h2d(hc->sgd_chunks_gpu, hc->sgd_chunks_host,
+                                (size_t)hc->num_sgd_chunks * sizeof(bcnn_hip_sgd_chunk));
+        }
     }
     const bcnn_learner *ln = net->learner;
-    bcnn_hip_sgd_update_chunks((const bcnn_hip_sgd_chunk *)hc->sgd_chunks_gpu, hc->num_sgd_chunks,
-                               net->batch_size * hc->dp_world, ln->learning_rate, ln->momentum / (float)hc->dp_world,
-                               ln->decay);
+    if (hc->num_sgd_chunks > 0)
+        bcnn_hip_sgd_update_chunks((const bcnn_hip_sgd_chunk *)hc->sgd_chunks_gpu, hc->num_sgd_chunks,
+                                   net->batch_size * hc->dp_world, ln->learning_rate,
+                                   ln->momentum / (float)hc->dp_world, ln->decay);
+    /* every other worker runs on every step like in the reference's loop (bcnn_net.c:316-326): the stand-alone
+     * PReLU node (its own batch divisor) and anything a user plugged into node->update */
+    for (int i = 0; i < net->num_nodes; ++i)
+        if (net->nodes[i].update && !update_is_tabled(&net->nodes[i])) net->nodes[i].update(net, &net->nodes[i]);
 }
 
 /* One fused pass per buffer (reference: axpy/axpy/scal sequence, bcnn_learner.c:67-104). Under data
@@ -685,6 +735,23 @@ void *bcnn_get_node_state(bcnn_net *net, int node, int which) {
         case 4: return sv->grad_data_gpu;
     }
     return NULL;
+}
+
+bcnn_status bcnn_forward_node(bcnn_net *net, int node) {
+    if (node < 0 || node >= net->num_nodes || !net->nodes[node].forward) return BCNN_INVALID_PARAMETER;
+    net->nodes[node].forward(net, &net->nodes[node]);
+    return BCNN_SUCCESS;
+}
+
+bcnn_status bcnn_backward_node(bcnn_net *net, int node) {
+    if (node < 0 || node >= net->num_nodes || !net->nodes[node].backward) return BCNN_INVALID_PARAMETER;
+    bcnn_hip_context *hc = hctx(net);
+    /* outside the executor nobody promised that the gradients were left unfilled: accumulate like the reference */
+    unsigned char *saved = hc->grad_fill_dead;
+    hc->grad_fill_dead = NULL;
+    net->nodes[node].backward(net, &net->nodes[node]);
+    hc->grad_fill_dead = saved;
+    return BCNN_SUCCESS;
 }
 
 void bcnn_synchronize(bcnn_net *net) {

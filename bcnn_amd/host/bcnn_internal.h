@@ -42,6 +42,13 @@ void bcnn_log(bcnn_log_context ctx, bcnn_log_level level, const char *fmt, ...);
 #define BCNN_INFO(ctx, fmt, ...) bcnn_log((ctx), BCNN_LOG_INFO, (fmt), ##__VA_ARGS__)
 #define BCNN_WARNING(ctx, fmt, ...) bcnn_log((ctx), BCNN_LOG_WARNING, (fmt), ##__VA_ARGS__)
 
+/* debugging switches of the host runtime exist only in an experiment build (-DBCNN_HIP_EXPERIMENT) */
+#ifdef BCNN_HIP_EXPERIMENT
+#define BCNN_EXP_ENV(name) getenv(name)
+#else
+#define BCNN_EXP_ENV(name) ((const char *)NULL)
+#endif
+
 typedef struct {
     int state;
     float r;
@@ -117,6 +124,7 @@ typedef struct bcnn_hip_context {
     size_t arena_size;  /* floats */
     int *param_ids;     /* tensor indices of trainable parameters, in creation order */
     int num_params;
+    int arena_members; /* how many of param_ids[] already live inside the arenas (bcnn_compile_net re-packs when it grows) */
     int dp_rank;
     int dp_world;
     int compiled;
@@ -129,6 +137,7 @@ typedef struct bcnn_hip_context {
     size_t *node_grad_first;
     /* per tensor: 1 = the zero-fill of its gradient before forward is dead (see mark_dead_grad_fills) */
     unsigned char *grad_fill_dead;
+    int grad_fill_count; /* entries of grad_fill_dead[] (tensors that existed at compile time) */
     struct bcnn_hip_sgd_chunk *sgd_chunks_host;
     void *sgd_chunks_gpu;
     int num_sgd_chunks, cap_sgd_chunks;

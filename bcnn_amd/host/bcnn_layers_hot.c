@@ -75,6 +75,18 @@ bcnn_status bcnn_add_convolutional_layer(bcnn_net *net, int num_filters, int siz
     BCNN_CHECK_AND_LOG(net->log_ctx, num_filters % num_groups == 0, BCNN_INVALID_PARAMETER,
                        "Number of output channels has to be a multiple of the number of groups\n");
     const int cg = sc / num_groups;
+    const int oh = (sh + 2 * pad - size) / stride + 1, ow = (sw + 2 * pad - size) / stride + 1;
+    /* A 1x1 kernel reads its source as a raw [C/g][OH*OW] matrix whatever stride / pad say (quirk 1,
+     * bcnn_conv_layer.c:445-446). With padding that makes OH*OW > H*W the reference walks past the end of the
+     * last image in host memory; on the device that would be an out-of-bounds read of x and WRITE of dx.
+     * Deliberate deviation: such a layer is refused here. */
+    if (size == 1 && oh * ow > sh * sw) {
+        free(node.src);
+        BCNN_CHECK_AND_LOG(net->log_ctx, 0, BCNN_INVALID_PARAMETER,
+                           "Convolution layer %s: a 1x1 kernel with pad %d gives %d x %d outputs from %d x %d inputs; "
+                           "the raw-view addressing of 1x1 kernels would run past the source tensor\n",
+                           dst_id, pad, ow, oh, sw, sh);
+    }
 
     char name[256];
     snprintf(name, sizeof(name), "%s_w", src_id);
@@ -99,7 +111,6 @@ bcnn_status bcnn_add_convolutional_layer(bcnn_net *net, int num_filters, int siz
     node.update = bcnn_update_conv_layer;
     node.release_param = bcnn_release_param_conv_layer;
 
-    const int oh = (sh + 2 * pad - size) / stride + 1, ow = (sw + 2 * pad - size) / stride + 1;
     BCNN_CHECK_STATUS(add_output(net, &node, sn, num_filters, oh, ow, dst_id));
     if (batch_norm) {
         param->batch_norm = 1;
@@ -445,7 +456,15 @@ void bcnn_backward_activation_layer(bcnn_net *net, bcnn_node *node) {
 }
 
 void bcnn_update_activation_layer(bcnn_net *net, bcnn_node *node) {
+    /* reference bcnn_activation_layer.c:262-291: momentum-SGD with the weights rule for both optimizers, and
+     * batch_size = weights->n, which is 1 for the [1,1,1,C] slope tensor -- NOT the net's batch size. Under data
+     * parallelism the all-reduced gradient already is the global sum, so the divisor stays 1; only the momentum
+     * carry is split over the ranks like everywhere else (bcnn_node_sgd_step). */
     bcnn_activation_param *p = (bcnn_activation_param *)node->param;
     if (p->activation != BCNN_ACT_PRELU) return;
-    bcnn_node_sgd_step(net, &net->tensors[node->src[1]], NULL);
+    bcnn_tensor *slopes = &net->tensors[node->src[1]];
+    if (!slopes->data_gpu || !slopes->grad_data_gpu) return;
+    const bcnn_learner *ln = net->learner;
+    bcnn_hip_sgd_update(slopes->data_gpu, NULL, slopes->grad_data_gpu, NULL, (size_t)bcnn_tensor_size(slopes), 0,
+                        slopes->n, ln->learning_rate, ln->momentum / (float)hctx(net)->dp_world, ln->decay);
 }

@@ -297,7 +297,7 @@ void bcnn_forward_cost_layer(bcnn_net *net, bcnn_node *node) {
      * device copy is what the loader uploaded, bcnn_data.c:413-425) and only the 4-byte result is read back, so
      * dst->data[0] is valid when bcnn_forward returns, as it is there. BCNN_HOST_COST_METRIC=1 keeps the host loop. */
     static int host_loop = -1;
-    if (host_loop < 0) host_loop = getenv("BCNN_HOST_COST_METRIC") != NULL;
+    if (host_loop < 0) host_loop = BCNN_EXP_ENV("BCNN_HOST_COST_METRIC") != NULL;
     if (host_loop || !label->data_gpu || !dst->grad_data_gpu) {
         if (dst->grad_data_gpu) bcnn_hip_memcpy_d2h(dst->grad_data, dst->grad_data_gpu, sz * sizeof(float));
         bcnn_hip_memcpy_d2h(pred->data, pred->data_gpu, sz * sizeof(float));

@@ -1,5 +1,7 @@
 /* bip_min.c -- libbip.so: bip_write_image as a dependency-free PNG writer (stored deflate blocks, CRC-32,
- * Adler-32). Exists so that unchanged consumers of the reference (src/cli/bcnn_cl.c) link; see include/bip/bip.h. */
+ * Adler-32) and bip_resize_bilinear. Exists so that unchanged consumers of the reference (src/cli/bcnn_cl.c,
+ * examples/inference_benchmark) link and run; see include/bip/bip.h. The decoders live in bip_decode.c. */
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -67,4 +69,48 @@ bip_status bip_write_image(char *filename, uint8_t *src, int32_t w, int32_t h, i
     fclose(fp);
     free(z); free(scan);
     return ok ? BIP_SUCCESS : BIP_UNKNOWN_ERROR;
+}
+
+/* Source position of destination sample i: half-pixel centres, then clamped so that (index, index + 1) stays
+ * inside the image; the fraction is quantised to 1/16 (reference bip.c:1118-1156). */
+static void resize_tap(size_t i, float scale, size_t src_extent, int32_t *index, int32_t *frac) {
+    float alpha = (float)((i + 0.5) * scale - 0.5);
+    long idx = (long)floor(alpha);
+    alpha -= idx;
+    if (idx < 0) { idx = 0; alpha = 0; }
+    if (idx > (long)src_extent - 2) { idx = (long)src_extent - 2; alpha = 1; }
+    if (idx < 0) { idx = 0; alpha = 0; } /* one-sample axis: replicate (the reference reads out of bounds here) */
+    *index = (int32_t)idx;
+    *frac = (int32_t)(alpha * 16 + 0.5);
+}
+
+bip_status bip_resize_bilinear(uint8_t *src, size_t src_width, size_t src_height, size_t src_stride, uint8_t *dst,
+                               size_t dst_width, size_t dst_height, size_t dst_stride, size_t depth) {
+    if (!src || !dst) return BIP_INVALID_PTR;
+    if (!src_width || !src_height || !dst_width || !dst_height) return BIP_INVALID_SIZE;
+    if (depth < 1 || depth > 4) {
+        fprintf(stderr, "resize_bilinear: 'depth' value must be >= 1 and <= 4\n");
+        return BIP_INVALID_PARAMETER;
+    }
+    int32_t *ix = (int32_t *)malloc(2 * dst_width * sizeof(int32_t)), *ax = ix ? ix + dst_width : NULL;
+    if (!ix) return BIP_UNKNOWN_ERROR;
+    const float x_scale = (float)src_width / dst_width, y_scale = (float)src_height / dst_height;
+    for (size_t x = 0; x < dst_width; ++x) resize_tap(x, x_scale, src_width, &ix[x], &ax[x]);
+    const size_t xstep = src_width > 1 ? depth : 0, ystep = src_height > 1 ? src_stride : 0;
+    for (size_t y = 0; y < dst_height; ++y) {
+        int32_t iy, ay;
+        resize_tap(y, y_scale, src_height, &iy, &ay);
+        const uint8_t *r0 = src + (size_t)iy * src_stride, *r1 = r0 + ystep;
+        uint8_t *out = dst + y * dst_stride;
+        for (size_t x = 0; x < dst_width; ++x)
+            for (size_t c = 0; c < depth; ++c) {
+                const size_t o = (size_t)ix[x] * depth + c;
+                /* horizontal pass in 1/16 units on both rows, vertical pass in 1/256 units, round to nearest */
+                const int32_t h0 = (r0[o] << 4) + (r0[o + xstep] - r0[o]) * ax[x];
+                const int32_t h1 = (r1[o] << 4) + (r1[o + xstep] - r1[o]) * ax[x];
+                out[x * depth + c] = (uint8_t)(((h0 << 4) + (h1 - h0) * ay + 128) >> 8);
+            }
+    }
+    free(ix);
+    return BIP_SUCCESS;
 }

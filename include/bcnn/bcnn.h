@@ -222,6 +222,11 @@ BCNN_API int bcnn_get_node_tensor(bcnn_net *net, int node, int is_dst, int slot)
 /* layer-private device state needed by parity tests: which = 0 maxpool indexes (int*), 1 saved_mean,
  * 2 saved_variance, 3 d(saved_mean), 4 d(saved_variance); returns a DEVICE pointer or NULL */
 BCNN_API void *bcnn_get_node_state(bcnn_net *net, int node, int which);
+/* Run ONE node's forward / backward worker on whatever its tensors currently hold (no executor bookkeeping:
+ * no zero fill of the dst gradients, no dead-fill elision -- a sole-writer gradient is accumulated like in the
+ * reference). Used by the teacher-forced parity walk, which feeds every node the REFERENCE's inputs. */
+BCNN_API bcnn_status bcnn_forward_node(bcnn_net *net, int node);
+BCNN_API bcnn_status bcnn_backward_node(bcnn_net *net, int node);
 
 #ifdef __cplusplus
 }

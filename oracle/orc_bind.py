@@ -36,6 +36,8 @@ def lib():
         "orc_gemm": [i, i, i, i, i, f, fp, i, fp, i, f, fp, i],
         "orc_add_bias": [fp, fp, i, i, i],
         "orc_grad_bias": [fp, fp, i, i, i],
+        "orc_scales": [fp, fp, i, i, i],
+        "orc_grad_scales": [fp, fp, i, i, i, fp],
         "orc_act_forward": [fp, i, fp, i, i, i],
         "orc_act_backward": [fp, fp, i, fp, fp, i, i, i],
         "orc_bn_forward": [fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, i, i, i, i],

@@ -81,6 +81,9 @@ def lib():
     L.bcnn_col2im.argtypes = [fp, i, i, i, i, i, i, fp]; L.bcnn_col2im.restype = None
     L.bcnn_add_bias.argtypes = [fp, fp, i, i, i, i]; L.bcnn_add_bias.restype = None
     L.bcnn_grad_bias.argtypes = [fp, fp, i, i, i]; L.bcnn_grad_bias.restype = None
+    L.bcnn_scales.argtypes = [fp, fp, i, i, i, i]; L.bcnn_scales.restype = None           # bcnn_mat.c:772-781
+    L.bcnn_grad_scales.argtypes = [fp, fp, i, i, i, fp]; L.bcnn_grad_scales.restype = None  # bcnn_mat.c:783-796
+    L.bcnn_scal.argtypes = [i, f, fp]; L.bcnn_scal.restype = None                          # bcnn_mat.c:319-364
     # driver accessors (oracle/ref_driver.c)
     L.ref_num_nodes.argtypes = [vp]; L.ref_num_nodes.restype = i
     L.ref_num_tensors.argtypes = [vp]; L.ref_num_tensors.restype = i
@@ -93,6 +96,8 @@ def lib():
     L.ref_set_mode_raw.argtypes = [vp, i]; L.ref_set_mode_raw.restype = None
     L.ref_set_threads.argtypes = [vp, i]; L.ref_set_threads.restype = None
     L.ref_get_threads.argtypes = [vp]; L.ref_get_threads.restype = i
+    L.ref_forward_node.argtypes = [vp, i]; L.ref_forward_node.restype = None
+    L.ref_backward_node.argtypes = [vp, i]; L.ref_backward_node.restype = None
     L.ref_maxpool_indexes.argtypes = [vp, i]; L.ref_maxpool_indexes.restype = C.POINTER(C.c_int)
     L.ref_bn_field.argtypes = [vp, i, i]; L.ref_bn_field.restype = fp
     L.ref_gemm.argtypes = [vp, i, i, i, i, i, f, fp, i, fp, i, f, fp, i]; L.ref_gemm.restype = None
@@ -238,6 +243,15 @@ class RefNet:
 
     def backward(self):
         self.L.bcnn_backward(self.net)
+
+    def forward_node(self, node):
+        self.L.ref_forward_node(self.net, node)
+
+    def backward_node(self, node):
+        self.L.ref_backward_node(self.net, node)
+
+    def num_nodes(self):
+        return self.L.ref_num_nodes(self.net)
 
     def set_mode(self, mode):
         self.L.ref_set_mode_raw(self.net, mode)

@@ -37,6 +37,10 @@ void ref_set_mode_raw(bcnn_net *net, int mode) { net->mode = (bcnn_mode)mode; }
 void ref_set_threads(bcnn_net *net, int nt) { net->num_threads = nt; }
 int ref_get_threads(bcnn_net *net) { return net->num_threads; }
 
+/* one node at a time (tests/test_teacher_forced.py): the plug-in workers of src/bcnn_node.h:44-47 */
+void ref_forward_node(bcnn_net *net, int node) { net->nodes[node].forward(net, &net->nodes[node]); }
+void ref_backward_node(bcnn_net *net, int node) { net->nodes[node].backward(net, &net->nodes[node]); }
+
 /* maxpool: param->indexes (src/layers/bcnn_maxpool_layer.h:34-47) */
 int *ref_maxpool_indexes(bcnn_net *net, int node) {
     if (net->nodes[node].type != BCNN_LAYER_MAXPOOL) return NULL;

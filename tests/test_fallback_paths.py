@@ -1,7 +1,9 @@
 """The convolution has two generations of GEMM kernels: the LDS-DMA ones (conv_igemm_dma.hip, conv_dw_dma.hip)
-take every shape they support, the register-staged ones (conv_igemm.hip, conv_bwd.hip) the rest. The switch
-BCNN_HIP_NO_DMA=1 (read once per process) forces the second set, so the whole golden suite is replayed in a
-child process to keep both generations pinned to the reference."""
+take every shape they support, the register-staged ones (conv_igemm.hip, conv_bwd.hip) the rest. The product
+library reads no environment; its EXPERIMENT build (bcnn_amd/lib/libbcnn_hip_exp.so: same sources compiled with
+-DBCNN_HIP_EXPERIMENT, selected through BCNN_HIP_LIB) has the switch BCNN_HIP_NO_DMA=1 (read once per process) that
+forces the second set, so the whole golden suite is replayed in a child process on that build to keep both
+generations pinned to the reference."""
 import os
 import subprocess
 import sys
@@ -18,6 +20,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_golden_suite_on_the_other_code_path(env):
     e = dict(os.environ)
     e.update(env)
+    e["BCNN_HIP_LIB"] = os.path.join(ROOT, "bcnn_amd", "lib", "libbcnn_hip_exp.so")
+    assert os.path.exists(e["BCNN_HIP_LIB"]), "experiment build missing: __graft_entry__.build() makes it"
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_hip_parity.py"), "-m", "gpu",
                         "-q", "-x", "-p", "no:cacheprovider"], cwd=ROOT, env=e, capture_output=True, text=True,
                        timeout=900)

@@ -11,8 +11,11 @@ uses what the operator offers at any size:
 * batch-norm statistics and outputs against the reference's formulas evaluated in float64 by torch on the device
   (a checker for a floating-point kernel, bcnn_batchnorm_layer.c:147-242, 263-332).
 
-Shapes: configs[1] (one 3->64 3x3 conv, 224x224, N=128), the ResNet-18 stem pool and first residual convs at N=128,
-MobileNet-v1's first depthwise layer at N=256."""
+Shapes: configs[1] (one 3->64 3x3 conv, 224x224, N=128); EVERY convolution shape of the ResNet-18 step at N=128 --
+the 7x7/s2 RGB stem (register-staged fallback kernels), the 3x3 layers of all four stages (64ch 56x56 ... 512ch
+7x7: other grid quantisations and dW tile variants), the three 3x3/s2 downsampling layers and the three 1x1/s2
+projections (raw-view quirk) -- and the stem pool; MobileNet-v1 at N=256: stride-1 and stride-2 depthwise layers
+and the 512 -> 1024 pointwise layer."""
 import numpy as np
 import pytest
 import torch
@@ -106,6 +109,30 @@ def test_resnet18_downsample_conv_n128_56_stride2():
     _conv_full_size(n=128, c=64, hw=56, f=128, k=3, s=2, p=1, act=0, images=(5,), chunk=8)
 
 
+# every remaining convolution shape of the benchmarked ResNet-18 step, at the benchmark's N = 128
+@pytest.mark.parametrize("name,c,hw,f,k,s,p,act,images,chunk", [
+    ("stem_7x7s2", 3, 224, 64, 7, 2, 3, 2, (0, 127), 4),          # conv_igemm_kernel / conv_dw_kernel fallbacks
+    ("stage2_3x3", 128, 28, 128, 3, 1, 1, 2, (1, 126), 8),
+    ("stage3_3x3", 256, 14, 256, 3, 1, 1, 2, (2, 125), 8),          # dW tile variant <2,2,2,1>, 14x14 quantisation
+    ("stage4_3x3", 512, 7, 512, 3, 1, 1, 0, (3, 124), 8),           # C*k*k = 4608: above the reference gemm's limit
+    ("down3_3x3s2", 128, 28, 256, 3, 2, 1, 2, (4,), 8),
+    ("down4_3x3s2", 256, 14, 512, 3, 2, 1, 2, (6,), 8),
+    ("proj2_1x1s2", 64, 56, 128, 1, 2, 0, 0, (7, 127), 8),          # raw-view addressing (quirk 1)
+    ("proj3_1x1s2", 128, 28, 256, 1, 2, 0, 0, (8,), 8),
+    ("proj4_1x1s2", 256, 14, 512, 1, 2, 0, 0, (9,), 8),
+])
+def test_resnet18_every_conv_shape_n128(name, c, hw, f, k, s, p, act, images, chunk):
+    _conv_full_size(n=128, c=c, hw=hw, f=f, k=k, s=s, p=p, act=act, images=images, chunk=chunk)
+
+
+def test_mobilenet_last_pointwise_n256_7_512_to_1024():
+    _conv_full_size(n=256, c=512, hw=7, f=1024, k=1, s=1, p=0, act=2, images=(0, 255), chunk=16)
+
+
+def test_mobilenet_pointwise_n256_56_64_to_128():
+    _conv_full_size(n=256, c=64, hw=56, f=128, k=1, s=1, p=0, act=2, images=(100,), chunk=16)
+
+
 def test_resnet18_fused_batchnorm_conv_n128_56_against_float64():
     """conv + fused batch-norm + ReLU, TRAIN mode: the fused statistics epilogue and the BN backward that
     recomputes its input, against float64 formulas on the plain conv output."""
@@ -181,32 +208,57 @@ def test_resnet18_stem_maxpool_n128_112():
         assert np.array_equal(_np(dx[i:i + 1]), exp["dx"])
 
 
-def test_mobilenet_first_depthwise_n256_112():
+def _depthwise_full_size(n, c, hw, k, stride, images, chunk):
     from bcnn_amd import ops
-    n, c, hw, k = 256, 32, 112, 3
+    oh, ow = ops.conv_out_hw(hw, hw, k, stride, 1)
     x = _rand((n, c, hw, hw), 31)
     wt = _rand((c * k * k,), 32, 0.3)
     bias = _rand((c,), 33, 0.1)
-    dy0 = _rand((n, c, hw, hw), 34, 1e-2)
-    y = torch.empty_like(x)
-    ops.depthwise_forward(x, wt, bias, y, k, 1, 1, 2)
+    dy0 = _rand((n, c, oh, ow), 34, 1e-2)
+    y = torch.empty((n, c, oh, ow), device=DEV)
+    ops.depthwise_forward(x, wt, bias, y, k, stride, 1, 2)
     dy, dx = dy0.clone(), torch.zeros_like(x)
     dw, db = torch.zeros_like(wt), torch.zeros_like(bias)
-    ops.depthwise_backward(x, wt, y, dy, dx, dw, db, k, 1, 1, 2)
+    ops.depthwise_backward(x, wt, y, dy, dx, dw, db, k, stride, 1, 2)
     torch.cuda.synchronize()
-    for i in (0, 255):
-        cs = dict(n=1, c=c, h=hw, w=hw, k=k, s=1, p=1, act=2, input_grad=1, x=_np(x[i:i + 1]), wt=_np(wt),
+    for i in images:
+        cs = dict(n=1, c=c, h=hw, w=hw, k=k, s=stride, p=1, act=2, input_grad=1, x=_np(x[i:i + 1]), wt=_np(wt),
                   bias=_np(bias), dy=_np(dy0[i:i + 1]), dw0=np.zeros(c * k * k, np.float32),
                   db0=np.zeros(c, np.float32), dx0=np.zeros((1, c, hw, hw), np.float32))
         exp = ob.orc_dw(cs)
         assert _rel(_np(y[i:i + 1]), exp["y"]) <= TOL
         assert _rel(_np(dx[i:i + 1]), exp["dx"]) <= TOL
     dw_sum, db_sum = torch.zeros_like(wt), torch.zeros_like(bias)
-    for a in range(0, n, 32):
-        ops.depthwise_backward(x[a:a + 32].contiguous(), wt, y[a:a + 32].contiguous(), dy0[a:a + 32].clone(),
-                               torch.zeros_like(x[a:a + 32]), dw_sum, db_sum, k, 1, 1, 2)
+    for a in range(0, n, chunk):
+        ops.depthwise_backward(x[a:a + chunk].contiguous(), wt, y[a:a + chunk].contiguous(), dy0[a:a + chunk].clone(),
+                               torch.zeros_like(x[a:a + chunk]), dw_sum, db_sum, k, stride, 1, 2)
     assert _rel(_np(dw), _np(dw_sum)) <= TOL
     assert _rel(_np(db), _np(db_sum)) <= TOL
+    # one chunk's weight / bias gradient against the oracle
+    a = n - 4
+    cs = dict(n=4, c=c, h=hw, w=hw, k=k, s=stride, p=1, act=2, input_grad=1, x=_np(x[a:]), wt=_np(wt),
+              bias=_np(bias), dy=_np(dy0[a:]), dw0=np.zeros(c * k * k, np.float32), db0=np.zeros(c, np.float32),
+              dx0=np.zeros((4, c, hw, hw), np.float32))
+    exp = ob.orc_dw(cs)
+    dw1, db1 = torch.zeros_like(wt), torch.zeros_like(bias)
+    ops.depthwise_backward(x[a:].contiguous(), wt, y[a:].contiguous(), dy0[a:].clone(), torch.zeros_like(x[a:]), dw1, db1,
+                           k, stride, 1, 2)
+    assert _rel(_np(dw1), exp["dw"]) <= TOL
+    assert _rel(_np(db1), exp["db"]) <= TOL
+
+
+def test_mobilenet_first_depthwise_n256_112():
+    _depthwise_full_size(n=256, c=32, hw=112, k=3, stride=1, images=(0, 255), chunk=32)
+
+
+def test_mobilenet_stride2_depthwise_n256_112_to_56():
+    _depthwise_full_size(n=256, c=64, hw=112, k=3, stride=2, images=(0, 255), chunk=32)
+
+
+def test_mobilenet_late_depthwise_n256_14_and_7():
+    _depthwise_full_size(n=256, c=512, hw=14, k=3, stride=1, images=(17,), chunk=32)
+    _depthwise_full_size(n=256, c=512, hw=14, k=3, stride=2, images=(18,), chunk=32)
+    _depthwise_full_size(n=256, c=1024, hw=7, k=3, stride=1, images=(19,), chunk=32)
 
 
 def test_activation_and_avgpool_at_conv_output_size():

@@ -43,3 +43,22 @@ def test_bcnn_cl_links_unchanged(tmp_path):
     # no GPU needed for the usage path: it returns before touching the library
     run = subprocess.run([exe], capture_output=True, text=True)
     assert run.returncode != 0 and "Usage" in run.stderr
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "examples", "inference_benchmark")), reason="reference tree not mounted")
+def test_inference_benchmark_links_unchanged(tmp_path):
+    """examples/inference_benchmark/inference_benchmark.c (the `inference-benchmark` target):
+    bcnn_load_net + bcnn_fill_tensor_with_image + bcnn_forward, and from libbip.so bip_load_image (:54) and
+    bip_resize_bilinear (:72)."""
+    from bcnn_amd import capi
+    capi.build()
+    exe = str(tmp_path / "inference-benchmark")
+    lib = os.path.join(ROOT, "bcnn_amd", "lib")
+    cmd = ["gcc", "-std=gnu99", "-O1", "-DBCNN_USE_HIP", "-I", os.path.join(ROOT, "include"),
+           "-I", os.path.join(ROOT, "bcnn_amd", "host"),
+           os.path.join(REF, "examples", "inference_benchmark", "inference_benchmark.c"), "-o", exe, "-L", lib,
+           "-lbcnn", "-lbip", "-lbcnn_hip", "-Wl,-rpath," + lib, "-lm"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-3000:]
+    run = subprocess.run([exe], capture_output=True, text=True)   # usage path: returns before touching the device
+    assert run.returncode != 0 and "Usage" in run.stderr

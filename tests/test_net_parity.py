@@ -72,7 +72,19 @@ def depthwise_graph(net):
     net.avgpool("pw2", "avg")
 
 
+def prelu_node_graph(net):
+    """a stand-alone PReLU activation node (the only stand-alone activation the reference's CPU build can run,
+    bcnn_activation_layer.c:148-163): its slopes are stepped with batch_size = weights->n = 1, not the net's
+    batch (bcnn_activation_layer.c:262-291) -- two SGD steps pin that divisor and the decay term"""
+    net.conv(8, 3, 1, 1, 1, 0, rb.ACT_NONE, "input", "c1")
+    net.activation(rb.ACT_PRELU, "c1")
+    net.maxpool(2, 2, rb.PADDING_SAME, "c1", "p1")
+    net.conv(8, 3, 1, 1, 1, 1, rb.ACT_RELU, "p1", "c2")
+    net.avgpool("c2", "avg")
+
+
 GRAPHS = {
+    "prelu_node": (prelu_node_graph, dict(w=12, h=12, c=3, n=4), False),
     "stack": (stack_graph, dict(w=16, h=12, c=3, n=3), False),
     "resnet_block": (resnet_block_graph, dict(w=16, h=16, c=3, n=4), True),
     # n = 16: bn3 normalises fc outputs over the batch only; with 4 samples per channel its statistics amplify
@@ -124,6 +136,8 @@ def test_net_matches_reference(gname):
             d[...] = rs.uniform(-0.2, 0.2, d.shape)
         elif nm.endswith("_run_var"):
             d[...] = rs.uniform(0.5, 1.5, d.shape)
+        elif "prelu" in nm:
+            d[...] = rs.uniform(0.1, 0.3, d.shape)
         assert hip.shape(i) == ref.shape(i), (nm, hip.shape(i), ref.shape(i))
         hip.data(i)[...] = d
         hip.upload(i)

@@ -1,0 +1,211 @@
+"""Teacher-forced walk over the benchmark graphs: every node of the HIP build is fed the REFERENCE's own input
+activations (forward) and the reference's own output gradient (backward), runs alone, and has to reproduce the
+reference's outputs of that node to the per-operator bar of 1e-4 (max|a-b| / max|b| per tensor) -- so nothing
+is hidden behind error amplification by ~20 stacked batch-norms, which is why the end-to-end comparison in
+tests/test_resnet18_parity.py needs 2e-3 / 2e-2.
+
+Protocol, per node i (the plug-in workers `node->forward/backward`, reference src/bcnn_node.h:44-47, are called
+one at a time on both sides: oracle/ref_driver.c ref_forward_node / ref_backward_node, and bcnn_forward_node /
+bcnn_backward_node of include/bcnn/bcnn.h):
+  forward : copy the reference's src tensors into the HIP net -> run node i on both -> compare every dst tensor
+            and every src tensor the node mutates (running mean / variance);
+  backward: copy data AND gradients of every tensor the node touches from the reference (the state right before
+            its backward) -> run node i's backward on both -> compare the gradients of all its tensors (src
+            gradients, weight / bias / scale gradients, the rewritten dst gradient).
+Layer-private state (saved batch statistics, pre-normalisation workspace, max-pool indexes) is each side's own,
+produced by its forward of that same node from identical inputs.
+
+Where the reference's in-tree gemm is itself wrong (dW for C/g*k*k > 4096, dX for
+F/g > 384; pinned by tests/test_reference_gemm_limits.py) that one tensor is compared against float64 torch on the
+same teacher-forced inputs instead; everything else of the node still against the reference."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from oracle import ref_bind as rb
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+class _Tee:
+    """builds the same graph on the reference and the HIP net and records the conv hyper-parameters per node"""
+
+    def __init__(self, ref, hip):
+        self.ref, self.hip, self.convs = ref, hip, {}
+
+    def conv(self, f, k, s, p, g=1, bn=0, act=0, src="input", dst="conv"):
+        i = self.ref.conv(f, k, s, p, g, bn, act, src, dst)
+        assert self.hip.conv(f, k, s, p, g, bn, act, src, dst) == i
+        self.convs[i] = dict(f=f, k=k, s=s, p=p, g=g, bn=bn, act=act)
+        return i
+
+    def __getattr__(self, name):
+        def both(*a, **kw):
+            i = getattr(self.ref, name)(*a, **kw)
+            assert getattr(self.hip, name)(*a, **kw) == i
+            return i
+        return both
+
+
+def _build(graph, shape, classes, **kw):
+    import bench
+    from bcnn_amd import capi
+    ctypes.CDLL(None).srand(20240607)
+    ref = rb.RefNet(mode=rb.MODE_TRAIN, **shape)
+    ref.L.ref_set_threads(ref.net, 8)
+    hip = capi.Net(mode=capi.MODE_TRAIN, **shape)
+    tee = _Tee(ref, hip)
+
+    class A:  # constants are identical on both sides
+        pass
+    for name in dir(rb):
+        if name.startswith(("ACT_", "PADDING_")):
+            setattr(A, name, getattr(rb, name))
+    getattr(bench, graph)(tee, A, classes=classes, **kw)
+    ref.compile()
+    hip.compile()
+    nt = ref.L.ref_num_tensors(ref.net)
+    names = [ref.L.ref_tensor_name(ref.net, i).decode() for i in range(nt)]
+    rs = np.random.RandomState(5)
+    for i in range(2, nt):  # non-trivial BN scales and biases; the HIP net gets the reference's parameters
+        d = ref.data(i)
+        if names[i].endswith("_scales"):
+            d[...] = rs.uniform(0.8, 1.2, d.shape)
+        elif names[i].endswith("_b"):
+            d[...] = rs.uniform(-0.1, 0.1, d.shape)
+        assert hip.shape(i) == ref.shape(i), names[i]
+    x = rs.uniform(-1, 1, ref.shape(0)).astype(np.float32)
+    lab = np.zeros(ref.shape(1), np.float32)
+    lab[np.arange(shape["n"]), rs.randint(0, classes, shape["n"])] = 1.0
+    ref.data(0)[...] = x
+    ref.data(1)[...] = lab
+    return ref, hip, names, tee.convs
+
+
+def _node_tensors(ref, i):
+    src = [ref.node_src(i, k) for k in range(ref.node_num_src(i))]
+    dst = [ref.node_dst(i, 0)]
+    return src, dst
+
+
+def _rel(a, b):
+    den = float(np.abs(b).max())
+    if den == 0.0:
+        return float(np.abs(a).max())  # reference all zero: so must we be
+    return float(np.abs(a.astype(np.float64) - b).max()) / den
+
+
+def _copy_in(ref, hip, ids, with_grad):
+    for t in ids:
+        hip.data(t)[...] = ref.data(t)
+        g = ref.grad(t) if with_grad else None
+        if g is not None and hip.grad(t) is not None:
+            hip.grad(t)[...] = g
+        hip.upload(t, with_grad and g is not None)
+
+
+def _conv_grads_fp64(x, w, dy, cp):
+    """float64 dW / dX of the reference's conv semantics (incl. the raw-view 1x1 quirk, bcnn_conv_layer.c:562-569)"""
+    import torch
+    x64, w64, dy64 = (torch.from_numpy(np.asarray(a, np.float64)) for a in (x, w, dy))
+    k, s, p, g = cp["k"], cp["s"], cp["p"], cp["g"]
+    if k == 1:
+        n, c, f = x64.shape[0], x64.shape[1], w64.shape[0]
+        ohow = dy64.shape[2] * dy64.shape[3]
+        assert g == 1
+        xr = x64.reshape(n, -1)[:, :c * ohow].reshape(n, c, ohow)
+        dyr = dy64.reshape(n, f, ohow)
+        dw = torch.einsum("nfq,ncq->fc", dyr, xr).reshape(w64.shape)
+        dxr = torch.einsum("fc,nfq->ncq", w64.reshape(f, c), dyr).reshape(n, c * ohow)
+        return dw.numpy(), dxr.numpy(), c * ohow
+    dw = torch.nn.grad.conv2d_weight(x64, w64.shape, dy64, stride=s, padding=p, groups=g)
+    dx = torch.nn.grad.conv2d_input(x64.shape, w64, dy64, stride=s, padding=p, groups=g)
+    return dw.numpy(), dx.numpy(), None
+
+
+def _walk(graph, shape, classes, **kw):
+    if not rb.available():
+        pytest.skip("oracle/_ref not present")
+    ref, hip, names, convs = _build(graph, shape, classes, **kw)
+    nn = ref.num_nodes()
+    worst = {"fwd": (0.0, ""), "bwd": (0.0, "")}
+    fp64_checked = []
+
+    def check(kind, a, b, what, tol=TOL):
+        err = _rel(a, b)
+        if err > worst[kind][0]:
+            worst[kind] = (err, what)
+        assert err <= tol, (kind, what, err)
+
+    # ---- forward, node by node ----------------------------------------------------------------------
+    for i in range(nn):
+        src, dst = _node_tensors(ref, i)
+        _copy_in(ref, hip, src, False)
+        ref.forward_node(i)
+        hip.forward_node(i)
+        for t in dst + src[1:]:
+            hip.download(t, False)
+            check("fwd", hip.data(t), ref.data(t), "node %d %s" % (i, names[t]))
+    # ---- backward, node by node, on the reference's own gradient chain -------------------------------
+    for i in range(nn - 1, -1, -1):
+        src, dst = _node_tensors(ref, i)
+        ids = list(dict.fromkeys(src + dst))
+        _copy_in(ref, hip, ids, True)
+        cp = convs.get(i)
+        pre_dx = None
+        if cp is not None:
+            x_t, w_t = src[0], src[1]
+            if ref.grad(x_t) is not None:
+                pre_dx = ref.grad(x_t).copy()
+        ref.backward_node(i)
+        hip.backward_node(i)
+        for t in ids:
+            if ref.grad(t) is None:
+                continue
+            hip.download(t, True)
+            what = "node %d d(%s)" % (i, names[t])
+            if cp is not None and t in (src[0], src[1]):
+                cg = ref.shape(src[1])[1]
+                bad_dw = t == src[1] and cg * cp["k"] * cp["k"] > 4096       # quirk 8: the reference is wrong here
+                bad_dx = t == src[0] and cp["f"] // cp["g"] > 384
+                if bad_dw or bad_dx:
+                    # the dst gradient AFTER the node's activation / batch-norm backward is what the GEMMs consumed
+                    dw64, dx64, prefix = _conv_grads_fp64(ref.data(src[0]), ref.data(src[1]), ref.grad(dst[0]), cp)
+                    if bad_dw:
+                        check("bwd", hip.grad(t), dw64, what + " [fp64]")
+                    elif prefix is None:
+                        check("bwd", hip.grad(t), dx64, what + " [fp64]")
+                    else:  # 1x1: only the raw-view prefix of each image is written, the rest keeps its old value
+                        n = dx64.shape[0]
+                        got = hip.grad(t).reshape(n, -1)
+                        check("bwd", got[:, :prefix], dx64, what + " [fp64]")
+                        assert np.array_equal(got[:, prefix:], pre_dx.reshape(n, -1)[:, prefix:]), what
+                    fp64_checked.append(what)
+                    continue
+            check("bwd", hip.grad(t), ref.grad(t), what)
+    ref.close()
+    hip.close()
+    print("teacher-forced %s: worst relative deviation fwd %.2e (%s), bwd %.2e (%s); %d tensors vs float64"
+          % (graph, worst["fwd"][0], worst["fwd"][1], worst["bwd"][0], worst["bwd"][1], len(fp64_checked)))
+    return worst, fp64_checked
+
+
+def test_resnet18_half_width_every_node_within_1e4():
+    """32..256 channels: everything the reference computes is sound, every tensor is compared with the reference"""
+    worst, fp64 = _walk("build_resnet18", dict(w=96, h=96, c=3, n=8), 10, base=32)
+    assert not fp64
+
+
+def test_resnet18_full_width_every_node_within_1e4():
+    """64..512 channels (the benchmarked widths): stage 4 crosses the reference's gemm limits, those dW / dX
+    tensors are compared against float64 instead"""
+    worst, fp64 = _walk("build_resnet18", dict(w=96, h=96, c=3, n=8), 10, base=64)
+    assert fp64  # the limits really are crossed at this width
+
+
+def test_mobilenet_v1_every_node_within_1e4():
+    """depthwise 3x3 (s1 and s2) -> stand-alone batch-norm -> pointwise conv + BN + ReLU, 32..1024 channels"""
+    _walk("build_mobilenet_v1", dict(w=64, h=64, c=3, n=4), 10)

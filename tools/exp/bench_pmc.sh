@@ -1,16 +1,19 @@
 #!/bin/bash
 # HBM traffic of every kernel of the bench.py ResNet-18 step: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in
 # separate passes (MI355X_MICROARCH.md: they do not fit one pass), summed per kernel name and divided by launches.
-# Writes gpurun_out/r01_resnet18_pmc.json (copy to profiles/). usage: bench_pmc.sh [workload]
+# Writes gpurun_out/${ROUND}_<workload>_pmc.json (copy to profiles/). usage: [ROUND=r02] bench_pmc.sh [workload]
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/bpmc; rm -rf $O; mkdir -p $O
 WL=${1:-resnet18}
+ROUND=${ROUND:-r02}
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/$C -- python3 $R/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline > $O/$C.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/$C -- python3 $R/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline --no-side-workloads > $O/$C.log 2>&1
   tail -1 $O/$C.log | cut -c1-160
 done
 python3 - <<PY
-import csv, glob, collections, json
+import csv, glob, collections, json, sys
+sys.path.insert(0, "$R")
+import bench
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(lambda: collections.defaultdict(int))
 for f in glob.glob("$O/*/**/*counter_collection.csv", recursive=True):
@@ -35,7 +38,8 @@ def cls(pred):
     return {"kernels": sorted(ks), "launches_per_step": launches, "hbm_bytes_per_step": tot,
             "hbm_bytes_per_launch": tot / launches if launches else None}
 out = {
- "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --workload $WL --steps 3 --warmup 1 (tools/exp/bench_pmc.sh), round 1",
+ "csrc_sha": bench.kernel_source_digest(),
+ "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --workload $WL --steps 3 --warmup 1 (tools/exp/bench_pmc.sh), $ROUND",
  "correction": "hbm_bytes = 2 x FETCH_SIZE + WRITE_SIZE: gfx950 FETCH_SIZE reports 1/2 of wide coalesced reads (MI355X_MICROARCH.md, HBM section); the dword LDS-DMA gathers of the conv kernels are not separately calibrated, WRITE_SIZE as reported; both counters are in KiB",
  "classes": {
    "conv_dw": cls(lambda k: "conv_dw" in k),
@@ -46,7 +50,7 @@ out = {
  "kernels": {k[:120]: v for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["hbm_bytes_per_step"])[:24]},
  "total_hbm_bytes_per_step": sum(v["hbm_bytes_per_step"] for v in rows.values()),
 }
-json.dump(out, open("$R/gpurun_out/r01_%s_pmc.json" % "$WL", "w"), indent=1)
+json.dump(out, open("$R/gpurun_out/${ROUND}_%s_pmc.json" % "$WL", "w"), indent=1)
 for c, v in out["classes"].items():
     print(c, v["launches_per_step"], "launches/step", "%.1f MB/launch" % ((v["hbm_bytes_per_launch"] or 0) / 1e6), "%.2f GB/step" % (v["hbm_bytes_per_step"] / 1e9))
 print("total %.2f GB/step" % (out["total_hbm_bytes_per_step"] / 1e9))
