@@ -37,7 +37,9 @@ void set_current_stream(hipStream_t st);  // runtime.hip
 // Optional per-kernel-class timing with HIP events on the launch stream (off by default; bench.py turns it
 // on to report the roofline of the dominant kernel from inside the timed region). runtime.hip.
 enum KClass { K_CONV_FWD = 0, K_CONV_DW, K_CONV_DX, K_BN_FWD, K_BN_BWD, K_POOL, K_ELTWISE_ACT, K_GEMM, K_SGD,
-              K_DEPTHWISE_FWD, K_DEPTHWISE_BWD, K_NUM };
+              K_DEPTHWISE_FWD, K_DEPTHWISE_BWD,
+              K_CONV_FWD_WINO, K_CONV_DX_WINO, K_CONV_DW_WINO,  // Winograd F(2x2,3x3) layers: FLOPs = what the MFMAs execute
+              K_NUM };
 struct KTimer {
     int idx;
     KTimer(int cls, double flops, double bytes);

@@ -27,6 +27,10 @@ bool conv_forward_direct(const float* x, const float* w, const float* bias, cons
 size_t conv_dw_direct_workspace_floats(const ConvShape& s);
 bool conv_backward_weights_direct(const float* x, const float* dy, float* dw, float* dbias, const ConvShape& s,
                                   float* workspace, size_t workspace_floats);
+// conv_winograd.hip: F(2x2, 3x3) for the deep 3x3 / s1 layers (false: the layer stays on the direct kernels)
+bool conv_forward_winograd(const float* x, const float* w, const float* bias, const float* slopes, float* y,
+                           const ConvShape& s, int act, int raw, ConvStats* stats);
+bool conv_backward_data_winograd(const float* w, const float* dy, float* dx, const ConvShape& s);
 
 static bool conv_backward_weights_dma_timed(const float* x, const float* dy, float* dw, const ConvShape& s,
                                             float* workspace, size_t workspace_floats) {
@@ -58,8 +62,9 @@ static SideStream* side_stream() {
 static void conv_fwd_any(const float* x, const float* w, const float* bias, const float* slopes, float* y,
                          const ConvShape& s, int act, int raw, ConvStats* stats = nullptr) {
     if (stats) stats->splits = 0;
-    if (!conv_forward_direct(x, w, bias, slopes, y, s, act, raw))
-        conv_forward_dispatch(x, w, bias, slopes, y, s, act, raw, stats);
+    if (conv_forward_direct(x, w, bias, slopes, y, s, act, raw)) return;
+    if (conv_forward_winograd(x, w, bias, slopes, y, s, act, raw, stats)) return;
+    conv_forward_dispatch(x, w, bias, slopes, y, s, act, raw, stats);
 }
 }  // namespace bcnn_hip
 
@@ -157,7 +162,7 @@ void bcnn_hip_conv_backward(const float* x, const float* w, const float* bias, c
         set_current_stream(main_stream);
     }
     if (!batch_norm && !bias_done) bcnn_hip_grad_bias(dbias, dy, n, f, s.OHOW);  // uses the shared reduce scratch
-    if (dx) conv_backward_data(w, dy, dx, s);
+    if (dx && !conv_backward_data_winograd(w, dy, dx, s)) conv_backward_data(w, dy, dx, s);
     if (side) HIP_CHECK(hipStreamWaitEvent(main_stream, side->done, 0));
 }
 

@@ -1,0 +1,99 @@
+"""Winograd F(2x2, 3x3) path (bcnn_amd/csrc/conv_winograd.hip; reference: the PREDICT-mode path of
+bcnn_conv_layer.c:388-436 on bcnn_mat.c:1403-2138). The product library only takes it for deep 3x3 / s1 layers
+(those shapes are covered at benchmark size by tests/test_full_size_properties.py and, through the reference's own
+Winograd outputs, by the conv_predict_winograd_ref_* fixtures). Here the EXPERIMENT build forces the path
+(BCNN_HIP_WINOGRAD=1) on small and ragged shapes -- odd heights / widths (partial last tiles), channel counts that
+are not multiples of the GEMM tiles, bias = 1.0 (quirk 2), fused activation, fused batch-norm (raw output), dX --
+and compares forward, dW (direct kernels on the same tensors), dX with the oracle at the usual 1e-4."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHILD = os.environ.get("BCNN_WINO_CHILD") == "1"
+
+SHAPES = [  # n, c, h, w, f, act, bn
+    (2, 16, 8, 8, 64, 0, 0),
+    (3, 24, 7, 9, 72, 2, 0),     # odd extents: partial tiles on both axes; ragged F
+    (2, 40, 5, 6, 64, 5, 0),     # leaky relu
+    (2, 32, 14, 14, 96, 2, 1),   # fused batch-norm + relu (raw conv output feeds the statistics)
+    (1, 64, 3, 3, 128, 0, 0),    # a single partial tile row / column
+    (2, 128, 7, 7, 128, 2, 1),
+]
+
+
+def _case(n, c, h, w, f, act, bn, seed):
+    from oracle import orc_bind as ob
+    rs = np.random.RandomState(seed)
+    cs = dict(op="conv", n=n, c=c, h=h, w=w, f=f, k=3, s=1, p=1, g=1, bn=bn, act=act, mode=ob.MODE_TRAIN, input_grad=1,
+              x=rs.uniform(-1, 1, (n, c, h, w)).astype(np.float32),
+              wt=(rs.uniform(-1, 1, (f, c, 3, 3)) * (3.0 / (c * 9)) ** 0.5).astype(np.float32),
+              bias=rs.uniform(-0.3, 0.3, f).astype(np.float32),
+              dy=(rs.uniform(-1, 1, (n, f, h, w)) * 1e-2).astype(np.float32))
+    cs["bias"][1] = 1.0  # quirk 2: bcnn_add_scalar skips exactly 1.0f
+    if bn:
+        cs.update(run_mean0=rs.uniform(-0.1, 0.1, f).astype(np.float32), run_var0=rs.uniform(0.5, 1.5, f).astype(np.float32),
+                  scales=rs.uniform(0.5, 1.5, f).astype(np.float32))
+    return cs
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not CHILD, reason="runs in the child process that test_winograd_forced_on_small_shapes spawns")
+@pytest.mark.parametrize("shape", SHAPES)
+def test_child_winograd_matches_oracle(shape):
+    from oracle import orc_bind as ob
+    from tests import _golden as G
+    from tests import _hip_cases as HC
+    cs = _case(*shape, seed=sum(shape))
+    got = HC.run_hip(cs)
+    want = ob.run_oracle(cs)
+    for key in sorted(want):
+        if key in got:
+            err = G.rel_err(got[key], want[key])
+            assert err <= 1e-4, (shape, key, err)
+
+
+@pytest.mark.gpu
+def test_winograd_forced_on_small_shapes():
+    exp = os.path.join(ROOT, "bcnn_amd", "lib", "libbcnn_hip_exp.so")
+    assert os.path.exists(exp), "experiment build missing: __graft_entry__.build() makes it"
+    e = dict(os.environ, BCNN_WINO_CHILD="1", BCNN_HIP_LIB=exp, BCNN_HIP_WINOGRAD="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-p",
+                        "no:cacheprovider", "-k", "child"], cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "%d passed" % len(SHAPES) in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.gpu
+def test_product_build_takes_winograd_for_the_deep_layers_and_agrees_with_the_direct_kernels():
+    """256ch 14x14 at N=16: inside the product rule. The experiment build with BCNN_HIP_WINOGRAD=0 gives the direct
+    kernels' result for the same tensors; the two algorithms agree far inside the parity bar."""
+    import torch
+    from bcnn_amd import _lib, ops
+    L = _lib.load()
+    n, c, hw, f = 16, 256, 14, 256
+    g = torch.Generator(device="cuda:0").manual_seed(3)
+    x = torch.rand((n, c, hw, hw), device="cuda:0", generator=g) * 2 - 1
+    wt = (torch.rand((f, c, 3, 3), device="cuda:0", generator=g) * 2 - 1) * (3.0 / (c * 9)) ** 0.5
+    bias = torch.rand(f, device="cuda:0", generator=g) - 0.5
+    y = torch.empty((n, f, hw, hw), device="cuda:0")
+    L.bcnn_hip_profile_reset()
+    L.bcnn_hip_profile_enable(1)
+    ops.conv_forward(x, wt, bias, y, 3, 1, 1, 1, 2)
+    L.bcnn_hip_profile_enable(0)
+    import ctypes as C
+    seen = {}
+    for cls in range(L.bcnn_hip_profile_num_classes()):
+        ms, cnt, fl, by = C.c_double(), C.c_longlong(), C.c_double(), C.c_double()
+        L.bcnn_hip_profile_read(cls, C.byref(ms), C.byref(cnt), C.byref(fl), C.byref(by))
+        if cnt.value:
+            seen[L.bcnn_hip_profile_class_name(cls).decode()] = fl.value
+    assert "conv_fwd_winograd" in seen and "conv_fwd" not in seen, seen
+    tiles = n * 7 * 7
+    assert seen["conv_fwd_winograd"] == 2.0 * 16 * tiles * c * f   # FLOPs the MFMAs execute, not the direct count
+    ref = torch.nn.functional.conv2d(x.double(), wt.double(), bias.double(), padding=1).relu()
+    err = float((y.double() - ref).abs().max() / ref.abs().max())
+    assert err <= 1e-5, err

@@ -1,0 +1,10 @@
+#!/bin/bash
+# Winograd F(2x2,3x3) vs the direct LDS-DMA kernels on the 3x3 / s1 shapes of the ResNet-18 step at N = 128
+# (experiment build: BCNN_HIP_WINOGRAD=0 forces direct, =1 forces Winograd). Run under gpurun from the repo root.
+export BCNN_HIP_LIB=$PWD/bcnn_amd/lib/libbcnn_hip_exp.so
+for shape in "128 64 56 56 64" "128 128 28 28 128" "128 256 14 14 256" "128 512 7 7 512" ${EXTRA_SHAPES}; do
+  for w in 0 1; do
+    echo "== N C H W F = $shape  BCNN_HIP_WINOGRAD=$w"
+    BCNN_HIP_WINOGRAD=$w python3 tools/prof_layer.py $shape 3 1 1 ${ITERS:-10} 2>&1 | grep -v amdgpu.ids
+  done
+done
