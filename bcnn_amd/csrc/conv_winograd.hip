@@ -25,6 +25,9 @@ namespace bcnn_hip {
 
 bool conv_forward_dma(const float* x, const float* w, const float* bias, const float* slopes, float* y,
                       const ConvShape& s, int act, int raw, ConvStats* stats);  // conv_igemm_dma.hip
+size_t conv_dw_dma_workspace_floats(const ConvShape& s);                        // conv_dw_dma.hip
+bool conv_backward_weights_dma(const float* x, const float* dy, float* dw, const ConvShape& s, float* workspace,
+                               size_t workspace_floats);
 
 // ---- transforms --------------------------------------------------------------------------------------------
 // B^T d B for one 4x4 patch (rows first, then columns): 32 additions.
@@ -118,19 +121,24 @@ __global__ __launch_bounds__(256) void wino_weight_transform_kernel(const float*
 }
 
 // y = A^T m A (+ bias, activation), A^T = [1 1 1 0; 0 1 -1 -1]. One thread per (f, t); 16 coalesced loads along t.
+// stats != nullptr (raw output feeding a fused batch-norm): the workgroup also publishes the sum and the sum of
+// squares of the values it stores, stats[(f * gridDim.x + blockIdx.x) * 2 + {0, 1}] -- the layout
+// bn_stats_finalize consumes (ConvStats), so the batch-norm needs no statistics pass of its own.
 template <bool PLAIN>
 __global__ __launch_bounds__(256) void wino_output_transform_kernel(const float* __restrict__ mm, float* __restrict__ y,
                                                                     const float* __restrict__ bias,
                                                                     const float* __restrict__ slopes, int act,
-                                                                    const WinoGeom g, int F) {
+                                                                    const WinoGeom g, int F, float* __restrict__ stats) {
+    __shared__ float red[2][4];
     const unsigned t = blockIdx.x * 256u + threadIdx.x;
     const int f = blockIdx.y;
-    if (t >= g.T) return;
+    const bool live = t < g.T;
+    if (!live && stats == nullptr) return;
     const size_t plane = (size_t)F * g.T;
-    const float* src = mm + (size_t)f * g.T + t;
+    const float* src = mm + (size_t)f * g.T + (live ? t : 0);
     float m[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) m[k] = src[(size_t)k * plane];
+    for (int k = 0; k < 16; ++k) m[k] = live ? src[(size_t)k * plane] : 0.f;
     float s[2][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -163,12 +171,94 @@ __global__ __launch_bounds__(256) void wino_output_transform_kernel(const float*
     float* dst = y + ((size_t)n * F + f) * (size_t)(g.H * g.W);
     const int oh = 2 * th, ow = 2 * tw;
     const bool two_cols = ow + 1 < g.W;
+    float sv = 0.f, sq = 0.f;
+    if (live) {
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        if (oh + a >= g.H) break;
-        float* row = dst + (oh + a) * g.W + ow;
-        row[0] = o[a][0];
-        if (two_cols) row[1] = o[a][1];
+        for (int a = 0; a < 2; ++a) {
+            if (oh + a >= g.H) break;
+            float* row = dst + (oh + a) * g.W + ow;
+            row[0] = o[a][0];
+            sv += o[a][0];
+            sq += o[a][0] * o[a][0];
+            if (two_cols) {
+                row[1] = o[a][1];
+                sv += o[a][1];
+                sq += o[a][1] * o[a][1];
+            }
+        }
+    }
+    if (stats != nullptr) {  // fixed-order reduction: 64-lane shuffle tree, then the four waves in order
+        sv = wave_sum(sv);
+        sq = wave_sum(sq);
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+        if (lane == 0) { red[0][wid] = sv; red[1][wid] = sq; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float* d = stats + ((size_t)f * gridDim.x + blockIdx.x) * 2;
+            d[0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+            d[1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        }
+    }
+}
+
+// Weight gradient in the transformed domain:  dU[xi][f][c] = sum_t dM[xi][f][t] * V[xi][c][t],
+//   dM = A dy_tile A^T (the adjoint of the output transform, A = [1 0; 1 1; 1 -1; 0 -1]),  dw[f][c] += G^T dU[.][f][c] G.
+__global__ __launch_bounds__(256) void wino_dy_transform_kernel(const float* __restrict__ dy, float* __restrict__ dm,
+                                                                const WinoGeom g) {
+    const unsigned t = blockIdx.x * 256u + threadIdx.x;
+    const int f = blockIdx.y;
+    if (t >= g.T) return;
+    const unsigned per_img = (unsigned)(g.TH * g.TW);
+    const unsigned n = t / per_img, r = t - n * per_img;
+    const int th = (int)(r / (unsigned)g.TW), tw = (int)(r - (unsigned)th * (unsigned)g.TW);
+    const float* p = dy + ((size_t)n * g.C + f) * (size_t)(g.H * g.W);
+    const int oh = 2 * th, ow = 2 * tw;
+    float d[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) d[a][b] = (oh + a < g.H && ow + b < g.W) ? p[(oh + a) * g.W + ow + b] : 0.f;
+    float q[4][2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        q[0][b] = d[0][b];
+        q[1][b] = d[0][b] + d[1][b];
+        q[2][b] = d[0][b] - d[1][b];
+        q[3][b] = -d[1][b];
+    }
+    float* dst = dm + (size_t)f * g.T + t;
+    const size_t plane = (size_t)g.C * g.T;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        dst[(size_t)(4 * i + 0) * plane] = q[i][0];
+        dst[(size_t)(4 * i + 1) * plane] = q[i][0] + q[i][1];
+        dst[(size_t)(4 * i + 2) * plane] = q[i][0] - q[i][1];
+        dst[(size_t)(4 * i + 3) * plane] = -q[i][1];
+    }
+}
+
+// dw[f][c][3][3] += G^T dU[.][f][c] G,  G^T = [1 .5 .5 0; 0 .5 -.5 0; 0 .5 .5 1]  (beta = 1: onto the momentum carry)
+__global__ __launch_bounds__(256) void wino_dw_finish_kernel(const float* __restrict__ du, float* __restrict__ dw, int F,
+                                                             int C) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= F * C) return;
+    const size_t plane = (size_t)F * C;
+    float u[4][4];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) u[k >> 2][k & 3] = du[(size_t)k * plane + idx];
+    float t[3][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        t[0][j] = u[0][j] + 0.5f * (u[1][j] + u[2][j]);
+        t[1][j] = 0.5f * (u[1][j] - u[2][j]);
+        t[2][j] = 0.5f * (u[1][j] + u[2][j]) + u[3][j];
+    }
+    float* out = dw + (size_t)idx * 9;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        out[a * 3 + 0] += t[a][0] + 0.5f * (t[a][1] + t[a][2]);
+        out[a * 3 + 1] += 0.5f * (t[a][1] - t[a][2]);
+        out[a * 3 + 2] += 0.5f * (t[a][1] + t[a][2]) + t[a][3];
     }
 }
 
@@ -222,7 +312,7 @@ static bool wino_profitable(const ConvShape& s) {
 }
 
 static void wino_run(const float* src, const float* w, float* dst, const ConvShape& s, int dx_mode, const float* bias,
-                     const float* slopes, int act, bool plain) {
+                     const float* slopes, int act, bool plain, ConvStats* stats = nullptr) {
     // src: x [N][C][H][W] (forward) or dy [N][F][H][W] (dX); J = reduction channels, M = produced channels
     const int J = dx_mode ? s.F : s.C, M = dx_mode ? s.C : s.F;
     WinoGeom g;
@@ -247,11 +337,13 @@ static void wino_run(const float* src, const float* w, float* dst, const ConvSha
     WinoGeom go = g;
     go.C = M;
     dim3 gout((unsigned)ceil_div(g.T, 256), (unsigned)M);
+    float* st = (stats && stats->partials && plain) ? stats->partials : nullptr;
     if (plain)
-        wino_output_transform_kernel<true><<<gout, 256, 0, current_stream()>>>(Mm, dst, nullptr, nullptr, 0, go, M);
+        wino_output_transform_kernel<true><<<gout, 256, 0, current_stream()>>>(Mm, dst, nullptr, nullptr, 0, go, M, st);
     else
-        wino_output_transform_kernel<false><<<gout, 256, 0, current_stream()>>>(Mm, dst, bias, slopes, act, go, M);
+        wino_output_transform_kernel<false><<<gout, 256, 0, current_stream()>>>(Mm, dst, bias, slopes, act, go, M, nullptr);
     KERNEL_CHECK();
+    if (stats) stats->splits = st ? (int)gout.x : 0;
 }
 
 // Algorithmic figures of the class timers: FLOPs the MFMAs really execute (transformed domain, 16 instead of 36
@@ -268,10 +360,12 @@ static double wino_bytes(const ConvShape& s) {
 bool conv_forward_winograd(const float* x, const float* w, const float* bias, const float* slopes, float* y,
                            const ConvShape& s, int act, int raw, ConvStats* stats) {
     if (!wino_applicable(s) || !wino_profitable(s)) return false;
-    if (stats) stats->splits = 0;  // the batch-norm that follows computes its own statistics on this path
     KTimer kt(K_CONV_FWD_WINO, wino_flops(s), wino_bytes(s));
     const bool plain = raw || (bias == nullptr && act == BCNN_HIP_ACT_NONE);
-    wino_run(x, w, y, s, /*dx_mode=*/0, bias, slopes, raw ? BCNN_HIP_ACT_NONE : act, plain);
+    // raw output for a fused batch-norm: the output transform also emits the per-channel statistics partials
+    // (ceil(T / 256) <= ceil(N*OH*OW / 64) entries per channel: inside the buffer conv.hip sized)
+    wino_run(x, w, y, s, /*dx_mode=*/0, bias, slopes, raw ? BCNN_HIP_ACT_NONE : act, plain, raw ? stats : nullptr);
+    if (stats && !raw) stats->splits = 0;
     return true;
 }
 
@@ -281,6 +375,55 @@ bool conv_backward_data_winograd(const float* w, const float* dy, float* dx, con
     if (s.F < 16 || s.C < 64) return false;
     KTimer kt(K_CONV_DX_WINO, wino_flops(s), wino_bytes(s));
     wino_run(dy, w, dx, s, /*dx_mode=*/1, nullptr, nullptr, BCNN_HIP_ACT_NONE, true);
+    return true;
+}
+
+// ---- weight gradient -----------------------------------------------------------------------------------------
+static ConvShape wino_dw_gemm_shape(const ConvShape& s) {
+    const int T = (int)((long long)s.N * ((s.H + 1) / 2) * ((s.W + 1) / 2));
+    return make_conv_shape(1, 16 * s.C, 1, T, 16 * s.F, 1, 1, 0, 16);
+}
+
+static bool wino_dw_applicable(const ConvShape& s) {
+    return wino_applicable(s) && wino_profitable(s) && s.C >= 16 && !(s.C & 1) && !(s.F & 1);
+}
+
+// split partials of the 16 grouped GEMMs (the caller's conv workspace, bcnn_hip_conv_workspace_size)
+size_t conv_dw_winograd_workspace_floats(const ConvShape& s) {
+    if (!wino_dw_applicable(s)) return 0;
+    return conv_dw_dma_workspace_floats(wino_dw_gemm_shape(s));
+}
+
+bool conv_backward_weights_winograd(const float* x, const float* dy, float* dw, const ConvShape& s, float* workspace,
+                                    size_t workspace_floats) {
+    if (!wino_dw_applicable(s)) return false;
+    const ConvShape gs = wino_dw_gemm_shape(s);
+    const size_t need = conv_dw_dma_workspace_floats(gs);
+    if (need == 0) return false;
+    KTimer kt(K_CONV_DW_WINO, wino_flops(s), wino_bytes(s));
+    WinoGeom g;
+    g.N = s.N; g.C = s.C; g.H = s.H; g.W = s.W;
+    g.TH = (s.H + 1) / 2; g.TW = (s.W + 1) / 2;
+    g.T = (unsigned)((long long)s.N * g.TH * g.TW);
+    const size_t v_floats = (size_t)16 * s.C * g.T, m_floats = (size_t)16 * s.F * g.T, u_floats = (size_t)16 * s.F * s.C;
+    float* V = wino_scratch(v_floats + m_floats + u_floats);
+    float* dM = V + v_floats;
+    float* dU = dM + m_floats;
+    dim3 gi((unsigned)ceil_div(g.T, 256), (unsigned)s.C);
+    wino_input_transform_kernel<<<gi, 256, 0, current_stream()>>>(x, V, g);
+    KERNEL_CHECK();
+    WinoGeom gy = g;
+    gy.C = s.F;
+    dim3 gd((unsigned)ceil_div(g.T, 256), (unsigned)s.F);
+    wino_dy_transform_kernel<<<gd, 256, 0, current_stream()>>>(dy, dM, gy);
+    KERNEL_CHECK();
+    HIP_CHECK(hipMemsetAsync(dU, 0, u_floats * sizeof(float), current_stream()));
+    if (!conv_backward_weights_dma(V, dM, dU, gs, workspace, workspace_floats)) {
+        fprintf(stderr, "[bcnn_hip] winograd dW: grouped GEMM shape rejected (C=%d F=%d T=%u)\n", s.C, s.F, g.T);
+        exit(1);
+    }
+    wino_dw_finish_kernel<<<ceil_div((long long)s.F * s.C, 256), 256, 0, current_stream()>>>(dU, dw, s.F, s.C);
+    KERNEL_CHECK();
     return true;
 }
 

@@ -174,6 +174,7 @@ def _walk(graph, shape, classes, **kw):
             x_t, w_t = src[0], src[1]
             if ref.grad(x_t) is not None:
                 pre_dx = ref.grad(x_t).copy()
+        pre_dy = ref.grad(dst[0]).copy() if ref.grad(dst[0]) is not None else None
         ref.backward_node(i)
         hip.backward_node(i)
         for t in ids:
@@ -200,8 +201,10 @@ def _walk(graph, shape, classes, **kw):
                     fp64_checked.append(what)
                     continue
             floor = ABS_FLOOR
-            if names[t].endswith("_b") and len(src) > 2 and t == src[2] and ref.grad(dst[0]) is not None:
-                floor = _sum_floor(ref.grad(dst[0]))  # db[c] = sum over (n, hw) of the node's (rewritten) dst gradient
+            if names[t].endswith("_b") and t in src[2:] and pre_dy is not None and pre_dy.ndim == 4:
+                # a bias gradient is a per-channel sum over (n, hw) of the node's dst gradient (as it came in, or as
+                # rewritten by the fused activation / batch-norm backward)
+                floor = max(_sum_floor(pre_dy), _sum_floor(ref.grad(dst[0])))
             check("bwd", hip.grad(t), ref.grad(t), what, floor=floor)
     ref.close()
     hip.close()
