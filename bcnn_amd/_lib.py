@@ -73,6 +73,13 @@ SIGNATURES = {
     "bcnn_hip_axpy_strided": (None, [i, f, vp, vp] + [i] * 11),
     "bcnn_hip_add_rowvec": (None, [vp, vp, i, i]),
     "bcnn_hip_softmax_forward": (None, [vp, vp, i, i, i]),
+    "bcnn_hip_comm_init": (None, [i, i, C.c_char_p]),
+    "bcnn_hip_comm_destroy": (None, []),
+    "bcnn_hip_comm_world": (i, []),
+    "bcnn_hip_comm_rank": (i, []),
+    "bcnn_hip_allreduce_sum": (None, [vp, sz]),
+    "bcnn_hip_broadcast": (None, [vp, sz, i]),
+    "bcnn_hip_comm_join": (None, []),
 }
 
 _lib = None

@@ -62,7 +62,7 @@ def lib():
         "bcnn_add_eltwise_layer": (i, [vp, i, cp, cp, cp]), "bcnn_add_fullc_layer": (i, [vp, i, i, i, i, cp, cp]),
         "bcnn_add_softmax_layer": (i, [vp, cp, cp]), "bcnn_add_cost_layer": (i, [vp, i, i, f, cp, cp, cp]),
         "bcnn_upload_tensor": (i, [vp, i, i]), "bcnn_download_tensor": (i, [vp, i, i]),
-        "bcnn_set_data_parallel": (i, [vp, i, i]),
+        "bcnn_set_data_parallel": (i, [vp, i, i]), "bcnn_set_data_parallel_comm": (i, [vp, i, i, cp]),
         "bcnn_set_gradient_ready_callback": (None, [vp, vp, vp]),
         "bcnn_get_gradient_arena": (vp, [vp, C.POINTER(sz)]), "bcnn_get_parameter_arena": (vp, [vp, C.POINTER(sz)]),
         "bcnn_synchronize": (None, [vp]), "bcnn_peek_tensor": (tp, [vp, i]), "bcnn_get_num_nodes": (i, [vp]),
@@ -209,6 +209,10 @@ class Net:
 
     def set_data_parallel(self, rank, world):
         assert self.L.bcnn_set_data_parallel(self.net, rank, world) == 0
+
+    def set_data_parallel_comm(self, rank, world, id_path=None):
+        """RCCL inside the library: bcnn_backward all-reduces the gradient arena itself (include/bcnn/bcnn.h)"""
+        assert self.L.bcnn_set_data_parallel_comm(self.net, rank, world, id_path.encode() if id_path else None) == 0
 
     def set_gradient_ready_callback(self, fn):
         """fn(first_float, num_floats) is called inside backward() as tail ranges of the gradient arena

@@ -35,6 +35,42 @@ KTimer::~KTimer() {
     if (idx >= 0) HIP_CHECK(hipEventRecord((*g_records)[idx].b, g_stream));
 }
 
+// The first device-touching HIP call initialises the runtime, and that initialisation re-seeds / consumes libc's
+// rand() (measured: srand(7); hipMalloc; rand() differs from run to run, tools/exp/dbg_rand.py). The reference's
+// builders -- and this build's, for source compatibility -- draw their initial weights from rand()
+// (bcnn_tensor.c:53-58), so a program that calls srand(seed) before building its net would get different parameters
+// in every run and on every rank of a data-parallel job. Every entry point that can be the first to touch a device
+// therefore forces the initialisation here, with the caller's generator state parked aside (rand() and random()
+// share it in glibc; initstate / setstate swap it out and back).
+__global__ void warm_kernel(float* p) { if (p && threadIdx.x == 0) p[0] = 1.0f; }
+
+static void warm_device_keeping_rand_state() {
+    static thread_local unsigned long long warmed = 0;  // bit per device ordinal
+    static thread_local bool any = false;
+    int dev = 0;
+    if (any) {  // the runtime itself is up: hipGetDevice is a plain query now
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || ((warmed >> dev) & 1ull)) return;
+    }
+    char scratch_state[256];
+    char* user_state = initstate(1u, scratch_state, sizeof(scratch_state));  // park the caller's generator
+    void* p = nullptr;
+    (void)hipFree(nullptr);
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (hipMalloc(&p, 256) == hipSuccess) {
+        // memset, a kernel launch and a copy: queue creation and code-object loading happen on first use
+        float h = 0.f;
+        (void)hipMemsetAsync(p, 0, 256, nullptr);
+        warm_kernel<<<1, 64, 0, nullptr>>>((float*)p);
+        (void)hipMemcpy(&h, p, sizeof(float), hipMemcpyDeviceToHost);
+        (void)hipDeviceSynchronize();
+        (void)hipFree(p);
+    }
+    (void)hipDeviceSynchronize();
+    if (user_state) setstate(user_state);
+    any = true;
+    if (dev >= 0 && dev < 64) warmed |= 1ull << dev;
+}
+
 __global__ void fill_f32_kernel(float* __restrict__ x, size_t n, float v) {
     // scalar head up to 16-byte alignment, 16-byte stores on the body, scalar tail
     size_t head = ((16 - (reinterpret_cast<uintptr_t>(x) & 15)) & 15) / 4;
@@ -61,7 +97,10 @@ int bcnn_hip_device_count(void) {
     return n;
 }
 
-void bcnn_hip_set_device(int id) { HIP_CHECK(hipSetDevice(id)); }
+void bcnn_hip_set_device(int id) {
+    HIP_CHECK(hipSetDevice(id));
+    warm_device_keeping_rand_state();
+}
 
 int bcnn_hip_get_device(void) {
     int id = 0;
@@ -80,6 +119,7 @@ const char* bcnn_hip_device_name(void) {
 float* bcnn_hip_malloc_f32(size_t n) {
     float* p = nullptr;
     if (n == 0) return nullptr;
+    warm_device_keeping_rand_state();
     HIP_CHECK(hipMalloc((void**)&p, n * sizeof(float)));
     HIP_CHECK(hipMemsetAsync(p, 0, n * sizeof(float), current_stream()));
     return p;
@@ -88,6 +128,7 @@ float* bcnn_hip_malloc_f32(size_t n) {
 int* bcnn_hip_malloc_i32(size_t n) {
     int* p = nullptr;
     if (n == 0) return nullptr;
+    warm_device_keeping_rand_state();
     HIP_CHECK(hipMalloc((void**)&p, n * sizeof(int)));
     HIP_CHECK(hipMemsetAsync(p, 0, n * sizeof(int), current_stream()));
     return p;
@@ -125,6 +166,7 @@ void bcnn_hip_sync(void) { HIP_CHECK(hipStreamSynchronize(current_stream())); }
 
 void* bcnn_hip_stream_create(void) {
     hipStream_t s;
+    warm_device_keeping_rand_state();
     HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     return (void*)s;
 }

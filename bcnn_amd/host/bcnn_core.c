@@ -244,6 +244,7 @@ void bcnn_end_net(bcnn_net **pnet) {
     if (!net) return;
     bcnn_hip_sync();
     bcnn_hip_context *hc = hctx(net);
+    if (hc->comm_active) bcnn_hip_comm_destroy();
     /* arena members do not own their device buffers */
     if (hc->compiled) {
         for (int i = 0; i < hc->arena_members; ++i) { /* parameters added after the last compile still own theirs */
@@ -399,6 +400,8 @@ int bcnn_grad_sole_writer(bcnn_net *net, int tensor) {
     return hc->grad_fill_dead && tensor >= 0 && tensor < hc->grad_fill_count && hc->grad_fill_dead[tensor] == 2;
 }
 
+static void comm_sync_parameters(bcnn_net *net);
+
 bcnn_status bcnn_compile_net(bcnn_net *net) {
     bcnn_hip_context *hc = hctx(net);
     /* (re)allocate the input tensor, as bcnn_init_workload does (reference bcnn_net.c:337-359) */
@@ -428,6 +431,7 @@ bcnn_status bcnn_compile_net(bcnn_net *net) {
         build_arenas(net);
         hc->compiled = 1;
         if (hc->grad_ready_fn) bcnn_set_gradient_ready_callback(net, hc->grad_ready_fn, hc->grad_ready_user);
+        comm_sync_parameters(net); /* communicator installed before the arena existed / new parameters appeared */
     }
     mark_dead_grad_fills(net);
     bcnn_hip_sync();
@@ -460,9 +464,25 @@ void bcnn_forward(bcnn_net *net) {
     }
 }
 
+/* in-library data parallelism: the gradient-ready callback of bcnn_set_data_parallel_comm */
+static void comm_flush(bcnn_hip_context *hc) {
+    if (hc->comm_lo < hc->comm_hi) {
+        bcnn_hip_allreduce_sum(hc->grad_arena_gpu + hc->comm_lo, hc->comm_hi - hc->comm_lo);
+        hc->comm_hi = hc->comm_lo;
+    }
+}
+
+static void comm_on_ready(size_t first, size_t count, void *user) {
+    bcnn_hip_context *hc = (bcnn_hip_context *)user;
+    (void)count; /* ranges arrive as a growing tail: [first, comm_lo) is new */
+    hc->comm_lo = first;
+    if (hc->comm_hi - hc->comm_lo >= hc->comm_bucket) comm_flush(hc);
+}
+
 void bcnn_backward(bcnn_net *net) {
     bcnn_hip_context *hc = hctx(net);
     size_t ready_from = hc->arena_size;
+    if (hc->comm_active) hc->comm_lo = hc->comm_hi = hc->arena_size;
     for (int i = net->num_nodes - 1; i >= 0; --i) {
         net->nodes[i].backward(net, &net->nodes[i]);
         if (hc->grad_ready_fn && hc->node_grad_first && hc->node_grad_first[i] < ready_from) {
@@ -472,6 +492,10 @@ void bcnn_backward(bcnn_net *net) {
     }
     if (hc->grad_ready_fn && ready_from > 0 && hc->arena_size > 0)  /* members no node claims (none today) */
         hc->grad_ready_fn(0, ready_from, hc->grad_ready_user);
+    if (hc->comm_active) {
+        comm_flush(hc);       /* what is left below the last full bucket */
+        bcnn_hip_comm_join(); /* bcnn_update (same stream) is ordered behind every bucket; the host does not block */
+    }
 }
 
 void bcnn_set_gradient_ready_callback(bcnn_net *net, bcnn_gradient_ready_fn fn, void *user) {
@@ -766,6 +790,31 @@ bcnn_status bcnn_set_data_parallel(bcnn_net *net, int rank, int world_size) {
     if (world_size < 1 || rank < 0 || rank >= world_size) return BCNN_INVALID_PARAMETER;
     hctx(net)->dp_rank = rank;
     hctx(net)->dp_world = world_size;
+    return BCNN_SUCCESS;
+}
+
+/* every rank continues from rank 0's parameters, whatever its own initialisation drew */
+static void comm_sync_parameters(bcnn_net *net) {
+    bcnn_hip_context *hc = hctx(net);
+    if (!hc->comm_active || !hc->param_arena_gpu || hc->arena_size == 0) return;
+    bcnn_hip_broadcast(hc->param_arena_gpu, hc->arena_size, 0);
+    bcnn_hip_comm_join();
+}
+
+bcnn_status bcnn_set_data_parallel_comm(bcnn_net *net, int rank, int world_size, const char *id_path) {
+    if (world_size < 1 || rank < 0 || rank >= world_size) return BCNN_INVALID_PARAMETER;
+    if (world_size > 1 && (!id_path || !id_path[0])) return BCNN_INVALID_PARAMETER;
+    bcnn_hip_context *hc = hctx(net);
+    if (bcnn_hip_comm_world() == 0) bcnn_hip_comm_init(rank, world_size, id_path); /* fatal on failure */
+    if (bcnn_hip_comm_world() != world_size || bcnn_hip_comm_rank() != rank) return BCNN_INVALID_PARAMETER;
+    hc->dp_rank = rank;
+    hc->dp_world = world_size;
+    hc->comm_active = 1;
+    hc->comm_bucket = (size_t)(8u << 20) / sizeof(float);
+    /* node order == arena order, backward walks it in reverse: the callback sees a growing tail (recomputed by
+     * bcnn_compile_net when the arena is (re)built after this call) */
+    bcnn_set_gradient_ready_callback(net, comm_on_ready, hc);
+    comm_sync_parameters(net);
     return BCNN_SUCCESS;
 }
 

@@ -142,6 +142,10 @@ typedef struct bcnn_hip_context {
     void *sgd_chunks_gpu;
     int num_sgd_chunks, cap_sgd_chunks;
     int sgd_collecting;
+    /* RCCL inside the library (bcnn_set_data_parallel_comm): finished tail ranges of the gradient arena are gathered
+     * into buckets of comm_bucket floats and all-reduced on the communicator's stream while backward continues */
+    int comm_active;
+    size_t comm_bucket, comm_lo, comm_hi;
 } bcnn_hip_context;
 
 /* ---- net ------------------------------------------------------------------------------------------ */

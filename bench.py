@@ -230,6 +230,10 @@ class Workload:
             del x, lab
             gptr, gsize = net.gradient_arena()
             grads = torch.as_tensor(capi.DeviceArray(gptr, gsize), device=dev) if dp else None
+            if dp:   # every rank continues from rank 0's parameters, whatever its own initialisation drew
+                pptr, psize = net.parameter_arena()
+                dist.broadcast(torch.as_tensor(capi.DeviceArray(pptr, psize), device=dev), 0)
+                torch.cuda.synchronize()
             bar = None
             if dp and overlap:
                 # Gradient all-reduce overlapped with backward: the C executor reports growing tail ranges of the

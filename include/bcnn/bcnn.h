@@ -205,6 +205,15 @@ BCNN_API bcnn_status bcnn_add_yolo_layer(bcnn_net *net, int num_boxes_per_cell, 
 BCNN_API bcnn_status bcnn_upload_tensor(bcnn_net *net, int tensor_index, int with_grad);
 BCNN_API bcnn_status bcnn_download_tensor(bcnn_net *net, int tensor_index, int with_grad);
 BCNN_API bcnn_status bcnn_set_data_parallel(bcnn_net *net, int rank, int world_size);
+/* The same, with the collective INSIDE the library (RCCL over xGMI, include/bcnn_hip.h): for a plain C program run as
+ * one process per GPU (the reference's process model, src/cli/bcnn_cl.c:281-285). Call after bcnn_hip_set_device /
+ * before training; `id_path` names a file every rank can reach, unique per job, through which rank 0 hands out the
+ * RCCL id (world_size == 1 may pass NULL). From then on bcnn_backward all-reduces (sum) the weight-gradient arena
+ * itself -- in ~8 MB buckets as the owning nodes finish, on the communicator's stream, overlapped with the rest of
+ * backward -- and bcnn_update is ordered behind the last bucket; bcnn_train_on_batch needs no other change. The
+ * communicator is destroyed by bcnn_end_net. A launcher that runs the collective itself (bench.py through
+ * torch.distributed) keeps using bcnn_set_data_parallel + bcnn_get_gradient_arena. */
+BCNN_API bcnn_status bcnn_set_data_parallel_comm(bcnn_net *net, int rank, int world_size, const char *id_path);
 BCNN_API float *bcnn_get_gradient_arena(bcnn_net *net, size_t *num_floats);  /* device pointer */
 BCNN_API float *bcnn_get_parameter_arena(bcnn_net *net, size_t *num_floats); /* device pointer */
 /* Overlap of the gradient all-reduce with backward. Parameters sit in the arena in node order and backward

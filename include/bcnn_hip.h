@@ -271,6 +271,29 @@ void bcnn_hip_axpy_strided(int num_batches, float a, const float *x_d, float *y_
 void bcnn_hip_add_rowvec(float *y_d, const float *v_d, int rows, int cols);
 void bcnn_hip_softmax_forward(const float *x_d, float *y_d, int n, int c, int hw);
 
+/* ---------------------------------------------------------------------------------------------
+ * Data-parallel exchange (RCCL over xGMI).  No reference counterpart (the reference is single-device); process
+ * model = the reference's one device per process (bcnn_cuda_set_device once in main, src/cli/bcnn_cl.c:281-285,
+ * src/bcnn_utils.c:201): N processes, each after bcnn_hip_set_device(local rank), form one communicator.
+ *   comm_init     : rank 0 creates the RCCL unique id and publishes it at `id_path` (a file all ranks can see, unique
+ *                   per job; atomic rename), the others wait for it (<= 120 s), then ncclCommInitRank on the current
+ *                   device. world == 1 may pass NULL. RCCL is dlopen'ed here, not linked. One communicator per process.
+ *   allreduce_sum : in-place sum of n floats across the ranks, queued on the communicator's own stream AFTER the
+ *                   work queued so far on the calling thread's stream (event ordering, no host block). Every rank
+ *                   must issue the same sequence of calls.
+ *   broadcast     : rank `root`'s n floats replace every other rank's, same ordering rules (a data-parallel job
+ *                   starts from rank 0's parameters whatever each rank's own initialisation drew).
+ *   comm_join     : the calling thread's stream waits for every collective queued so far (no host block).
+ * Any RCCL / HIP failure prints and exit()s like every other device error.
+ * ------------------------------------------------------------------------------------------- */
+void bcnn_hip_comm_init(int rank, int world, const char *id_path);
+void bcnn_hip_comm_destroy(void);
+int bcnn_hip_comm_world(void);   /* 0 while no communicator exists */
+int bcnn_hip_comm_rank(void);
+void bcnn_hip_allreduce_sum(float *buf_d, size_t n);
+void bcnn_hip_broadcast(float *buf_d, size_t n, int root);
+void bcnn_hip_comm_join(void);
+
 #ifdef __cplusplus
 }
 #endif
