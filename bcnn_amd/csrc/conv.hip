@@ -31,6 +31,10 @@ bool conv_backward_weights_direct(const float* x, const float* dy, float* dw, fl
 bool conv_forward_winograd(const float* x, const float* w, const float* bias, const float* slopes, float* y,
                            const ConvShape& s, int act, int raw, ConvStats* stats);
 bool conv_backward_data_winograd(const float* w, const float* dy, float* dx, const ConvShape& s);
+// conv_winograd_fused.hip: the same algorithm in one kernel for the wide-and-shallow layers
+bool conv_forward_winograd_fused(const float* x, const float* w, const float* bias, const float* slopes, float* y,
+                                 const ConvShape& s, int act, int raw, ConvStats* stats);
+bool conv_backward_data_winograd_fused(const float* w, const float* dy, float* dx, const ConvShape& s);
 size_t conv_dw_winograd_workspace_floats(const ConvShape& s);
 bool conv_backward_weights_winograd(const float* x, const float* dy, float* dw, const ConvShape& s, float* workspace,
                                     size_t workspace_floats);
@@ -66,6 +70,7 @@ static void conv_fwd_any(const float* x, const float* w, const float* bias, cons
                          const ConvShape& s, int act, int raw, ConvStats* stats = nullptr) {
     if (stats) stats->splits = 0;
     if (conv_forward_direct(x, w, bias, slopes, y, s, act, raw)) return;
+    if (conv_forward_winograd_fused(x, w, bias, slopes, y, s, act, raw, stats)) return;
     if (conv_forward_winograd(x, w, bias, slopes, y, s, act, raw, stats)) return;
     conv_forward_dispatch(x, w, bias, slopes, y, s, act, raw, stats);
 }
@@ -169,7 +174,8 @@ void bcnn_hip_conv_backward(const float* x, const float* w, const float* bias, c
         set_current_stream(main_stream);
     }
     if (!batch_norm && !bias_done) bcnn_hip_grad_bias(dbias, dy, n, f, s.OHOW);  // uses the shared reduce scratch
-    if (dx && !conv_backward_data_winograd(w, dy, dx, s)) conv_backward_data(w, dy, dx, s);
+    if (dx && !conv_backward_data_winograd_fused(w, dy, dx, s) && !conv_backward_data_winograd(w, dy, dx, s))
+        conv_backward_data(w, dy, dx, s);
     if (side) HIP_CHECK(hipStreamWaitEvent(main_stream, side->done, 0));
 }
 

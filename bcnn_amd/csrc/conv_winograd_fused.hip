@@ -1,0 +1,381 @@
+// conv_winograd_fused.hip -- Winograd F(2x2, 3x3) forward / dX in ONE kernel, for the wide-and-shallow 3x3 / s1
+// layers (64 and 128 channels at 56x56 / 28x28) where the three-kernel form of conv_winograd.hip loses: there the
+// transformed tensors V and M are 4x the activation each (0.4 GB per layer at N = 128) and streaming them through HBM
+// costs more than the 2.25x fewer MACs save. Here V only ever exists in LDS and M only in the accumulators:
+//
+//   workgroup = 64 output channels x 64 tiles (2x2 outputs each) x all 16 Winograd positions xi, 8 waves;
+//   wave w owns positions xi = 2w, 2w+1: acc[2][2 f-tiles][2 t-tiles] of 32x32 (128 accumulator registers);
+//   K loop over 8 input channels at a time:
+//     U chunk [16][8][64 f]  transformed weights, global -> LDS by LDS-DMA (16 B per lane, 4 rows per instruction);
+//     V chunk [16][8][64 t]  wave w loads the 4x4 patches of channel w for the 64 tiles straight into registers
+//                            (buffer loads: an out-of-range offset returns the zero padding), requested BEFORE the
+//                            MFMAs of the current chunk and transformed (B^T d B, 32 adds) and written to the other
+//                            LDS stage AFTER them -- the loads fly under 32 MFMAs per wave;
+//     32 v_mfma_f32_32x32x2_f32 per wave and chunk, operands by ds_read_b32 (conflict-free: f / t contiguous);
+//   epilogue: accumulators -> LDS as M[xi][f][t] (two halves of 32 channels), then one (f, t) per lane: A^T m A,
+//   bias / activation, 8-byte stores, and for a fused batch-norm the per-channel sum / sum of squares of the
+//   stored values by a wave reduction (a wave holds one channel x 64 tiles).
+// dX of such a layer is the same convolution of dy with the rotated, transposed filter.
+//
+// Reference: bcnn_forward_conv_layer_cpu's Winograd branch (bcnn_conv_layer.c:388-436) on bcnn_mat.c:1403-2138
+// (PREDICT mode there; here also TRAIN forward / dX, inside the 1e-4 parity bar).
+#include "conv_common.h"
+#include "lds_dma.h"
+
+namespace bcnn_hip {
+
+constexpr int WF_BT = 64;  // tiles per workgroup
+constexpr int WF_BF = 64;  // output channels per workgroup
+constexpr int WF_KC = 8;   // reduction channels per chunk == waves per workgroup (wave w transforms channel w)
+constexpr int WF_STAGE = 16 * WF_KC * (WF_BF + WF_BT);  // floats per LDS stage: U then V
+
+struct WinoFusedArgs {
+    const float* src;  // x (forward) or dy (dX): [N][J][H][W]
+    const float* upk;  // transformed weights [16][Jpad][Mpad], zero padded
+    float* dst;        // [N][M][H][W]
+    const float* bias;
+    const float* slopes;
+    float* stats;      // optional: [M][tblocks][2]
+    int N, J, M, H, W, TH, TW;
+    unsigned T;
+    int Jpad, Mpad, mblocks, tblocks;
+    int act, add_bias;
+    unsigned src_bytes, upk_bytes;
+};
+
+__global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * WF_STAGE];  // 128 KB: two stages; the epilogue's M[16][32][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int mb = lb % a.mblocks, tb = lb / a.mblocks;
+    const int m0 = mb * WF_BF;
+    const int HW = a.H * a.W;
+
+    // ---- this lane's tile (the same one for the input transform and for the output transform) -----------
+    const unsigned t = (unsigned)tb * WF_BT + (unsigned)lane;
+    const bool tile_ok = t < a.T;
+    const unsigned per_img = (unsigned)(a.TH * a.TW);
+    const unsigned n = tile_ok ? t / per_img : 0u;
+    const unsigned rr = tile_ok ? t - n * per_img : 0u;
+    const int th = (int)(rr / (unsigned)a.TW), tw = (int)(rr - (unsigned)th * (unsigned)a.TW);
+    const int ih0 = 2 * th - 1, iw0 = 2 * tw - 1;
+    unsigned voff[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ih = ih0 + i, iw = iw0 + j;
+            const bool ok = tile_ok && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+            voff[i][j] = ok ? ((n * (unsigned)a.J * (unsigned)HW) + (unsigned)(ih * a.W + iw)) * 4u : kOOB;
+        }
+    const auto rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src), 0, (int)a.src_bytes, 0x00020000);
+    const rsrc_i4 rs_u = make_rsrc(a.upk, a.upk_bytes);
+    const unsigned lds0 = lds_offset(&lds[0]);
+    // LDS-DMA of U: 4 rows (k) x 64 floats per instruction; lane -> row lane / 16, floats 4 * (lane % 16) ..
+    const unsigned u_voff = ((unsigned)(lane >> 4) * (unsigned)a.Mpad + (unsigned)(lane & 15) * 4u) * 4u;
+
+    float d[4][4];
+    auto load_patch = [&](int kc) {  // channel kc*8 + wid of this lane's tile
+        const unsigned soff = (unsigned)(kc * WF_KC + wid) * (unsigned)HW * 4u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                d[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_src, (int)voff[i][j], (int)soff, 0));
+    };
+    auto dma_u = [&](int kc, int stage) {  // wave w brings in its own two positions: 2 x 8 rows of 64 floats
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int xi = 2 * wid + (q >> 1), r0 = (q & 1) * 4;
+            const unsigned soff = (((unsigned)xi * (unsigned)a.Jpad + (unsigned)(kc * WF_KC + r0)) * (unsigned)a.Mpad + (unsigned)m0) * 4u;
+            dma_row_x4(rs_u, lds0 + (unsigned)((stage * WF_STAGE + (xi * WF_KC + r0) * WF_BF) * 4), u_voff, soff);
+        }
+    };
+    auto write_v = [&](int stage) {  // B^T d B -> V[xi][wid][lane]
+        float tt[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            tt[0][j] = d[0][j] - d[2][j];
+            tt[1][j] = d[1][j] + d[2][j];
+            tt[2][j] = d[2][j] - d[1][j];
+            tt[3][j] = d[1][j] - d[3][j];
+        }
+        float* v = lds + stage * WF_STAGE + 16 * WF_KC * WF_BF + wid * WF_BT + lane;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[(4 * i + 0) * WF_KC * WF_BT] = tt[i][0] - tt[i][2];
+            v[(4 * i + 1) * WF_KC * WF_BT] = tt[i][1] + tt[i][2];
+            v[(4 * i + 2) * WF_KC * WF_BT] = tt[i][2] - tt[i][1];
+            v[(4 * i + 3) * WF_KC * WF_BT] = tt[i][1] - tt[i][3];
+        }
+    };
+
+    f32x16 acc[2][2][2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[e][i][j][r] = 0.f;
+
+    const int nchunks = a.Jpad / WF_KC;
+    dma_u(0, 0);
+    load_patch(0);
+    write_v(0);
+    dma_wait();
+    __syncthreads();
+    for (int kc = 0; kc < nchunks; ++kc) {
+        const int cur = kc & 1, nxt = cur ^ 1;
+        const bool more = kc + 1 < nchunks;
+        if (more) {
+            dma_u(kc + 1, nxt);   // stage `nxt` was last read before the barrier that ended iteration kc - 1
+            load_patch(kc + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // requests first, then the MFMAs they fly under
+        const float* us = lds + cur * WF_STAGE + (2 * wid) * WF_KC * WF_BF;
+        const float* vs = lds + cur * WF_STAGE + 16 * WF_KC * WF_BF + (2 * wid) * WF_KC * WF_BT;
+#pragma unroll
+        for (int ks = 0; ks < WF_KC / 2; ++ks) {
+            float af[2][2], bf[2][2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    af[e][i] = us[(e * WF_KC + 2 * ks + lhi) * WF_BF + i * 32 + l31];
+                    bf[e][i] = vs[(e * WF_KC + 2 * ks + lhi) * WF_BT + i * 32 + l31];
+                }
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[e][i][j] = mfma32(af[e][i], bf[e][j], acc[e][i][j]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) write_v(nxt);
+        dma_wait();
+        __syncthreads();
+    }
+
+    // ---- epilogue: M[xi][f][t] through LDS, 32 channels at a time ---------------------------------------
+    const bool plain = !a.add_bias && a.act == BCNN_HIP_ACT_NONE;
+    const int oh = 2 * th, ow = 2 * tw;
+    const bool two_cols = ow + 1 < a.W, two_rows = oh + 1 < a.H;
+    const bool vec2 = (a.W & 1) == 0;  // rows start 8-byte aligned, ow is even
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (half) __syncthreads();  // the first half's readers are done
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    lds[((2 * wid + e) * 32 + mfma_row(r, lane)) * WF_BT + j * 32 + l31] = acc[e][half][j][r];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int fl = q * 8 + wid;               // wave-uniform channel inside the half
+            const int f = m0 + half * 32 + fl;
+            if (f >= a.M) continue;                   // uniform
+            float m[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) m[k] = lds[(k * 32 + fl) * WF_BT + lane];
+            float s[2][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s[0][j] = m[j] + m[4 + j] + m[8 + j];
+                s[1][j] = m[4 + j] - m[8 + j] - m[12 + j];
+            }
+            float o[2][2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                o[r][0] = s[r][0] + s[r][1] + s[r][2];
+                o[r][1] = s[r][1] - s[r][2] - s[r][3];
+            }
+            if (!plain) {
+                float b = a.add_bias ? a.bias[f] : 0.f;
+                if (b == 1.0f) b = 0.f;  // bcnn_add_scalar of the AVX build adds nothing for exactly 1.0f (quirk 2)
+                const float sl = (a.act == BCNN_HIP_ACT_PRELU && a.slopes) ? a.slopes[f] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        float vv = o[r][c];
+                        if (b != 0.0f) vv += b;
+                        if (a.act != BCNN_HIP_ACT_NONE) vv = act_fwd_cheap(vv, a.act, sl);
+                        o[r][c] = vv;
+                    }
+            }
+            float sv = 0.f, sq = 0.f;
+            if (tile_ok) {
+                float* row = a.dst + ((size_t)(n * (unsigned)a.M + (unsigned)f) * (size_t)HW) + (size_t)(oh * a.W + ow);
+                if (vec2) {
+                    *reinterpret_cast<float2*>(row) = make_float2(o[0][0], o[0][1]);
+                    if (two_rows) *reinterpret_cast<float2*>(row + a.W) = make_float2(o[1][0], o[1][1]);
+                } else {
+                    row[0] = o[0][0];
+                    if (two_cols) row[1] = o[0][1];
+                    if (two_rows) {
+                        row[a.W] = o[1][0];
+                        if (two_cols) row[a.W + 1] = o[1][1];
+                    }
+                }
+                if (a.stats) {
+                    sv = o[0][0]; sq = o[0][0] * o[0][0];
+                    if (two_cols) { sv += o[0][1]; sq += o[0][1] * o[0][1]; }
+                    if (two_rows) {
+                        sv += o[1][0]; sq += o[1][0] * o[1][0];
+                        if (two_cols) { sv += o[1][1]; sq += o[1][1] * o[1][1]; }
+                    }
+                }
+            }
+            if (a.stats) {  // this wave holds channel f for the workgroup's 64 tiles
+                sv = wave_sum(sv);
+                sq = wave_sum(sq);
+                if (lane == 0) {
+                    float* p = a.stats + ((size_t)f * a.tblocks + tb) * 2;
+                    p[0] = sv; p[1] = sq;
+                }
+            }
+        }
+    }
+}
+
+// U[xi][j][m] = (G g G^T)[xi] packed [16][Jpad][Mpad] with zero padding.
+//   forward: m = f, j = c; dX: m = c, j = f and the filter rotated by 180 degrees
+__global__ __launch_bounds__(256) void wino_pack_weights_kernel(const float* __restrict__ w, float* __restrict__ u, int F,
+                                                                int C, int dx_mode, int Jpad, int Mpad) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= Jpad * Mpad) return;
+    const int j = idx / Mpad, m = idx - j * Mpad;
+    const int M = dx_mode ? C : F, J = dx_mode ? F : C;
+    float t[4][3];
+    if (m < M && j < J) {
+        const int f = dx_mode ? j : m, c = dx_mode ? m : j;
+        const float* p = w + ((size_t)f * C + c) * 9;
+        float g[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) g[r][b] = dx_mode ? p[(2 - r) * 3 + (2 - b)] : p[r * 3 + b];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            t[0][b] = g[0][b];
+            t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+            t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+            t[3][b] = g[2][b];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) t[r][b] = 0.f;
+    }
+    const size_t plane = (size_t)Jpad * Mpad;
+    float* dst = u + idx;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        dst[(size_t)(4 * r + 0) * plane] = t[r][0];
+        dst[(size_t)(4 * r + 1) * plane] = 0.5f * (t[r][0] + t[r][1] + t[r][2]);
+        dst[(size_t)(4 * r + 2) * plane] = 0.5f * (t[r][0] - t[r][1] + t[r][2]);
+        dst[(size_t)(4 * r + 3) * plane] = t[r][2];
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------
+struct WfScratch {
+    float* p = nullptr;
+    size_t cap = 0;
+    int dev = -1;
+};
+static thread_local WfScratch g_wf_scratch;
+static float* wf_scratch(size_t floats) {
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    WfScratch& sc = g_wf_scratch;
+    if (sc.p == nullptr || sc.cap < floats || sc.dev != dev) {
+        if (sc.p && sc.dev == dev) {
+            HIP_CHECK(hipStreamSynchronize(current_stream()));
+            HIP_CHECK(hipFree(sc.p));
+        }
+        const size_t cap = floats < (1u << 20) ? (1u << 20) : floats;
+        HIP_CHECK(hipMalloc((void**)&sc.p, cap * sizeof(float)));
+        sc.cap = cap;
+        sc.dev = dev;
+    }
+    return sc.p;
+}
+
+static int g_wf_force = -1;  // experiment build: BCNN_HIP_WINOGRAD_FUSED=0/1 overrides the rule
+static bool wino_fused_wanted(const ConvShape& s, int J, int M) {
+    if (s.ksz != 3 || s.stride != 1 || s.pad != 1 || s.groups != 1) return false;
+    if (J < 16 || (J % WF_KC) != 0 || M < 32) return false;
+    if ((size_t)s.N * J * s.HW * 4 >= 0x7ffffff0ull || (size_t)s.N * M * s.HW * 4 >= 0x7ffffff0ull) return false;
+    if (g_wf_force < 0) {
+        const char* e = BCNN_EXP_ENV("BCNN_HIP_WINOGRAD_FUSED");
+        g_wf_force = e ? (e[0] == '0' ? 0 : 1) : 2;
+    }
+    if (g_wf_force != 2) return g_wf_force == 1;
+    // the layers whose transformed tensors would not stay on chip in the three-kernel form (conv_winograd.hip takes
+    // the deeper ones): 64 / 128 channels at 56x56 / 28x28 in the benchmark
+    const double T = (double)s.N * ((s.H + 1) / 2) * ((s.W + 1) / 2);
+    const double vm_bytes = 16.0 * T * (s.C + s.F) * 4.0;
+    return s.C >= 64 && s.F >= 64 && s.C <= 128 && s.F <= 128 && vm_bytes > 230e6;
+}
+
+static void wino_fused_run(const float* src, const float* w, float* dst, const ConvShape& s, int dx_mode,
+                           const float* bias, const float* slopes, int act, int add_bias, ConvStats* stats) {
+    WinoFusedArgs a;
+    a.src = src; a.dst = dst; a.bias = bias; a.slopes = slopes;
+    a.N = s.N; a.J = dx_mode ? s.F : s.C; a.M = dx_mode ? s.C : s.F; a.H = s.H; a.W = s.W;
+    a.TH = (s.H + 1) / 2; a.TW = (s.W + 1) / 2;
+    a.T = (unsigned)((long long)s.N * a.TH * a.TW);
+    a.Jpad = (a.J + WF_KC - 1) / WF_KC * WF_KC;
+    a.Mpad = (a.M + WF_BF - 1) / WF_BF * WF_BF;
+    a.mblocks = a.Mpad / WF_BF;
+    a.tblocks = (int)((a.T + WF_BT - 1) / WF_BT);
+    a.act = act; a.add_bias = add_bias;
+    a.src_bytes = (unsigned)((size_t)s.N * a.J * s.HW * 4);
+    const size_t u_floats = (size_t)16 * a.Jpad * a.Mpad;
+    a.upk_bytes = (unsigned)(u_floats * 4);
+    float* U = wf_scratch(u_floats);
+    a.upk = U;
+    wino_pack_weights_kernel<<<ceil_div((long long)a.Jpad * a.Mpad, 256), 256, 0, current_stream()>>>(w, U, s.F, s.C, dx_mode,
+                                                                                                    a.Jpad, a.Mpad);
+    KERNEL_CHECK();
+    a.stats = (stats && stats->partials) ? stats->partials : nullptr;
+    wino_fused_kernel<<<(unsigned)(a.tblocks * a.mblocks), 512, 0, current_stream()>>>(a);
+    KERNEL_CHECK();
+    if (stats) stats->splits = a.stats ? a.tblocks : 0;
+}
+
+static double wf_flops(const ConvShape& s) {
+    const double T = (double)s.N * ((s.H + 1) / 2) * ((s.W + 1) / 2);
+    return 2.0 * 16.0 * T * s.C * s.F;
+}
+static double wf_bytes(const ConvShape& s) {
+    return 4.0 * ((double)s.N * s.C * s.HW + (double)s.F * s.K + (double)s.N * s.F * s.OHOW);
+}
+
+bool conv_forward_winograd_fused(const float* x, const float* w, const float* bias, const float* slopes, float* y,
+                                 const ConvShape& s, int act, int raw, ConvStats* stats) {
+    if (!wino_fused_wanted(s, s.C, s.F)) return false;
+    KTimer kt(K_CONV_FWD_WINO, wf_flops(s), wf_bytes(s));
+    if (stats && !raw) stats->splits = 0;
+    wino_fused_run(x, w, y, s, 0, bias, slopes, raw ? BCNN_HIP_ACT_NONE : act, raw ? 0 : (bias != nullptr), raw ? stats : nullptr);
+    return true;
+}
+
+bool conv_backward_data_winograd_fused(const float* w, const float* dy, float* dx, const ConvShape& s) {
+    if (!wino_fused_wanted(s, s.F, s.C)) return false;
+    KTimer kt(K_CONV_DX_WINO, wf_flops(s), wf_bytes(s));
+    wino_fused_run(dy, w, dx, s, 1, nullptr, nullptr, BCNN_HIP_ACT_NONE, 0, nullptr);
+    return true;
+}
+
+}  // namespace bcnn_hip

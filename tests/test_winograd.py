@@ -57,10 +57,13 @@ def test_child_winograd_matches_oracle(shape):
 
 
 @pytest.mark.gpu
-def test_winograd_forced_on_small_shapes():
+@pytest.mark.parametrize("switch", ["BCNN_HIP_WINOGRAD", "BCNN_HIP_WINOGRAD_FUSED"],
+                         ids=["transform_kernels_around_the_grouped_gemm", "single_fused_kernel"])
+def test_winograd_forced_on_small_shapes(switch):
     exp = os.path.join(ROOT, "bcnn_amd", "lib", "libbcnn_hip_exp.so")
     assert os.path.exists(exp), "experiment build missing: __graft_entry__.build() makes it"
-    e = dict(os.environ, BCNN_WINO_CHILD="1", BCNN_HIP_LIB=exp, BCNN_HIP_WINOGRAD="1")
+    e = dict(os.environ, BCNN_WINO_CHILD="1", BCNN_HIP_LIB=exp, BCNN_HIP_WINOGRAD="0", BCNN_HIP_WINOGRAD_FUSED="0")
+    e[switch] = "1"
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-p",
                         "no:cacheprovider", "-k", "child"], cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
