@@ -4,7 +4,8 @@
 // costs more than the 2.25x fewer MACs save. Here V only ever exists in LDS and M only in the accumulators:
 //
 //   workgroup = 64 output channels x 64 tiles (2x2 outputs each) x all 16 Winograd positions xi, 8 waves;
-//   wave w owns positions xi = 2w, 2w+1: acc[2][2 f-tiles][2 t-tiles] of 32x32 (128 accumulator registers);
+//   wave w owns ROW i = w / 2 of the 4x4 position matrix (xi = 4i .. 4i+3) for 32 of the 64 channels:
+//   acc[4 positions][2 t-tiles] of 32x32 (128 accumulator registers);
 //   K loop over 8 input channels at a time:
 //     U chunk [16][8][64 f]  transformed weights, global -> LDS by LDS-DMA (16 B per lane, 4 rows per instruction);
 //     V chunk [16][8][64 t]  wave w loads the 4x4 patches of channel w for the 64 tiles straight into registers
@@ -12,9 +13,10 @@
 //                            MFMAs of the current chunk and transformed (B^T d B, 32 adds) and written to the other
 //                            LDS stage AFTER them -- the loads fly under 32 MFMAs per wave;
 //     32 v_mfma_f32_32x32x2_f32 per wave and chunk, operands by ds_read_b32 (conflict-free: f / t contiguous);
-//   epilogue: accumulators -> LDS as M[xi][f][t] (two halves of 32 channels), then one (f, t) per lane: A^T m A,
-//   bias / activation, 8-byte stores, and for a fused batch-norm the per-channel sum / sum of squares of the
-//   stored values by a wave reduction (a wave holds one channel x 64 tiles).
+//   epilogue: a wave holds a whole row of M, so the column half of the output transform (M A: 4 -> 2 values) is done
+//   on the accumulators; S[i][b][f][t] (128 KB) goes through LDS once, then one (f, t) per lane finishes A^T S,
+//   adds bias / activation, stores 8 bytes per row, and for a fused batch-norm reduces the per-channel sum / sum
+//   of squares of the stored values over the wave (a wave holds one channel x 64 tiles).
 // dX of such a layer is the same convolution of dy with the rotated, transposed filter.
 //
 // Reference: bcnn_forward_conv_layer_cpu's Winograd branch (bcnn_conv_layer.c:388-436) on bcnn_mat.c:1403-2138
@@ -43,171 +45,231 @@ struct WinoFusedArgs {
     unsigned src_bytes, upk_bytes;
 };
 
+// EPI: 0 = plain store, 1 = bias + ReLU, 2 = bias + any other cheap activation (runtime switch)
+//
+// Persistent: one workgroup per CU (128 KB of LDS) walks the (tile block, channel block) pairs with stride gridDim.x,
+// so no CU waits for a dispatch between blocks. The two halves of the workgroup run the chunk's phases in opposite
+// order -- waves 0-3 transform the NEXT chunk's patches first and multiply afterwards, waves 4-7 multiply first --
+// so that on every SIMD (which hosts one wave of each half) the vector-ALU / LDS-store work of one wave runs beside
+// the MFMAs of the other instead of both waves doing the same thing at the same time.
+template <int EPI>
 __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs a) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * WF_STAGE];  // 128 KB: two stages; the epilogue's M[16][32][64]
+    __shared__ __attribute__((aligned(16))) float lds[2 * WF_STAGE];  // 128 KB: two stages; the epilogue's S[4][2][64][64]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lhi = lane >> 5;
-    const int lb = xcd_remap(blockIdx.x, gridDim.x);
-    const int mb = lb % a.mblocks, tb = lb / a.mblocks;
-    const int m0 = mb * WF_BF;
     const int HW = a.H * a.W;
-
-    // ---- this lane's tile (the same one for the input transform and for the output transform) -----------
-    const unsigned t = (unsigned)tb * WF_BT + (unsigned)lane;
-    const bool tile_ok = t < a.T;
-    const unsigned per_img = (unsigned)(a.TH * a.TW);
-    const unsigned n = tile_ok ? t / per_img : 0u;
-    const unsigned rr = tile_ok ? t - n * per_img : 0u;
-    const int th = (int)(rr / (unsigned)a.TW), tw = (int)(rr - (unsigned)th * (unsigned)a.TW);
-    const int ih0 = 2 * th - 1, iw0 = 2 * tw - 1;
-    unsigned voff[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int ih = ih0 + i, iw = iw0 + j;
-            const bool ok = tile_ok && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
-            voff[i][j] = ok ? ((n * (unsigned)a.J * (unsigned)HW) + (unsigned)(ih * a.W + iw)) * 4u : kOOB;
-        }
+    const int wrow = wid >> 1, fh = wid & 1;  // this wave's row of positions and its half of the 64 channels
+    const bool early = wid < 4;               // transforms at the head of a chunk (see above)
     const auto rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src), 0, (int)a.src_bytes, 0x00020000);
     const rsrc_i4 rs_u = make_rsrc(a.upk, a.upk_bytes);
     const unsigned lds0 = lds_offset(&lds[0]);
     // LDS-DMA of U: 4 rows (k) x 64 floats per instruction; lane -> row lane / 16, floats 4 * (lane % 16) ..
     const unsigned u_voff = ((unsigned)(lane >> 4) * (unsigned)a.Mpad + (unsigned)(lane & 15) * 4u) * 4u;
+    const unsigned per_img = (unsigned)(a.TH * a.TW);
+    const int nchunks = a.Jpad / WF_KC;
+    const int nblocks = a.tblocks * a.mblocks;
 
-    float d[4][4];
-    auto load_patch = [&](int kc) {  // channel kc*8 + wid of this lane's tile
-        const unsigned soff = (unsigned)(kc * WF_KC + wid) * (unsigned)HW * 4u;
+    for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+        const int mb = blk % a.mblocks, tb = blk / a.mblocks;  // channel blocks of one tile block run together
+        const int m0 = mb * WF_BF;
+        if (blk != (int)blockIdx.x) __syncthreads();  // the previous block's epilogue has read S
+
+        // ---- this lane's tile (the same one for the input transform and for the output transform) -------
+        const unsigned t = (unsigned)tb * WF_BT + (unsigned)lane;
+        const bool tile_ok = t < a.T;
+        const unsigned n = tile_ok ? t / per_img : 0u;
+        const unsigned rr = tile_ok ? t - n * per_img : 0u;
+        const int th = (int)(rr / (unsigned)a.TW), tw = (int)(rr - (unsigned)th * (unsigned)a.TW);
+        const int ih0 = 2 * th - 1, iw0 = 2 * tw - 1;
+        unsigned voff[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                d[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_src, (int)voff[i][j], (int)soff, 0));
-    };
-    auto dma_u = [&](int kc, int stage) {  // wave w brings in its own two positions: 2 x 8 rows of 64 floats
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int xi = 2 * wid + (q >> 1), r0 = (q & 1) * 4;
-            const unsigned soff = (((unsigned)xi * (unsigned)a.Jpad + (unsigned)(kc * WF_KC + r0)) * (unsigned)a.Mpad + (unsigned)m0) * 4u;
-            dma_row_x4(rs_u, lds0 + (unsigned)((stage * WF_STAGE + (xi * WF_KC + r0) * WF_BF) * 4), u_voff, soff);
-        }
-    };
-    auto write_v = [&](int stage) {  // B^T d B -> V[xi][wid][lane]
-        float tt[4][4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            tt[0][j] = d[0][j] - d[2][j];
-            tt[1][j] = d[1][j] + d[2][j];
-            tt[2][j] = d[2][j] - d[1][j];
-            tt[3][j] = d[1][j] - d[3][j];
-        }
-        float* v = lds + stage * WF_STAGE + 16 * WF_KC * WF_BF + wid * WF_BT + lane;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            v[(4 * i + 0) * WF_KC * WF_BT] = tt[i][0] - tt[i][2];
-            v[(4 * i + 1) * WF_KC * WF_BT] = tt[i][1] + tt[i][2];
-            v[(4 * i + 2) * WF_KC * WF_BT] = tt[i][2] - tt[i][1];
-            v[(4 * i + 3) * WF_KC * WF_BT] = tt[i][1] - tt[i][3];
-        }
-    };
+            for (int j = 0; j < 4; ++j) {
+                const int ih = ih0 + i, iw = iw0 + j;
+                const bool ok = tile_ok && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+                voff[i][j] = ok ? ((n * (unsigned)a.J * (unsigned)HW) + (unsigned)(ih * a.W + iw)) * 4u : kOOB;
+            }
 
-    f32x16 acc[2][2][2];
+        float d[4][4];
+        auto load_patch = [&](int kc) {  // channel kc*8 + wid of this lane's tile
+            const unsigned soff = (unsigned)(kc * WF_KC + wid) * (unsigned)HW * 4u;
 #pragma unroll
-    for (int e = 0; e < 2; ++e)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+                for (int j = 0; j < 4; ++j)
+                    d[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_src, (int)voff[i][j], (int)soff, 0));
+        };
+        auto dma_u = [&](int kc, int stage) {  // each wave brings in two positions: 2 x 8 rows of 64 floats
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[e][i][j][r] = 0.f;
-
-    const int nchunks = a.Jpad / WF_KC;
-    dma_u(0, 0);
-    load_patch(0);
-    write_v(0);
-    dma_wait();
-    __syncthreads();
-    for (int kc = 0; kc < nchunks; ++kc) {
-        const int cur = kc & 1, nxt = cur ^ 1;
-        const bool more = kc + 1 < nchunks;
-        if (more) {
-            dma_u(kc + 1, nxt);   // stage `nxt` was last read before the barrier that ended iteration kc - 1
-            load_patch(kc + 1);
-        }
-        __builtin_amdgcn_sched_barrier(0);  // requests first, then the MFMAs they fly under
-        const float* us = lds + cur * WF_STAGE + (2 * wid) * WF_KC * WF_BF;
-        const float* vs = lds + cur * WF_STAGE + 16 * WF_KC * WF_BF + (2 * wid) * WF_KC * WF_BT;
-#pragma unroll
-        for (int ks = 0; ks < WF_KC / 2; ++ks) {
-            float af[2][2], bf[2][2];
-#pragma unroll
-            for (int e = 0; e < 2; ++e)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    af[e][i] = us[(e * WF_KC + 2 * ks + lhi) * WF_BF + i * 32 + l31];
-                    bf[e][i] = vs[(e * WF_KC + 2 * ks + lhi) * WF_BT + i * 32 + l31];
-                }
-#pragma unroll
-            for (int e = 0; e < 2; ++e)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[e][i][j] = mfma32(af[e][i], bf[e][j], acc[e][i][j]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) write_v(nxt);
-        dma_wait();
-        __syncthreads();
-    }
-
-    // ---- epilogue: M[xi][f][t] through LDS, 32 channels at a time ---------------------------------------
-    const bool plain = !a.add_bias && a.act == BCNN_HIP_ACT_NONE;
-    const int oh = 2 * th, ow = 2 * tw;
-    const bool two_cols = ow + 1 < a.W, two_rows = oh + 1 < a.H;
-    const bool vec2 = (a.W & 1) == 0;  // rows start 8-byte aligned, ow is even
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        if (half) __syncthreads();  // the first half's readers are done
-#pragma unroll
-        for (int e = 0; e < 2; ++e)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    lds[((2 * wid + e) * 32 + mfma_row(r, lane)) * WF_BT + j * 32 + l31] = acc[e][half][j][r];
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int fl = q * 8 + wid;               // wave-uniform channel inside the half
-            const int f = m0 + half * 32 + fl;
-            if (f >= a.M) continue;                   // uniform
-            float m[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) m[k] = lds[(k * 32 + fl) * WF_BT + lane];
-            float s[2][4];
+            for (int q = 0; q < 4; ++q) {
+                const int xi = 2 * wid + (q >> 1), r0 = (q & 1) * 4;
+                const unsigned soff = (((unsigned)xi * (unsigned)a.Jpad + (unsigned)(kc * WF_KC + r0)) * (unsigned)a.Mpad + (unsigned)m0) * 4u;
+                dma_row_x4(rs_u, lds0 + (unsigned)((stage * WF_STAGE + (xi * WF_KC + r0) * WF_BF) * 4), u_voff, soff);
+            }
+        };
+        auto write_v = [&](int stage) {  // B^T d B -> V[xi][wid][lane]
+            float tt[4][4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                s[0][j] = m[j] + m[4 + j] + m[8 + j];
-                s[1][j] = m[4 + j] - m[8 + j] - m[12 + j];
+                tt[0][j] = d[0][j] - d[2][j];
+                tt[1][j] = d[1][j] + d[2][j];
+                tt[2][j] = d[2][j] - d[1][j];
+                tt[3][j] = d[1][j] - d[3][j];
             }
+            float* v = lds + stage * WF_STAGE + 16 * WF_KC * WF_BF + wid * WF_BT + lane;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[(4 * i + 0) * WF_KC * WF_BT] = tt[i][0] - tt[i][2];
+                v[(4 * i + 1) * WF_KC * WF_BT] = tt[i][1] + tt[i][2];
+                v[(4 * i + 2) * WF_KC * WF_BT] = tt[i][2] - tt[i][1];
+                v[(4 * i + 3) * WF_KC * WF_BT] = tt[i][1] - tt[i][3];
+            }
+        };
+
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][tt][r] = 0.f;
+
+        auto multiply = [&](int cur) {  // 32 MFMAs on stage `cur`
+            const float* us = lds + cur * WF_STAGE + (4 * wrow) * WF_KC * WF_BF + fh * 32 + l31;
+            const float* vs = lds + cur * WF_STAGE + 16 * WF_KC * WF_BF + (4 * wrow) * WF_KC * WF_BT + l31;
+            // fragments of k-step ks + 1 are fetched from LDS before the MFMAs of k-step ks are issued
+            float af[2][4], bf[2][4][2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                af[0][j] = us[(j * WF_KC + lhi) * WF_BF];
+                bf[0][j][0] = vs[(j * WF_KC + lhi) * WF_BT];
+                bf[0][j][1] = vs[(j * WF_KC + lhi) * WF_BT + 32];
+            }
+#pragma unroll
+            for (int ks = 0; ks < WF_KC / 2; ++ks) {
+                const int fc = ks & 1, fn = fc ^ 1;
+                if (ks + 1 < WF_KC / 2) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        af[fn][j] = us[(j * WF_KC + 2 * ks + 2 + lhi) * WF_BF];
+                        bf[fn][j][0] = vs[(j * WF_KC + 2 * ks + 2 + lhi) * WF_BT];
+                        bf[fn][j][1] = vs[(j * WF_KC + 2 * ks + 2 + lhi) * WF_BT + 32];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) {
+#ifndef WF_ABL_NOMFMA
+                        acc[j][tt] = mfma32(af[fc][j], bf[fc][j][tt], acc[j][tt]);
+#else
+                        acc[j][tt][0] += af[fc][j] * bf[fc][j][tt];
+#endif
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+
+        // ---- K loop -------------------------------------------------------------------------------------
+        dma_u(0, 0);
+        load_patch(0);
+        write_v(0);
+#ifndef WF_ABL_NOXFORM
+        if (early && nchunks > 1) load_patch(1);  // the early half always holds the next chunk's patches in registers
+#endif
+        dma_wait();
+        __syncthreads();
+        for (int kc = 0; kc < nchunks; ++kc) {
+            const int cur = kc & 1, nxt = cur ^ 1;
+            const bool more = kc + 1 < nchunks;
+            // stage `nxt` was last read before the barrier that ended iteration kc - 1
+#ifndef WF_ABL_NOXFORM
+            if (early && more) write_v(nxt);         // patches of chunk kc + 1: requested during chunk kc - 1
+#endif
+            if (more) dma_u(kc + 1, nxt);
+#ifndef WF_ABL_NOXFORM
+            if (!early && more) load_patch(kc + 1);
+#endif
+            __builtin_amdgcn_sched_barrier(0);       // requests first, then the MFMAs they fly under
+            multiply(cur);
+            __builtin_amdgcn_sched_barrier(0);
+            if (early) {
+#ifndef WF_ABL_NOXFORM
+                if (kc + 2 < nchunks) load_patch(kc + 2);
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                dma_wait_n<16>();                    // the 4 LDS-DMAs are older than the 16 patch loads: those may fly on
+            } else {
+#ifndef WF_ABL_NOXFORM
+                if (more) write_v(nxt);
+#endif
+                dma_wait();
+            }
+            __syncthreads();
+        }
+
+#ifdef WF_ABL_NOEPI
+        {
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sum += acc[j][tt][r];
+            if (sum == 123.456f) a.dst[0] = sum;
+            continue;
+        }
+#endif
+        // ---- epilogue -----------------------------------------------------------------------------------
+        // (1) column half of A^T m A on the accumulators: S[b] = sum_j m[j] * A[j][b], A^T = [1 1 1 0; 0 1 -1 -1];
+        //     S[wrow][b][f][t] -> LDS (the K loop's last barrier has retired every read of the stages)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float m0v = acc[0][tt][r], m1v = acc[1][tt][r], m2v = acc[2][tt][r], m3v = acc[3][tt][r];
+                const int f = fh * 32 + mfma_row(r, lane);
+                float* p = lds + ((wrow * 2) * WF_BF + f) * WF_BT + tt * 32 + l31;
+                p[0] = m0v + m1v + m2v;
+                p[WF_BF * WF_BT] = m1v - m2v - m3v;
+            }
+        __syncthreads();
+        // (2) one (channel, tile) per lane: the row half, bias / activation, stores, statistics
+        const int oh = 2 * th, ow = 2 * tw;
+        const bool two_cols = ow + 1 < a.W, two_rows = oh + 1 < a.H;
+        const bool vec2 = (a.W & 1) == 0;  // rows start 8-byte aligned, ow is even
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int fl = q * 8 + wid;  // wave-uniform channel
+            const int f = m0 + fl;
+            if (f >= a.M) continue;      // uniform
+            float sb[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) sb[i][b] = lds[((i * 2 + b) * WF_BF + fl) * WF_BT + lane];
             float o[2][2];
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                o[r][0] = s[r][0] + s[r][1] + s[r][2];
-                o[r][1] = s[r][1] - s[r][2] - s[r][3];
+            for (int b = 0; b < 2; ++b) {
+                o[0][b] = sb[0][b] + sb[1][b] + sb[2][b];
+                o[1][b] = sb[1][b] - sb[2][b] - sb[3][b];
             }
-            if (!plain) {
-                float b = a.add_bias ? a.bias[f] : 0.f;
-                if (b == 1.0f) b = 0.f;  // bcnn_add_scalar of the AVX build adds nothing for exactly 1.0f (quirk 2)
-                const float sl = (a.act == BCNN_HIP_ACT_PRELU && a.slopes) ? a.slopes[f] : 0.f;
+            if (EPI != 0) {
+                float bv = a.add_bias ? a.bias[f] : 0.f;
+                if (bv == 1.0f) bv = 0.f;  // bcnn_add_scalar of the AVX build adds nothing for exactly 1.0f (quirk 2)
+                const float sl = (EPI == 2 && a.act == BCNN_HIP_ACT_PRELU && a.slopes) ? a.slopes[f] : 0.f;
 #pragma unroll
                 for (int r = 0; r < 2; ++r)
 #pragma unroll
                     for (int c = 0; c < 2; ++c) {
                         float vv = o[r][c];
-                        if (b != 0.0f) vv += b;
-                        if (a.act != BCNN_HIP_ACT_NONE) vv = act_fwd_cheap(vv, a.act, sl);
+                        if (bv != 0.0f) vv += bv;
+                        if (EPI == 1) vv = vv * (float)(vv > 0);  // RELU as the reference's multiply (-0.0f, NaN propagate)
+                        else if (a.act != BCNN_HIP_ACT_NONE) vv = act_fwd_cheap(vv, a.act, sl);
                         o[r][c] = vv;
                     }
             }
@@ -321,11 +383,11 @@ static bool wino_fused_wanted(const ConvShape& s, int J, int M) {
         g_wf_force = e ? (e[0] == '0' ? 0 : 1) : 2;
     }
     if (g_wf_force != 2) return g_wf_force == 1;
-    // the layers whose transformed tensors would not stay on chip in the three-kernel form (conv_winograd.hip takes
-    // the deeper ones): 64 / 128 channels at 56x56 / 28x28 in the benchmark
-    const double T = (double)s.N * ((s.H + 1) / 2) * ((s.W + 1) / 2);
-    const double vm_bytes = 16.0 * T * (s.C + s.F) * 4.0;
-    return s.C >= 64 && s.F >= 64 && s.C <= 128 && s.F <= 128 && vm_bytes > 230e6;
+    // Measured on the ResNet-18 shapes at N = 128 (tools/exp/wino_sweep.sh): 1.2-1.6x faster than
+    // the direct LDS-DMA kernels from 64 channels up, and as fast as or faster than the three-kernel form
+    // (conv_winograd.hip) on the deep layers -- so it takes every eligible layer with enough tiles to fill the chip.
+    const long long T = (long long)s.N * ((s.H + 1) / 2) * ((s.W + 1) / 2);
+    return J >= 64 && M >= 64 && T * ((M + WF_BF - 1) / WF_BF) >= (long long)WF_BT * kCUs / 2;
 }
 
 static void wino_fused_run(const float* src, const float* w, float* dst, const ConvShape& s, int dx_mode,
@@ -349,7 +411,12 @@ static void wino_fused_run(const float* src, const float* w, float* dst, const C
                                                                                                     a.Jpad, a.Mpad);
     KERNEL_CHECK();
     a.stats = (stats && stats->partials) ? stats->partials : nullptr;
-    wino_fused_kernel<<<(unsigned)(a.tblocks * a.mblocks), 512, 0, current_stream()>>>(a);
+    const int nblocks = a.tblocks * a.mblocks;
+    const unsigned grid = (unsigned)(nblocks < kCUs ? nblocks : kCUs);  // persistent: one 128 KB workgroup per CU
+    const bool plain = !a.add_bias && a.act == BCNN_HIP_ACT_NONE;
+    if (plain) wino_fused_kernel<0><<<grid, 512, 0, current_stream()>>>(a);
+    else if (a.act == BCNN_HIP_ACT_RELU) wino_fused_kernel<1><<<grid, 512, 0, current_stream()>>>(a);
+    else wino_fused_kernel<2><<<grid, 512, 0, current_stream()>>>(a);
     KERNEL_CHECK();
     if (stats) stats->splits = a.stats ? a.tblocks : 0;
 }
