@@ -35,6 +35,9 @@ bool conv_backward_data_winograd(const float* w, const float* dy, float* dx, con
 bool conv_forward_winograd_fused(const float* x, const float* w, const float* bias, const float* slopes, float* y,
                                  const ConvShape& s, int act, int raw, ConvStats* stats);
 bool conv_backward_data_winograd_fused(const float* w, const float* dy, float* dx, const ConvShape& s);
+size_t conv_dw_winograd_fused_workspace_floats(const ConvShape& s);
+bool conv_backward_weights_winograd_fused(const float* x, const float* dy, float* dw, const ConvShape& s, float* workspace,
+                                          size_t workspace_floats);
 size_t conv_dw_winograd_workspace_floats(const ConvShape& s);
 bool conv_backward_weights_winograd(const float* x, const float* dy, float* dw, const ConvShape& s, float* workspace,
                                     size_t workspace_floats);
@@ -84,7 +87,9 @@ size_t bcnn_hip_conv_workspace_size(int n, int c, int h, int w, int f, int k, in
     const ConvShape s = make_conv_shape(n, c, h, w, f, k, stride, pad, groups);
     size_t m = conv_dw_workspace_floats(s);
     const size_t b = conv_dw_direct_workspace_floats(s), d = conv_dw_dma_workspace_floats(s);
-    const size_t wg = conv_dw_winograd_workspace_floats(s);
+    size_t wg = conv_dw_winograd_workspace_floats(s);
+    const size_t wgf = conv_dw_winograd_fused_workspace_floats(s);
+    if (wgf > wg) wg = wgf;
     if (b > m) m = b;
     if (d > m) m = d;
     if (wg > m) m = wg;
@@ -162,6 +167,8 @@ void bcnn_hip_conv_backward(const float* x, const float* w, const float* bias, c
     static const int dma_on = BCNN_EXP_ENV("BCNN_HIP_NO_DMA") ? 0 : 1;  // A/B switch for profiling
     if (conv_backward_weights_direct(x, dy, dw, batch_norm ? nullptr : dbias, s, workspace, workspace_elems))
         bias_done = true;
+    else if (conv_backward_weights_winograd_fused(x, dy, dw, s, workspace, workspace_elems))
+        bias_done = false;
     else if (conv_backward_weights_winograd(x, dy, dw, s, workspace, workspace_elems))
         bias_done = false;
     else if (dma_on && conv_backward_weights_dma_timed(x, dy, dw, s, workspace, workspace_elems))

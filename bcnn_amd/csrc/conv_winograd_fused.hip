@@ -445,4 +445,296 @@ bool conv_backward_data_winograd_fused(const float* w, const float* dy, float* d
     return true;
 }
 
+
+// =============================================================================================================
+// Weight gradient in the transformed domain, one kernel:  dU[xi][f][c] = sum_t dM[xi][f][t] * V[xi][c][t]
+//   dM = A dy_tile A^T (adjoint of the output transform), V = B^T x_patch B; then dw += G^T dU G (finalize kernel).
+// A GEMM per position with the reduction over ALL tiles of the batch: a workgroup owns a 64 x 64 (f, c) block of
+// all 16 positions (8 waves x 2 positions x 2x2 accumulator tiles = 128 registers) and a contiguous range of tiles;
+// per chunk of 8 tiles every thread transforms one (f, tile) dy block and one (c, tile) x patch straight from
+// global memory into LDS ([xi][channel][tile], rows padded to 9 floats: conflict-free fragment reads), requested
+// before the chunk's 32 MFMAs per wave and written after them. Partial blocks go to the workspace and are added to
+// dw in a fixed order (deterministic; keeps the `+=` onto the momentum carry, bcnn_conv_layer.c:547-553).
+// =============================================================================================================
+constexpr int WD_KT = 8;                 // tiles per chunk
+constexpr int WD_ROW = WD_KT + 1;        // padded LDS row
+constexpr int WD_OP = 16 * 64 * WD_ROW;  // floats per operand and stage
+
+struct WinoDwArgs {
+    const float* x;    // [N][C][H][W]
+    const float* dy;   // [N][F][H][W]
+    float* partials;   // [splits][fblocks * cblocks][16][64][64]
+    int N, C, F, H, W, TH, TW;
+    unsigned T, tiles_per_split;
+    int fblocks, cblocks, splits;
+    unsigned x_bytes, dy_bytes;
+};
+
+__global__ __launch_bounds__(512, 2) void wino_dw_fused_kernel(const WinoDwArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * 2 * WD_OP];  // two stages of (dM, V): 147 KB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int nob = a.fblocks * a.cblocks;
+    const int ob = blockIdx.x % nob, sp = blockIdx.x / nob;
+    const int f0 = (ob % a.fblocks) * 64, c0 = (ob / a.fblocks) * 64;
+    const unsigned tbeg = (unsigned)sp * a.tiles_per_split;
+    unsigned tend = tbeg + a.tiles_per_split;
+    if (tend > a.T) tend = a.T;
+    const int nchunks = tbeg < tend ? (int)((tend - tbeg + WD_KT - 1) / WD_KT) : 0;
+    const int HW = a.H * a.W;
+    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+    const auto rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, (int)a.dy_bytes, 0x00020000);
+
+    // this thread's transform item in every chunk: channel ch (of both the f block and the c block), tile tl
+    const int tl = lane & 7, ch = wid * 8 + (lane >> 3);
+    const bool f_ok = f0 + ch < a.F, c_ok = c0 + ch < a.C;
+    // tile coordinates of (tbeg + tl), advanced by 8 tiles per chunk (TW >= 8: one carry at most)
+    unsigned t = tbeg + (unsigned)tl;
+    const unsigned per_img = (unsigned)(a.TH * a.TW);
+    int n = (int)(t / per_img);
+    const unsigned rr = t - (unsigned)n * per_img;
+    int th = (int)(rr / (unsigned)a.TW), tw = (int)(rr - (unsigned)th * (unsigned)a.TW);
+
+    float d[4][4], g[2][2];
+    auto load_items = [&]() {
+        const bool live = t < tend;
+        // x patch: rows 2th-1 .. 2th+2, columns 2tw-1 .. 2tw+2 of channel c0 + ch; zero outside the image
+        const int ih0 = 2 * th - 1, iw0 = 2 * tw - 1;
+        const unsigned xb = (unsigned)(((n * a.C + c0 + ch) * a.H + ih0) * a.W + iw0) * 4u;
+        bool rok[4], cok[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            rok[i] = c_ok && (unsigned)(ih0 + i) < (unsigned)a.H;
+            cok[i] = (unsigned)(iw0 + i) < (unsigned)a.W;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)(xb + (unsigned)(i * a.W + j) * 4u), 0, 0));
+                d[i][j] = (rok[i] && cok[j]) ? v : 0.f;
+            }
+        // dy block: rows 2th, 2th+1, columns 2tw, 2tw+1 of channel f0 + ch; zero outside / for tiles past the range
+        const unsigned yb = (unsigned)(((n * a.F + f0 + ch) * a.H + 2 * th) * a.W + 2 * tw) * 4u;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_dy, (int)(yb + (unsigned)(r * a.W + c) * 4u), 0, 0));
+                g[r][c] = (live && f_ok && 2 * th + r < a.H && 2 * tw + c < a.W) ? v : 0.f;
+            }
+    };
+    auto advance = [&]() {
+        t += WD_KT;
+        tw += WD_KT;
+        if (tw >= a.TW) { tw -= a.TW; ++th; }
+        if (th >= a.TH) { th -= a.TH; ++n; }
+    };
+    auto write_items = [&](int stage) {
+        float* pm = lds + stage * 2 * WD_OP + ch * WD_ROW + tl;
+        float* pv = pm + WD_OP;
+        // dM = A g A^T, A = [1 0; 1 1; 1 -1; 0 -1]
+        float q[4][2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            q[0][c] = g[0][c];
+            q[1][c] = g[0][c] + g[1][c];
+            q[2][c] = g[0][c] - g[1][c];
+            q[3][c] = -g[1][c];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            pm[(4 * i + 0) * 64 * WD_ROW] = q[i][0];
+            pm[(4 * i + 1) * 64 * WD_ROW] = q[i][0] + q[i][1];
+            pm[(4 * i + 2) * 64 * WD_ROW] = q[i][0] - q[i][1];
+            pm[(4 * i + 3) * 64 * WD_ROW] = -q[i][1];
+        }
+        // V = B^T d B
+        float tt[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            tt[0][j] = d[0][j] - d[2][j];
+            tt[1][j] = d[1][j] + d[2][j];
+            tt[2][j] = d[2][j] - d[1][j];
+            tt[3][j] = d[1][j] - d[3][j];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            pv[(4 * i + 0) * 64 * WD_ROW] = tt[i][0] - tt[i][2];
+            pv[(4 * i + 1) * 64 * WD_ROW] = tt[i][1] + tt[i][2];
+            pv[(4 * i + 2) * 64 * WD_ROW] = tt[i][2] - tt[i][1];
+            pv[(4 * i + 3) * 64 * WD_ROW] = tt[i][1] - tt[i][3];
+        }
+    };
+
+    f32x16 acc[2][2][2];  // [position of the pair][f tile][c tile]
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[e][i][j][r] = 0.f;
+
+    if (nchunks > 0) {
+        load_items();
+        write_items(0);
+    }
+    __syncthreads();
+    for (int kc = 0; kc < nchunks; ++kc) {
+        const int cur = kc & 1, nxt = cur ^ 1;
+        const bool more = kc + 1 < nchunks;
+        if (more) {
+            advance();
+            load_items();
+        }
+        __builtin_amdgcn_sched_barrier(0);  // requests first, then the MFMAs they fly under
+        const float* ms = lds + cur * 2 * WD_OP + (2 * wid) * 64 * WD_ROW + l31 * WD_ROW + lhi;
+        const float* vs = ms + WD_OP;
+#pragma unroll
+        for (int ks = 0; ks < WD_KT / 2; ++ks) {
+            float af[2][2], bf[2][2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    af[e][i] = ms[(e * 64 + i * 32) * WD_ROW + 2 * ks];
+                    bf[e][i] = vs[(e * 64 + i * 32) * WD_ROW + 2 * ks];
+                }
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[e][i][j] = mfma32(af[e][i], bf[e][j], acc[e][i][j]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) write_items(nxt);
+        __syncthreads();
+    }
+    // ---- publish the partial block: [sp][ob][xi][f][c] -----------------------------------------------------
+    float* out = a.partials + ((size_t)sp * nob + ob) * (size_t)(16 * 64 * 64);
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    out[((2 * wid + e) * 64 + i * 32 + mfma_row(r, lane)) * 64 + j * 32 + l31] = acc[e][i][j][r];
+}
+
+// dw[f][c][3][3] += G^T (sum_sp partial[sp][ob][.][f][c]) G,  G^T = [1 .5 .5 0; 0 .5 -.5 0; 0 .5 .5 1].
+// block = 16 positions x 16 channels c of one f: every thread sums its (xi, f, c) over the splits in order
+// (four independent chains), then 16 threads finish the 4x4 -> 3x3 transform.
+__global__ __launch_bounds__(256) void wino_dw_fused_finalize_kernel(const float* __restrict__ partials, int splits,
+                                                                     int fblocks, int cblocks, int F, int C,
+                                                                     float* __restrict__ dw) {
+    __shared__ float u[16][17];
+    const int xi = threadIdx.x >> 4, cq = threadIdx.x & 15;
+    const int nob = fblocks * cblocks;
+    const int fl = blockIdx.x & 63, cgrp = (blockIdx.x >> 6) & 3, ob = blockIdx.x >> 8;
+    const int f = (ob % fblocks) * 64 + fl, c = (ob / fblocks) * 64 + cgrp * 16 + cq;
+    const float* p = partials + (size_t)ob * (16 * 64 * 64) + ((size_t)xi * 64 + fl) * 64 + cgrp * 16 + cq;
+    const size_t stride = (size_t)nob * (16 * 64 * 64);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int sp = 0;
+    for (; sp + 3 < splits; sp += 4) {
+        const float v0 = p[(size_t)sp * stride], v1 = p[(size_t)(sp + 1) * stride];
+        const float v2 = p[(size_t)(sp + 2) * stride], v3 = p[(size_t)(sp + 3) * stride];
+        s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+    }
+    for (; sp < splits; ++sp) s0 += p[(size_t)sp * stride];
+    u[xi][cq] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (threadIdx.x < 16 && f < F && c < C) {
+        const int q = threadIdx.x;
+        float m[4][4];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) m[k >> 2][k & 3] = u[k][q];
+        float t[3][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            t[0][j] = m[0][j] + 0.5f * (m[1][j] + m[2][j]);
+            t[1][j] = 0.5f * (m[1][j] - m[2][j]);
+            t[2][j] = 0.5f * (m[1][j] + m[2][j]) + m[3][j];
+        }
+        float* o = dw + ((size_t)f * C + c) * 9;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            o[r * 3 + 0] += t[r][0] + 0.5f * (t[r][1] + t[r][2]);
+            o[r * 3 + 1] += 0.5f * (t[r][1] - t[r][2]);
+            o[r * 3 + 2] += 0.5f * (t[r][1] + t[r][2]) + t[r][3];
+        }
+    }
+}
+
+struct WinoDwPlan {
+    bool ok;
+    int fblocks, cblocks, splits;
+    unsigned T, tiles_per_split;
+    size_t partial_floats;
+};
+
+static int g_wd_force = -1;  // experiment build: BCNN_HIP_WINOGRAD_DW_FUSED=0/1 overrides the rule
+static WinoDwPlan wino_dw_fused_plan(const ConvShape& s) {
+    WinoDwPlan p;
+    p.ok = false; p.partial_floats = 0;
+    if (s.ksz != 3 || s.stride != 1 || s.pad != 1 || s.groups != 1) return p;
+    const int TW = (s.W + 1) / 2, TH = (s.H + 1) / 2;
+    if (TW < WD_KT || s.C < 32 || s.F < 32) return p;  // the tile walk carries at most once per chunk
+    if ((size_t)s.N * s.C * s.HW * 4 >= 0x7ffffff0ull || (size_t)s.N * s.F * s.HW * 4 >= 0x7ffffff0ull) return p;
+    if (g_wd_force < 0) {
+        const char* e = BCNN_EXP_ENV("BCNN_HIP_WINOGRAD_DW_FUSED");
+        g_wd_force = e ? (e[0] == '0' ? 0 : 1) : 2;
+    }
+    if (g_wd_force == 0) return p;
+    if (g_wd_force == 2 && (s.C < 64 || s.F < 64)) return p;
+    p.T = (unsigned)((long long)s.N * TH * TW);
+    p.fblocks = (s.F + 63) / 64; p.cblocks = (s.C + 63) / 64;
+    const int nob = p.fblocks * p.cblocks;
+    int splits = kCUs / nob;  // one 147 KB workgroup per CU
+    if (splits < 1) splits = 1;
+    unsigned per = (p.T + (unsigned)splits - 1) / (unsigned)splits;
+    per = (per + WD_KT - 1) / WD_KT * WD_KT;
+    if (per < 4 * WD_KT) per = 4 * WD_KT;
+    p.tiles_per_split = per;
+    p.splits = (int)((p.T + per - 1) / per);
+    if (g_wd_force == 2 && p.splits * nob < kCUs / 2) return p;  // too few tiles to fill the chip
+    p.partial_floats = (size_t)p.splits * nob * (16 * 64 * 64);
+    p.ok = true;
+    return p;
+}
+
+size_t conv_dw_winograd_fused_workspace_floats(const ConvShape& s) { return wino_dw_fused_plan(s).partial_floats; }
+
+bool conv_backward_weights_winograd_fused(const float* x, const float* dy, float* dw, const ConvShape& s, float* workspace,
+                                          size_t workspace_floats) {
+    const WinoDwPlan p = wino_dw_fused_plan(s);
+    if (!p.ok) return false;
+    if (workspace == nullptr || workspace_floats < p.partial_floats) {
+        fprintf(stderr, "[bcnn_hip] conv backward: workspace too small (%zu floats given, %zu needed)\n", workspace_floats,
+                p.partial_floats);
+        exit(1);
+    }
+    KTimer kt(K_CONV_DW_WINO, wf_flops(s), wf_bytes(s));
+    WinoDwArgs a;
+    a.x = x; a.dy = dy; a.partials = workspace;
+    a.N = s.N; a.C = s.C; a.F = s.F; a.H = s.H; a.W = s.W; a.TH = (s.H + 1) / 2; a.TW = (s.W + 1) / 2;
+    a.T = p.T; a.tiles_per_split = p.tiles_per_split;
+    a.fblocks = p.fblocks; a.cblocks = p.cblocks; a.splits = p.splits;
+    a.x_bytes = (unsigned)((size_t)s.N * s.C * s.HW * 4);
+    a.dy_bytes = (unsigned)((size_t)s.N * s.F * s.HW * 4);
+    const int nob = p.fblocks * p.cblocks;
+    wino_dw_fused_kernel<<<(unsigned)(p.splits * nob), 512, 0, current_stream()>>>(a);
+    KERNEL_CHECK();
+    wino_dw_fused_finalize_kernel<<<(unsigned)(nob * 256), 256, 0, current_stream()>>>(workspace, p.splits, p.fblocks, p.cblocks,
+                                                                                      s.F, s.C, dw);
+    KERNEL_CHECK();
+    return true;
+}
+
 }  // namespace bcnn_hip

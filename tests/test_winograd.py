@@ -22,6 +22,9 @@ SHAPES = [  # n, c, h, w, f, act, bn
     (2, 32, 14, 14, 96, 2, 1),   # fused batch-norm + relu (raw conv output feeds the statistics)
     (1, 64, 3, 3, 128, 0, 0),    # a single partial tile row / column
     (2, 128, 7, 7, 128, 2, 1),
+    (2, 64, 16, 16, 64, 2, 1),   # >= 8 tiles per row: the fused weight-gradient kernel's tile walk
+    (3, 40, 17, 19, 72, 0, 0),   # odd extents, channel blocks that are not full (40 of 64, 72 = 64 + 8)
+    (1, 64, 32, 32, 128, 5, 0),
 ]
 
 
@@ -57,13 +60,15 @@ def test_child_winograd_matches_oracle(shape):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("switch", ["BCNN_HIP_WINOGRAD", "BCNN_HIP_WINOGRAD_FUSED"],
-                         ids=["transform_kernels_around_the_grouped_gemm", "single_fused_kernel"])
-def test_winograd_forced_on_small_shapes(switch):
+@pytest.mark.parametrize("switches", [("BCNN_HIP_WINOGRAD",), ("BCNN_HIP_WINOGRAD_FUSED", "BCNN_HIP_WINOGRAD_DW_FUSED")],
+                         ids=["transform_kernels_around_the_grouped_gemm", "fused_kernels"])
+def test_winograd_forced_on_small_shapes(switches):
     exp = os.path.join(ROOT, "bcnn_amd", "lib", "libbcnn_hip_exp.so")
     assert os.path.exists(exp), "experiment build missing: __graft_entry__.build() makes it"
-    e = dict(os.environ, BCNN_WINO_CHILD="1", BCNN_HIP_LIB=exp, BCNN_HIP_WINOGRAD="0", BCNN_HIP_WINOGRAD_FUSED="0")
-    e[switch] = "1"
+    e = dict(os.environ, BCNN_WINO_CHILD="1", BCNN_HIP_LIB=exp, BCNN_HIP_WINOGRAD="0", BCNN_HIP_WINOGRAD_FUSED="0",
+             BCNN_HIP_WINOGRAD_DW_FUSED="0")
+    for sw in switches:
+        e[sw] = "1"
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-p",
                         "no:cacheprovider", "-k", "child"], cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
