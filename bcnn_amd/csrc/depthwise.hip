@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ x
 // dx[n][c][ih][iw] += sum_{kh,kw} w[c][kh][kw] * g[n][c][oh][ow],  oh*stride - pad + kh == ih
 __global__ __launch_bounds__(256) void dw_bwd_data_kernel(const float* __restrict__ g, const float* __restrict__ w,
                                                           float* __restrict__ dx, const DwShape s,
-                                                          unsigned total) {
+                                                          unsigned total, int overwrite) {
     const unsigned gstride = gridDim.x * blockDim.x;
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gstride) {
         const unsigned iw = i % (unsigned)s.W, t = i / (unsigned)s.W;
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(const float* __restric
         const int c = (int)(plane % (unsigned)s.C);
         const float* gp = g + (long long)plane * s.OH * s.OW;
         const float* wk = w + c * s.ksz * s.ksz;
-        float acc = dx[i];
+        float acc = overwrite ? 0.f : dx[i];  // overwrite: the caller skipped the zero fill (sole writer)
         for (int kh = s.ksz - 1; kh >= 0; --kh) {  // ascending oh, like the reference's scatter order
             const int th = (int)ih + s.pad - kh;
             if (th < 0 || th % s.stride) continue;
@@ -344,6 +344,7 @@ struct Dw3DxArgs {
     unsigned row_groups;       // input rows (stride-1 kernel: ceil(H / VR) row groups)
     unsigned gpr_magic, h_magic;  // magic of groups_per_row / row_groups
     unsigned total_groups;     // planes * row_groups * groups_per_row
+    int overwrite;             // dx is assigned 0 + sum instead of accumulated onto (no read of dx)
 };
 template <int S>  // S = compile-time stride (1, 2), 0 = runtime stride
 __global__ __launch_bounds__(256) void dw3_bwd_data_kernel(const float* __restrict__ g, const float* __restrict__ w,
@@ -363,7 +364,10 @@ __global__ __launch_bounds__(256) void dw3_bwd_data_kernel(const float* __restri
     float* dst = dx + ((size_t)plane * s.H + ih) * s.W + iw0;
     const bool vec = iw0 + 4 <= s.W && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
     float acc[4];
-    if (vec) {
+    if (a.overwrite) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = 0.f;
+    } else if (vec) {
         const float4 v = *reinterpret_cast<const float4*>(dst);
         acc[0] = v.x; acc[1] = v.y; acc[2] = v.z; acc[3] = v.w;
     } else {
@@ -464,7 +468,7 @@ __global__ __launch_bounds__(256) void dw3_bwd_data_s1_kernel(const float* __res
     float acc[VR][4];
 #pragma unroll
     for (int r = 0; r < VR; ++r) {
-        if (ih0 + r < s.H) {
+        if (ih0 + r < s.H && !a.overwrite) {
             if (vec) {
                 const float4 v = *reinterpret_cast<const float4*>(dst0 + r * s.W);
                 acc[r][0] = v.x; acc[r][1] = v.y; acc[r][2] = v.z; acc[r][3] = v.w;
@@ -547,7 +551,7 @@ void bcnn_hip_depthwise_forward(const float* x, const float* w, const float* bia
 
 void bcnn_hip_depthwise_backward(const float* x, const float* w, const float* y, float* dy, float* dx,
                                  float* dw, float* dbias, int n, int c, int h, int wd, int k, int stride,
-                                 int pad, int act) {
+                                 int pad, int act, int overwrite) {
     DwShape s{n, c, h, wd, (h + 2 * pad - k) / stride + 1, (wd + 2 * pad - k) / stride + 1, k, stride, pad};
     const int ohow = s.OH * s.OW;
     const long long total_o = (long long)n * c * ohow;
@@ -555,7 +559,7 @@ void bcnn_hip_depthwise_backward(const float* x, const float* w, const float* y,
     // algorithmic bytes: activation backward (y, dy r/w), bias gradient (dy), dW (x, dy), dX (dy, dx r/w)
     KTimer kt(K_DEPTHWISE_BWD, 4.0 * (double)total_o * k * k,
               4.0 * (((act != BCNN_HIP_ACT_NONE) ? 3.0 : 0.0) * (double)total_o + (double)total_o +
-                     (dx ? ((double)n * c * h * wd + (double)total_o) + ((double)total_o + 2.0 * (double)n * c * h * wd)
+                     (dx ? ((double)n * c * h * wd + (double)total_o) + ((double)total_o + (overwrite ? 1.0 : 2.0) * (double)n * c * h * wd)
                          : 0.0)));
     activation_backward_grad_bias(y, dy, dbias, n, c, ohow, act);  // one sweep: dy *= act'(y), dbias += sum
     if (!dx) return;  // reference: dW and dX are both skipped when the source has no gradient (:318, :432)
@@ -592,13 +596,14 @@ void bcnn_hip_depthwise_backward(const float* x, const float* w, const float* y,
         Dw3DxArgs a;
         a.s = s; a.groups_per_row = gpr_i; a.row_groups = rgs_i; a.gpr_magic = dw_magic(gpr_i); a.h_magic = dw_magic(rgs_i);
         a.total_groups = (unsigned)groups_i;
+        a.overwrite = overwrite;
         const unsigned blocks = (unsigned)((groups_i + 255) / 256);
         if (stride == 1) dw3_bwd_data_s1_kernel<VRX><<<blocks, 256, 0, current_stream()>>>(dy, w, dx, a);
         else if (stride == 2) dw3_bwd_data_kernel<2><<<blocks, 256, 0, current_stream()>>>(dy, w, dx, a);
         else dw3_bwd_data_kernel<0><<<blocks, 256, 0, current_stream()>>>(dy, w, dx, a);
     } else {
         dw_bwd_data_kernel<<<stream_grid((size_t)total_i, 256), 256, 0, current_stream()>>>(dy, w, dx, s,
-                                                                                         (unsigned)total_i);
+                                                                                         (unsigned)total_i, overwrite);
     }
     KERNEL_CHECK();
 }

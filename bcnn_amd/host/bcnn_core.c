@@ -371,7 +371,9 @@ static void mark_dead_grad_fills(bcnn_net *net) {
          * gather; the full-size operand of a same-shape eltwise add) needs no fill either if that writer assigns
          * `0 + sum` instead of accumulating: mark 2, the node's backward asks bcnn_grad_sole_writer(). Holds for
          * the forward -> backward order every caller of the reference uses (bcnn_train_on_batch). */
-        if (uses == 1 && nd->type == BCNN_LAYER_MAXPOOL) {
+        if (uses == 1 && (nd->type == BCNN_LAYER_MAXPOOL || nd->type == BCNN_LAYER_DEPTHWISE_CONV2D)) {
+            /* max-pooling's gather and the depthwise data gradient (a gather too: one thread owns a dx element,
+             * bcnn_depthwise_conv_layer.c:432-547 accumulates onto the zero fill) */
             hc->grad_fill_dead[t] = 2;
             continue;
         }

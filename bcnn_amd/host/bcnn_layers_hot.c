@@ -246,7 +246,7 @@ void bcnn_backward_depthwise_conv_layer(bcnn_net *net, bcnn_node *node) {
     bcnn_tensor *b = &net->tensors[node->src[2]], *y = &net->tensors[node->dst[0]];
     bcnn_hip_depthwise_backward(x->data_gpu, w->data_gpu, y->data_gpu, y->grad_data_gpu, x->grad_data_gpu,
                                 w->grad_data_gpu, b->grad_data_gpu, x->n, x->c, x->h, x->w, p->size, p->stride,
-                                p->pad, (int)p->activation);
+                                p->pad, (int)p->activation, bcnn_grad_sole_writer(net, node->src[0]));
 }
 
 void bcnn_update_depthwise_conv_layer(bcnn_net *net, bcnn_node *node) { /* bcnn_depthwise_conv_layer.c:565-610 */

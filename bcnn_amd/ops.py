@@ -126,11 +126,12 @@ def depthwise_forward(x, wt, bias, y, k, stride, pad, act=0):
     _lib.load().bcnn_hip_depthwise_forward(_f32(x), _f32(wt), _f32(bias), _f32(y), n, c, h, w, k, stride, pad, act)
 
 
-def depthwise_backward(x, wt, y, dy, dx, dw, dbias, k, stride, pad, act=0):
-    """bcnn_backward_depthwise_conv_layer_cpu (bcnn_depthwise_conv_layer.c:295-547)"""
+def depthwise_backward(x, wt, y, dy, dx, dw, dbias, k, stride, pad, act=0, overwrite=False):
+    """bcnn_backward_depthwise_conv_layer_cpu (bcnn_depthwise_conv_layer.c:295-547); overwrite: dx = 0 + sums
+    (the executor's no-fill mode for a sole gradient writer) instead of dx += sums"""
     n, c, h, w = x.shape
     _lib.load().bcnn_hip_depthwise_backward(_f32(x), _f32(wt), _f32(y), _f32(dy), _f32(dx), _f32(dw),
-                                            _f32(dbias), n, c, h, w, k, stride, pad, act)
+                                            _f32(dbias), n, c, h, w, k, stride, pad, act, 1 if overwrite else 0)
 
 
 def gemm(ta, tb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc):

@@ -198,12 +198,15 @@ void bcnn_hip_avgpool_backward(const float *dy_d, float *dx_d, int n, int c, int
  * bcnn_depthwise_conv_layer.c:165-293, 295-547: weights [c][k][k]; y = act(dwconv + bias);
  * backward: dy *= act'(y) in place, dbias += ..., and ONLY IF dx_d != NULL: dw += ..., dx += ...
  * (accumulating, no zero-fill). No unsynchronised `+=` races (the CUDA kernel at :113 has one).
+ * overwrite != 0 (same contract as bcnn_hip_maxpool_backward): the caller guarantees dx is semantically all-zero
+ * (it skipped the executor's zero fill because this node is the tensor's only gradient writer): dx is assigned
+ * 0 + the same sums, without being read.
  * ------------------------------------------------------------------------------------------- */
 void bcnn_hip_depthwise_forward(const float *x_d, const float *w_d, const float *bias_d, float *y_d,
                                 int n, int c, int h, int w, int k, int stride, int pad, int act);
 void bcnn_hip_depthwise_backward(const float *x_d, const float *w_d, const float *y_d, float *dy_d,
                                  float *dx_d, float *dw_d, float *dbias_d, int n, int c, int h, int w,
-                                 int k, int stride, int pad, int act);
+                                 int k, int stride, int pad, int act, int overwrite);
 
 /* ---------------------------------------------------------------------------------------------
  * SGD step on a parameter arena.  Replaces bcnn_sgd_update_gpu (bcnn_learner.c:86-104); semantics

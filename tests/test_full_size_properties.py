@@ -234,6 +234,11 @@ def _depthwise_full_size(n, c, hw, k, stride, images, chunk):
                                torch.zeros_like(x[a:a + chunk]), dw_sum, db_sum, k, stride, 1, 2)
     assert _rel(_np(dw), _np(dw_sum)) <= TOL
     assert _rel(_np(db), _np(db_sum)) <= TOL
+    # the executor's no-fill mode: dx = 0 + sums over whatever the buffer holds, bit-identical to accumulate-onto-zero
+    dx2 = torch.full_like(x, 9.0)
+    ops.depthwise_backward(x, wt, y, dy0.clone(), dx2, torch.zeros_like(wt), torch.zeros_like(bias), k, stride, 1, 2,
+                           overwrite=True)
+    assert torch.equal(dx2.view(torch.int32), dx.view(torch.int32))
     # one chunk's weight / bias gradient against the oracle
     a = n - 4
     cs = dict(n=4, c=c, h=hw, w=hw, k=k, s=stride, p=1, act=2, input_grad=1, x=_np(x[a:]), wt=_np(wt),
