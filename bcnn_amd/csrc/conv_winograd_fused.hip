@@ -37,10 +37,12 @@ struct WinoFusedArgs {
     float* dst;        // [N][M][H][W]
     const float* bias;
     const float* slopes;
-    float* stats;      // optional: [M][tblocks][2]
+    float* stats;      // optional: [M][2 * tblocks][2] (one slot per half block)
     int N, J, M, H, W, TH, TW;
     unsigned T;
     int Jpad, Mpad, mblocks, tblocks;
+    int nfull;         // units [0, nfull) are whole 64-tile blocks, the rest are the two 32-tile halves of the last blocks
+    int nunits;
     int act, add_bias;
     unsigned src_bytes, upk_bytes;
 };
@@ -68,16 +70,20 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
     const unsigned u_voff = ((unsigned)(lane >> 4) * (unsigned)a.Mpad + (unsigned)(lane & 15) * 4u) * 4u;
     const unsigned per_img = (unsigned)(a.TH * a.TW);
     const int nchunks = a.Jpad / WF_KC;
-    const int nblocks = a.tblocks * a.mblocks;
 
-    for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+    // Work units: whole blocks first; when the last round would leave most CUs idle, its blocks are split into
+    // two 32-tile halves (second t-tile of the accumulators unused) so that twice as many CUs share that round.
+    for (int unit = blockIdx.x; unit < a.nunits; unit += gridDim.x) {
+        const bool whole = unit < a.nfull;
+        const int blk = whole ? unit : a.nfull + ((unit - a.nfull) >> 1);
+        const int half = whole ? 0 : ((unit - a.nfull) & 1);
         const int mb = blk % a.mblocks, tb = blk / a.mblocks;  // channel blocks of one tile block run together
         const int m0 = mb * WF_BF;
-        if (blk != (int)blockIdx.x) __syncthreads();  // the previous block's epilogue has read S
+        if (unit != (int)blockIdx.x) __syncthreads();  // the previous unit's epilogue has read S
 
         // ---- this lane's tile (the same one for the input transform and for the output transform) -------
-        const unsigned t = (unsigned)tb * WF_BT + (unsigned)lane;
-        const bool tile_ok = t < a.T;
+        const unsigned t = (unsigned)tb * WF_BT + (unsigned)(half * 32) + (unsigned)lane;
+        const bool tile_ok = t < a.T && (whole || lane < 32);
         const unsigned n = tile_ok ? t / per_img : 0u;
         const unsigned rr = tile_ok ? t - n * per_img : 0u;
         const int th = (int)(rr / (unsigned)a.TW), tw = (int)(rr - (unsigned)th * (unsigned)a.TW);
@@ -160,15 +166,15 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int tt = 0; tt < 2; ++tt) {
+                for (int j = 0; j < 4; ++j) {
 #ifndef WF_ABL_NOMFMA
-                        acc[j][tt] = mfma32(af[fc][j], bf[fc][j][tt], acc[j][tt]);
+                    acc[j][0] = mfma32(af[fc][j], bf[fc][j][0], acc[j][0]);
+                    if (whole) acc[j][1] = mfma32(af[fc][j], bf[fc][j][1], acc[j][1]);  // uniform
 #else
-                        acc[j][tt][0] += af[fc][j] * bf[fc][j][tt];
+                    acc[j][0][0] += af[fc][j] * bf[fc][j][0];
+                    acc[j][1][0] += af[fc][j] * bf[fc][j][1];
 #endif
-                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
@@ -228,7 +234,8 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
         // (1) column half of A^T m A on the accumulators: S[b] = sum_j m[j] * A[j][b], A^T = [1 1 1 0; 0 1 -1 -1];
         //     S[wrow][b][f][t] -> LDS (the K loop's last barrier has retired every read of the stages)
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
+        for (int tt = 0; tt < 2; ++tt) {
+            if (tt == 1 && !whole) break;  // uniform
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float m0v = acc[0][tt][r], m1v = acc[1][tt][r], m2v = acc[2][tt][r], m3v = acc[3][tt][r];
@@ -237,6 +244,7 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
                 p[0] = m0v + m1v + m2v;
                 p[WF_BF * WF_BT] = m1v - m2v - m3v;
             }
+        }
         __syncthreads();
         // (2) one (channel, tile) per lane: the row half, bias / activation, stores, statistics
         const int oh = 2 * th, ow = 2 * tw;
@@ -299,9 +307,10 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
             if (a.stats) {  // this wave holds channel f for the workgroup's 64 tiles
                 sv = wave_sum(sv);
                 sq = wave_sum(sq);
-                if (lane == 0) {
-                    float* p = a.stats + ((size_t)f * a.tblocks + tb) * 2;
+                if (lane == 0) {  // slot per half block; a whole block owns both and zeroes the second
+                    float* p = a.stats + ((size_t)f * (2 * a.tblocks) + 2 * tb + half) * 2;
                     p[0] = sv; p[1] = sq;
+                    if (whole) { p[2] = 0.f; p[3] = 0.f; }
                 }
             }
         }
@@ -413,12 +422,16 @@ static void wino_fused_run(const float* src, const float* w, float* dst, const C
     a.stats = (stats && stats->partials) ? stats->partials : nullptr;
     const int nblocks = a.tblocks * a.mblocks;
     const unsigned grid = (unsigned)(nblocks < kCUs ? nblocks : kCUs);  // persistent: one 128 KB workgroup per CU
+    // the last round's R blocks as 2R half blocks when that fills no more than one round
+    const int rem = nblocks % (int)grid;
+    a.nfull = (rem > 0 && 2 * rem <= (int)grid && nblocks > (int)grid) ? nblocks - rem : nblocks;
+    a.nunits = a.nfull + 2 * (nblocks - a.nfull);
     const bool plain = !a.add_bias && a.act == BCNN_HIP_ACT_NONE;
     if (plain) wino_fused_kernel<0><<<grid, 512, 0, current_stream()>>>(a);
     else if (a.act == BCNN_HIP_ACT_RELU) wino_fused_kernel<1><<<grid, 512, 0, current_stream()>>>(a);
     else wino_fused_kernel<2><<<grid, 512, 0, current_stream()>>>(a);
     KERNEL_CHECK();
-    if (stats) stats->splits = a.stats ? a.tblocks : 0;
+    if (stats) stats->splits = a.stats ? 2 * a.tblocks : 0;
 }
 
 static double wf_flops(const ConvShape& s) {
