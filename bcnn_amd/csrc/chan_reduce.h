@@ -12,9 +12,13 @@
 
 namespace bcnn_hip {
 
+#ifndef CHAN_WG_PER_CU
+#define CHAN_WG_PER_CU 4
+#endif
 inline int chan_splits(int channels, long long per_channel) {
-    // aim for >= ~4 workgroups per CU overall, but keep >= 4096 elements per workgroup
-    long long want = (4LL * kCUs + channels - 1) / channels;
+    // aim for >= ~4 workgroups per CU overall (16 measured no faster: tools/exp/bn_trace.sh), but keep >= 4096
+    // elements per workgroup
+    long long want = ((long long)CHAN_WG_PER_CU * kCUs + channels - 1) / channels;
     long long maxs = (per_channel + 4095) / 4096;
     if (want > maxs) want = maxs;
     if (want < 1) want = 1;
@@ -38,15 +42,35 @@ __global__ __launch_bounds__(256) void chan_reduce_partial(const F f, int C, int
     float acc[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) acc[v] = 0.f;
+    // (image, offset in plane) of the running index is carried along instead of divided out per step (the per-thread
+    // order of the additions is unchanged: bit-identical results; measured neutral, the loop is not VALU-bound)
     if ((HW & 3) == 0) {
-        for (int idx = lo + threadIdx.x * 4; idx < hi; idx += 256 * 4) {
-            const int n = idx / HW, i = idx - n * HW;
-            f.vec4(((long long)n * C + c) * HW + i, c, acc);
+        int idx = lo + threadIdx.x * 4;
+        if (idx < hi) {
+            const int n0 = idx / HW;
+            int i = idx - n0 * HW;
+            long long base = ((long long)n0 * C + c) * HW;
+            const long long img = (long long)C * HW;
+#pragma unroll 4
+            for (; idx < hi; idx += 256 * 4) {
+                f.vec4(base + i, c, acc);
+                i += 256 * 4;
+                while (i >= HW) { i -= HW; base += img; }
+            }
         }
     } else {
-        for (int idx = lo + threadIdx.x; idx < hi; idx += 256) {
-            const int n = idx / HW, i = idx - n * HW;
-            f(((long long)n * C + c) * HW + i, c, acc);
+        int idx = lo + threadIdx.x;
+        if (idx < hi) {
+            const int n0 = idx / HW;
+            int i = idx - n0 * HW;
+            long long base = ((long long)n0 * C + c) * HW;
+            const long long img = (long long)C * HW;
+#pragma unroll 4
+            for (; idx < hi; idx += 256) {
+                f(base + i, c, acc);
+                i += 256;
+                while (i >= HW) { i -= HW; base += img; }
+            }
         }
     }
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;

@@ -473,6 +473,8 @@ constexpr int WD_KT = 8;                 // tiles per chunk
 constexpr int WD_ROW = WD_KT + 1;        // padded LDS row
 constexpr int WD_OP = 16 * 64 * WD_ROW;  // floats per operand and stage
 
+struct WdF4 { float x, y, z, w; } __attribute__((packed, aligned(4)));  // 16-byte load, 4-byte aligned
+
 struct WinoDwArgs {
     const float* x;    // [N][C][H][W]
     const float* dy;   // [N][F][H][W]
@@ -496,8 +498,6 @@ __global__ __launch_bounds__(512, 2) void wino_dw_fused_kernel(const WinoDwArgs 
     if (tend > a.T) tend = a.T;
     const int nchunks = tbeg < tend ? (int)((tend - tbeg + WD_KT - 1) / WD_KT) : 0;
     const int HW = a.H * a.W;
-    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
-    const auto rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, (int)a.dy_bytes, 0x00020000);
 
     // this thread's transform item in every chunk: channel ch (of both the f block and the c block), tile tl
     const int tl = lane & 7, ch = wid * 8 + (lane >> 3);
@@ -512,31 +512,40 @@ __global__ __launch_bounds__(512, 2) void wino_dw_fused_kernel(const WinoDwArgs 
     float d[4][4], g[2][2];
     auto load_items = [&]() {
         const bool live = t < tend;
-        // x patch: rows 2th-1 .. 2th+2, columns 2tw-1 .. 2tw+2 of channel c0 + ch; zero outside the image
+        // x patch: rows 2th-1 .. 2th+2, columns 2tw-1 .. 2tw+2 of channel c0 + ch; zero outside the image.
+        // One 16-byte buffer load per row (4-byte aligned) that never leaves the row (W is even here): from column
+        // 2tw-1 in general, from column 0 for the first tile of a row (its column -1 is padding), from column W-4
+        // for the last one (its column 2tw+2 = W is padding); the vector is shifted accordingly. A row outside the
+        // image or a channel past the block gets an out-of-range offset and comes back as zeros.
         const int ih0 = 2 * th - 1, iw0 = 2 * tw - 1;
-        const unsigned xb = (unsigned)(((n * a.C + c0 + ch) * a.H + ih0) * a.W + iw0) * 4u;
-        bool rok[4], cok[4];
+        const bool first = tw == 0, last = iw0 + 3 >= a.W;
+        const int sc = iw0 + (first ? 1 : 0) - (last ? 1 : 0);
+        const unsigned xb = (unsigned)(((n * a.C + c0 + ch) * a.H + ih0) * a.W + sc);  // elements
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            rok[i] = c_ok && (unsigned)(ih0 + i) < (unsigned)a.H;
-            cok[i] = (unsigned)(iw0 + i) < (unsigned)a.W;
+            // Global (not buffer) loads: hipcc 7.2 lowers element reads of __builtin_amdgcn_raw_buffer_load_b64 / _b128
+            // to ONE dword load replicated (tools/micro/bufload_probe.hip). A row outside the image reads the tensor's
+            // first elements instead and is zeroed afterwards -- no exec branches.
+            const bool rok = c_ok && live && (unsigned)(ih0 + i) < (unsigned)a.H;
+            const unsigned off = rok ? xb + (unsigned)(i * a.W) : 0u;
+            const WdF4 q = *reinterpret_cast<const WdF4*>(a.x + off);
+            const float q0 = rok ? q.x : 0.f, q1 = rok ? q.y : 0.f, q2 = rok ? q.z : 0.f, q3 = rok ? q.w : 0.f;
+            d[i][0] = first ? 0.f : (last ? q1 : q0);
+            d[i][1] = first ? q0 : (last ? q2 : q1);
+            d[i][2] = first ? q1 : (last ? q3 : q2);
+            d[i][3] = first ? q2 : (last ? 0.f : q3);
         }
+        // dy block: rows 2th, 2th+1, columns 2tw, 2tw+1 of channel f0 + ch (8-byte aligned: W is even); zero outside
+        // the image / for tiles past the range
+        const unsigned yb = (unsigned)(((n * a.F + f0 + ch) * a.H + 2 * th) * a.W + 2 * tw);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, (int)(xb + (unsigned)(i * a.W + j) * 4u), 0, 0));
-                d[i][j] = (rok[i] && cok[j]) ? v : 0.f;
-            }
-        // dy block: rows 2th, 2th+1, columns 2tw, 2tw+1 of channel f0 + ch; zero outside / for tiles past the range
-        const unsigned yb = (unsigned)(((n * a.F + f0 + ch) * a.H + 2 * th) * a.W + 2 * tw) * 4u;
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_dy, (int)(yb + (unsigned)(r * a.W + c) * 4u), 0, 0));
-                g[r][c] = (live && f_ok && 2 * th + r < a.H && 2 * tw + c < a.W) ? v : 0.f;
-            }
+        for (int r = 0; r < 2; ++r) {
+            const bool rok = live && f_ok && 2 * th + r < a.H;
+            const unsigned off = rok ? yb + (unsigned)(r * a.W) : 0u;
+            const float2 q = *reinterpret_cast<const float2*>(a.dy + off);
+            g[r][0] = rok ? q.x : 0.f;
+            g[r][1] = rok ? q.y : 0.f;
+        }
     };
     auto advance = [&]() {
         t += WD_KT;
@@ -601,7 +610,9 @@ __global__ __launch_bounds__(512, 2) void wino_dw_fused_kernel(const WinoDwArgs 
         const bool more = kc + 1 < nchunks;
         if (more) {
             advance();
+#ifndef WD_ABL_NOXFORM
             load_items();
+#endif
         }
         __builtin_amdgcn_sched_barrier(0);  // requests first, then the MFMAs they fly under
         const float* ms = lds + cur * 2 * WD_OP + (2 * wid) * 64 * WD_ROW + l31 * WD_ROW + lhi;
@@ -621,10 +632,18 @@ __global__ __launch_bounds__(512, 2) void wino_dw_fused_kernel(const WinoDwArgs 
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[e][i][j] = mfma32(af[e][i], bf[e][j], acc[e][i][j]);
+                    for (int j = 0; j < 2; ++j) {
+#ifndef WD_ABL_NOMFMA
+                        acc[e][i][j] = mfma32(af[e][i], bf[e][j], acc[e][i][j]);
+#else
+                        acc[e][i][j][0] += af[e][i] * bf[e][j];
+#endif
+                    }
         }
         __builtin_amdgcn_sched_barrier(0);
+#ifndef WD_ABL_NOXFORM
         if (more) write_items(nxt);
+#endif
         __syncthreads();
     }
     // ---- publish the partial block: [sp][ob][xi][f][c] -----------------------------------------------------
@@ -698,7 +717,7 @@ static WinoDwPlan wino_dw_fused_plan(const ConvShape& s) {
     p.ok = false; p.partial_floats = 0;
     if (s.ksz != 3 || s.stride != 1 || s.pad != 1 || s.groups != 1) return p;
     const int TW = (s.W + 1) / 2, TH = (s.H + 1) / 2;
-    if (TW < WD_KT || s.C < 32 || s.F < 32) return p;  // the tile walk carries at most once per chunk
+    if (TW < WD_KT || (s.W & 1) || s.C < 32 || s.F < 32) return p;  // one carry per chunk at most; 16-byte row loads
     if ((size_t)s.N * s.C * s.HW * 4 >= 0x7ffffff0ull || (size_t)s.N * s.F * s.HW * 4 >= 0x7ffffff0ull) return p;
     if (g_wd_force < 0) {
         const char* e = BCNN_EXP_ENV("BCNN_HIP_WINOGRAD_DW_FUSED");

@@ -195,6 +195,11 @@ def roofline_of(prof, workload, traffic_ok):
         roof = {"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
     traffic, source = pmc_traffic(workload, name) if traffic_ok else (None, "non-default batch or variant: no PMC summary applies")
+    if "winograd" in name:
+        # the class timers of the Winograd kernels carry the FLOPs the MFMAs really execute (16 instead of 36
+        # multiplies per 2x2 outputs: DESIGN.md section 4.8); the direct-convolution count of the same layers is 2.25x that
+        roof["flops_counted"] = "executed (Winograd transformed domain); direct-equivalent rate = 2.25 x achieved"
+        roof["direct_equivalent_tflops"] = round(2.25 * tf, 2)
     roof.update({"traffic": traffic, "traffic_source": source, "launches": d["launches"], "avg_ms": round(avg_ms, 4),
                  "algorithmic_flops_per_launch": d["flops"] / d["launches"],
                  "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],

@@ -25,6 +25,7 @@ SHAPES = [  # n, c, h, w, f, act, bn
     (2, 64, 16, 16, 64, 2, 1),   # >= 8 tiles per row: the fused weight-gradient kernel's tile walk
     (3, 40, 17, 19, 72, 0, 0),   # odd extents, channel blocks that are not full (40 of 64, 72 = 64 + 8)
     (1, 64, 32, 32, 128, 5, 0),
+    (2, 40, 18, 16, 72, 2, 0),   # even width (16-byte row loads of the fused dW kernel), ragged channel blocks
 ]
 
 
