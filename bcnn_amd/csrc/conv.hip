@@ -35,6 +35,10 @@ bool conv_backward_data_winograd(const float* w, const float* dy, float* dx, con
 bool conv_forward_winograd_fused(const float* x, const float* w, const float* bias, const float* slopes, float* y,
                                  const ConvShape& s, int act, int raw, ConvStats* stats);
 bool conv_backward_data_winograd_fused(const float* w, const float* dy, float* dx, const ConvShape& s);
+// few input channels (the RGB stem): padded-plane GEMM over all (c, kr, kc) rows (conv_dw_dma.hip)
+size_t conv_dw_small_c_workspace_floats(const ConvShape& s);
+bool conv_backward_weights_small_c(const float* x, const float* dy, float* dw, const ConvShape& s, float* workspace,
+                                   size_t workspace_floats);
 size_t conv_dw_winograd_fused_workspace_floats(const ConvShape& s);
 bool conv_backward_weights_winograd_fused(const float* x, const float* dy, float* dw, const ConvShape& s, float* workspace,
                                           size_t workspace_floats);
@@ -90,6 +94,8 @@ size_t bcnn_hip_conv_workspace_size(int n, int c, int h, int w, int f, int k, in
     size_t wg = conv_dw_winograd_workspace_floats(s);
     const size_t wgf = conv_dw_winograd_fused_workspace_floats(s);
     if (wgf > wg) wg = wgf;
+    const size_t sc = conv_dw_small_c_workspace_floats(s);
+    if (sc > wg) wg = sc;
     if (b > m) m = b;
     if (d > m) m = d;
     if (wg > m) m = wg;
@@ -173,6 +179,12 @@ void bcnn_hip_conv_backward(const float* x, const float* w, const float* bias, c
         bias_done = false;
     else if (dma_on && conv_backward_weights_dma_timed(x, dy, dw, s, workspace, workspace_elems))
         bias_done = false;
+    else if (dma_on && conv_dw_small_c_workspace_floats(s) > 0) {
+        KTimer kt(K_CONV_DW, 2.0 * (double)s.total_q * s.Mg * s.K * s.groups,
+                  4.0 * ((double)s.N * s.C * s.HW + (double)s.F * s.K + (double)s.N * s.F * s.OHOW));
+        conv_backward_weights_small_c(x, dy, dw, s, workspace, workspace_elems);
+        bias_done = false;
+    }
     else
         bias_done = conv_backward_weights(x, dy, dw, dbias, s, workspace, workspace_elems,
                                           /*want_bias=*/!batch_norm);

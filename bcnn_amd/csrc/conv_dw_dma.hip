@@ -35,6 +35,10 @@ struct DwDmaArgs {
     unsigned ow_magic;     // ceil(2^32 / OW)
     int b_row_stride;      // elements between consecutive c rows of the gathered operand (HW; OH*OW for 1x1)
     int kk2;
+    // rowmode (few input channels, the RGB stem): x is a zero-padded copy and the GEMM-N rows are ALL (c, kr, kc)
+    // of ONE "tap": row j sits at the wave-uniform offset c * plane + kr * pitch + kc from the lane's pixel
+    int rowmode, nrows, row_kk, row_ks, row_plane, row_pitch;
+    unsigned row_kk_magic, row_ks_magic;
 };
 
 constexpr int DWQ = 32;    // q per K-tile
@@ -74,7 +78,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_dw_dma_kernel(const DwDmaAr
     unsigned q = qbeg + (unsigned)l31;
     unsigned n = q / (unsigned)s.OHOW;
     unsigned pix = q - n * (unsigned)s.OHOW;
-    const unsigned row_a = (unsigned)lhi * (unsigned)s.OHOW, row_b = (unsigned)lhi * (unsigned)a.b_row_stride;
+    const unsigned row_a = (unsigned)lhi * (unsigned)s.OHOW, row_b = a.rowmode ? 0u : (unsigned)lhi * (unsigned)a.b_row_stride;
     unsigned va = kOOB, vb = kOOB;
     auto lane_offsets = [&]() {
         const bool qv = q < qend;
@@ -116,8 +120,21 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_dw_dma_kernel(const DwDmaAr
         for (int i = 0; i < BPAIRS / NW; ++i) {
             const int p = wid * (BPAIRS / NW) + i;
             const int c = c0 + 2 * p;
-            const unsigned soff = (b_grp + (unsigned)(c < s.Cg ? c : 0) * (unsigned)a.b_row_stride) * 4u;
-            dma_row(rs_b, base + (unsigned)((APAIRS + p) * DWPAIR * 4), vb, soff);
+            if (a.rowmode) {
+                // rows (c, c + 1) of the pair sit at unrelated offsets: the upper half-wave adds the difference
+                auto row_off = [&](int j) -> unsigned {
+                    if (j >= a.nrows) j = 0;  // finite values into columns that are never published
+                    const unsigned ch = magic_div((unsigned)j, a.row_kk_magic), r = (unsigned)j - ch * (unsigned)a.row_kk;
+                    const unsigned kr = magic_div(r, a.row_ks_magic), kc = r - kr * (unsigned)a.row_ks;
+                    return (ch * (unsigned)a.row_plane + kr * (unsigned)a.row_pitch + kc) * 4u;
+                };
+                const unsigned o0 = row_off(c), o1 = row_off(c + 1);
+                const unsigned vbp = vb == kOOB ? kOOB : vb + (unsigned)lhi * (o1 - o0);
+                dma_row(rs_b, base + (unsigned)((APAIRS + p) * DWPAIR * 4), vbp, o0);
+            } else {
+                const unsigned soff = (b_grp + (unsigned)(c < s.Cg ? c : 0) * (unsigned)a.b_row_stride) * 4u;
+                dma_row(rs_b, base + (unsigned)((APAIRS + p) * DWPAIR * 4), vb, soff);
+            }
         }
     };
 
@@ -303,6 +320,7 @@ bool conv_backward_weights_dma(const float* x, const float* dy, float* dw, const
         exit(1);
     }
     DwDmaArgs a;
+    a.rowmode = 0; a.nrows = 0;
     a.x = x; a.dy = dy; a.partials = workspace; a.s = s;
     a.mtiles = p.mtiles; a.ntiles = p.ntiles; a.qsplits = p.qsplits; a.q_per_split = p.q_per_split;
     a.Mpad = p.Mpad; a.Npad = p.Npad; a.kk2 = p.kk2;
@@ -328,6 +346,72 @@ bool conv_backward_weights_dma(const float* x, const float* dy, float* dw, const
     else
         conv_dw_dma_finalize_kernel<4><<<(unsigned)((total + 63) / 64), 256, 0, current_stream()>>>(
             workspace, p.qsplits, s.groups, s.Mg, s.Cg, p.kk2, p.Mpad, p.Npad, dw);
+    KERNEL_CHECK();
+    return true;
+}
+
+// ---- few input channels (the RGB stem): dW[f][(c, kr, kc)] as ONE GEMM over the zero-padded input ----------
+bool conv_small_c_applicable(const ConvShape& s);                                                    // conv_igemm_dma.hip
+float* conv_small_c_padded_input(const float* x, const ConvShape& s, size_t extra_floats, float** extra);
+
+static DwDmaPlan plan_dw_small_c(const ConvShape& s) {
+    DwDmaPlan p;
+    p.ok = false; p.partial_floats = 0;
+    if (!conv_small_c_applicable(s) || (s.Mg & 1) || s.OHOW < DWQ || s.total_q < 4 * DWQ) return p;
+    p.kk2 = 1;
+    p.cfg = 0;  // 64 x 64 tiles: 147 rows -> three column tiles
+    const int BM = kDwTiles[p.cfg].bm, BN = kDwTiles[p.cfg].bn;
+    p.mtiles = ceil_div(s.Mg, BM); p.ntiles = ceil_div(s.K, BN);
+    p.Mpad = p.mtiles * BM; p.Npad = p.ntiles * BN;
+    const long long tiles = (long long)p.mtiles * p.ntiles;
+    long long want = (8LL * kCUs + tiles - 1) / tiles;
+    const long long maxs = (s.total_q + 8 * DWQ - 1) / (8 * DWQ);
+    if (want > maxs) want = maxs;
+    if (want < 1) want = 1;
+    long long per = (s.total_q + want - 1) / want;
+    per = (per + DWQ - 1) / DWQ * DWQ;
+    p.q_per_split = (int)per;
+    p.qsplits = (int)((s.total_q + per - 1) / per);
+    p.partial_floats = (size_t)p.qsplits * (size_t)p.Mpad * p.Npad;
+    p.ok = true;
+    return p;
+}
+
+size_t conv_dw_small_c_workspace_floats(const ConvShape& s) { return plan_dw_small_c(s).partial_floats; }
+
+bool conv_backward_weights_small_c(const float* x, const float* dy, float* dw, const ConvShape& s, float* workspace,
+                                   size_t workspace_floats) {
+    const DwDmaPlan p = plan_dw_small_c(s);
+    if (!p.ok) return false;
+    if (workspace == nullptr || workspace_floats < p.partial_floats) {
+        fprintf(stderr, "[bcnn_hip] conv backward: workspace too small (%zu floats given, %zu needed)\n", workspace_floats,
+                p.partial_floats);
+        exit(1);
+    }
+    const int Hp = s.H + 2 * s.pad, Wp = s.W + 2 * s.pad;
+    float* xp = conv_small_c_padded_input(x, s, 0, nullptr);
+    const ConvShape sp = make_conv_shape(s.N, s.C, Hp, Wp, s.F, s.ksz, s.stride, 0, 1);
+    DwDmaArgs a;
+    a.x = xp; a.dy = dy; a.partials = workspace; a.s = sp;
+    a.mtiles = p.mtiles; a.ntiles = p.ntiles; a.qsplits = p.qsplits; a.q_per_split = p.q_per_split;
+    a.Mpad = p.Mpad; a.Npad = p.Npad; a.kk2 = 1;
+    a.x_bytes = (unsigned)((size_t)s.N * s.C * Hp * Wp * 4);
+    a.dy_bytes = (unsigned)((size_t)s.N * s.F * s.OHOW * 4);
+    a.ow_magic = magic_of_u(sp.OW);
+    a.b_row_stride = 0;
+    a.rowmode = 1; a.nrows = s.K; a.row_kk = s.ksz * s.ksz; a.row_ks = s.ksz; a.row_plane = Hp * Wp; a.row_pitch = Wp;
+    a.row_kk_magic = magic_of_u(a.row_kk); a.row_ks_magic = magic_of_u(a.row_ks);
+    dim3 grid((unsigned)(p.mtiles * p.ntiles * p.qsplits), 1u);
+    conv_dw_dma_kernel<2, 2, 1, 1><<<grid, (unsigned)kDwTiles[0].threads, 0, current_stream()>>>(a);
+    KERNEL_CHECK();
+    // partials [qs][1][1][Mpad][Npad] -> dw[f][j] += ..., j = (c, kr, kc): the weight tensor's own layout
+    const size_t total = (size_t)s.Mg * s.K;
+    if (p.qsplits > 16)
+        conv_dw_dma_finalize_kernel<16><<<(unsigned)((total + 63) / 64), 1024, 0, current_stream()>>>(
+            workspace, p.qsplits, 1, s.Mg, s.K, 1, p.Mpad, p.Npad, dw);
+    else
+        conv_dw_dma_finalize_kernel<4><<<(unsigned)((total + 63) / 64), 256, 0, current_stream()>>>(
+            workspace, p.qsplits, 1, s.Mg, s.K, 1, p.Mpad, p.Npad, dw);
     KERNEL_CHECK();
     return true;
 }

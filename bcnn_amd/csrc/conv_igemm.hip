@@ -313,6 +313,8 @@ static void dispatch_igemm(IgemmArgs& a, long long max_cols) {
 bool conv_forward_dma(const float* x, const float* w, const float* bias, const float* slopes, float* y,
                       const ConvShape& s, int act, int raw, ConvStats* stats);        // conv_igemm_dma.hip
 bool conv_backward_data_dma(const float* w, const float* dy, float* dx, const ConvShape& s);
+bool conv_forward_small_c(const float* x, const float* w, const float* bias, const float* slopes, float* y,
+                          const ConvShape& s, int act, int raw, ConvStats* stats);   // conv_igemm_dma.hip
 
 static bool dma_enabled() {
     static const int on = BCNN_EXP_ENV("BCNN_HIP_NO_DMA") ? 0 : 1;  // A/B switch for profiling
@@ -331,6 +333,7 @@ void conv_forward_dispatch(const float* x, const float* w, const float* bias, co
     KTimer kt(K_CONV_FWD, 2.0 * (double)s.total_q * s.Mg * s.K * s.groups,
               4.0 * ((double)s.N * s.C * s.HW + (double)s.F * s.K + (double)s.N * s.F * s.OHOW));
     if (dma_enabled() && conv_forward_dma(x, w, bias, slopes, y, s, act, raw, stats)) return;
+    if (dma_enabled() && conv_forward_small_c(x, w, bias, slopes, y, s, act, raw, stats)) return;
     IgemmArgs a;
     a.a_base = w; a.b_base = x; a.out = y; a.bias = bias; a.slopes = slopes; a.s = s;
     a.mode = 0;

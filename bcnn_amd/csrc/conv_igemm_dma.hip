@@ -81,6 +81,11 @@ struct DmaArgs {
     // stats[((g*Mg + m) * stats_splits + column tile) * 2 + {0: sum, 1: sum of squares}]
     float* stats;
     int stats_splits;
+    // rowmode (few input channels, e.g. the 7x7 RGB stem): the gathered tensor is a zero-padded copy of x and the
+    // reduction runs over ALL (c, kr, kc) rows as ONE "tap": row j reads the lane's pixel at the wave-uniform offset
+    // c * plane + kr * pitch + kc, (c, kr, kc) = (j / kk, (j % kk) / ks, j % ks) by magic multiplies on the scalar unit
+    int rowmode, row_kk, row_ks, row_plane, row_pitch;
+    unsigned row_kk_magic, row_ks_magic;
     DmaClass cls[kDmaMaxClasses];
 };
 
@@ -214,7 +219,14 @@ __global__ __launch_bounds__(64 * WM * WN, ABL_LB) void conv_igemm_dma_kernel(co
             const unsigned sa = (a_tile0 + (unsigned)(t * a.Jpad + j) * (unsigned)a.Mpad) * 4u;
             if (!HALF || (r & 1) == 0) {  // HALF: rows (row, row + 1) travel together (J is even: launch precondition)
                 const int jc = j < a.J ? j : a.J - (HALF ? 2 : 1);  // padded rows meet a zero A row: any legal row(s)
-                const unsigned sb = (unsigned)jc * (unsigned)a.b_major_stride * 4u;
+                unsigned sb;
+                if (a.rowmode) {
+                    const unsigned c = magic_div((unsigned)jc, a.row_kk_magic), r = (unsigned)jc - c * (unsigned)a.row_kk;
+                    const unsigned kr = magic_div(r, a.row_ks_magic), kc = r - kr * (unsigned)a.row_ks;
+                    sb = (c * (unsigned)a.row_plane + kr * (unsigned)a.row_pitch + kc) * 4u;
+                } else {
+                    sb = (unsigned)jc * (unsigned)a.b_major_stride * 4u;
+                }
 #pragma unroll
                 for (int h = 0; h < BH; ++h)
                     dma_row(rs_b, lds_b0 + (unsigned)(((buf * BK + row) * BN + h * 64) * 4), voff[h], sb);
@@ -532,6 +544,7 @@ bool conv_forward_dma(const float* x, const float* w, const float* bias, const f
     if (!dma_supported(s, s.Mg, s.Cg, (size_t)s.N * s.C * s.HW)) return false;
     const int kk2 = s.pointwise ? 1 : s.ksz * s.ksz;
     DmaArgs a;
+    a.rowmode = 0;
     a.b_base = x; a.out = y; a.bias = bias; a.slopes = slopes; a.s = s;
     a.mode = 0; a.act = raw ? BCNN_HIP_ACT_NONE : act; a.add_bias = raw ? 0 : 1;
     a.M = s.Mg; a.J = s.Cg; a.Jpad = round_up(a.J, kDmaBK); a.Mpad = round_up(a.M, 128); a.kk2 = kk2;
@@ -553,10 +566,83 @@ bool conv_forward_dma(const float* x, const float* w, const float* bias, const f
     return true;
 }
 
+// ---- few input channels (the RGB stem): padded-plane GEMM over all (c, kr, kc) rows ---------------------------
+// xp[n][c][ih + pad][iw + pad] = x[n][c][ih][iw], zero border: every tap of every output pixel is then a plain,
+// always-valid offset from the pixel's base, so the whole reduction is one "tap" for the LDS-DMA kernel.
+__global__ __launch_bounds__(256) void conv_pad_input_kernel(const float* __restrict__ x, float* __restrict__ xp, int H, int W,
+                                                             int Hp, int Wp, int pad, unsigned total) {
+    const unsigned stride = gridDim.x * blockDim.x;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const unsigned iw = i % (unsigned)Wp, t = i / (unsigned)Wp;
+        const unsigned ih = t % (unsigned)Hp, plane = t / (unsigned)Hp;
+        const int sh = (int)ih - pad, sw = (int)iw - pad;
+        xp[i] = ((unsigned)sh < (unsigned)H && (unsigned)sw < (unsigned)W) ? x[((size_t)plane * H + sh) * W + sw] : 0.f;
+    }
+}
+
+static unsigned magic_u32(int d) { return d > 1 ? (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned)d) : 0u; }
+
+bool conv_small_c_applicable(const ConvShape& s) {
+    if (s.groups != 1 || s.pointwise || s.ksz > 7 || s.Cg >= 8 || s.Mg <= 32) return false;
+    if (s.K < 64) return false;  // K <= 32 has the LDS-free kernels of conv_direct.hip
+    const long long Hp = s.H + 2 * s.pad, Wp = s.W + 2 * s.pad;
+    if ((long long)s.N * s.C * Hp * Wp * 4 >= 0x7ffffff0LL || (long long)s.N * s.F * s.OHOW * 4 >= 0x7ffffff0LL) return false;
+    return true;
+}
+
+// the zero-padded copy, shared by the forward pass and the weight gradient of the step (same thread, same x)
+float* conv_small_c_padded_input(const float* x, const ConvShape& s, size_t extra_floats, float** extra) {
+    const int Hp = s.H + 2 * s.pad, Wp = s.W + 2 * s.pad;
+    const size_t xp_floats = (size_t)s.N * s.C * Hp * Wp;
+    float* base = dma_scratch(xp_floats + extra_floats + 64);
+    float* xp = base;
+    if (extra) *extra = base + ((xp_floats + 63) & ~(size_t)63);
+    conv_pad_input_kernel<<<stream_grid(xp_floats / 4 + 1, 256), 256, 0, current_stream()>>>(x, xp, s.H, s.W, Hp, Wp, s.pad,
+                                                                                          (unsigned)xp_floats);
+    KERNEL_CHECK();
+    return xp;
+}
+
+bool conv_forward_small_c(const float* x, const float* w, const float* bias, const float* slopes, float* y,
+                          const ConvShape& s, int act, int raw, ConvStats* stats) {
+    if (stats) stats->splits = 0;
+    if (!conv_small_c_applicable(s)) return false;
+    const int Hp = s.H + 2 * s.pad, Wp = s.W + 2 * s.pad;
+    DmaArgs a;
+    a.J = s.K; a.M = s.Mg; a.Jpad = round_up(a.J, kDmaBK); a.Mpad = round_up(a.M, 128); a.kk2 = 1;
+    const size_t at_floats = (size_t)a.Jpad * a.Mpad;
+    float* at = nullptr;
+    float* xp = conv_small_c_padded_input(x, s, at_floats, &at);
+    // the problem as the kernel sees it: the padded tensor, no padding left, one tap
+    const ConvShape sp = make_conv_shape(s.N, s.C, Hp, Wp, s.F, s.ksz, s.stride, 0, 1);
+    a.s = sp;
+    a.b_base = xp; a.out = y; a.bias = bias; a.slopes = slopes;
+    a.mode = 0; a.act = raw ? BCNN_HIP_ACT_NONE : act; a.add_bias = raw ? 0 : 1;
+    a.at = at; a.at_bytes = (unsigned)(at_floats * 4);
+    a.b_bytes = (unsigned)((size_t)s.N * s.C * Hp * Wp * 4);
+    a.b_major_stride = 0;
+    a.rowmode = 1; a.row_kk = s.ksz * s.ksz; a.row_ks = s.ksz; a.row_plane = Hp * Wp; a.row_pitch = Wp;
+    a.row_kk_magic = magic_u32(a.row_kk); a.row_ks_magic = magic_u32(a.row_ks);
+    a.nclass = 1;
+    DmaClass& ci = a.cls[0];
+    ci.ih0 = 0; ci.iw0 = 0; ci.Hc = sp.OH; ci.Wc = sp.OW; ci.ntaps = 1; ci.tap0 = 0; ci.nkx = 1; ci.sgn = 1;
+    // A^T[j][m] = W[m][j]: the weight tensor [F][C*k*k] read as a 1x1 filter bank over J = C*k*k "channels"
+    ConvShape ws = s;
+    ws.Cg = s.K; ws.Mg = s.Mg; ws.ksz = 1;
+    unsigned char tapoff[kDmaMaxTaps];
+    tapoff[0] = 0;
+    pack_weights(w, at, ws, 0, a.M, a.J, a.Jpad, a.Mpad, 1, tapoff);
+    a.stats = (stats && raw) ? stats->partials : nullptr;
+    launch_dma(a, (int)s.total_q);
+    if (a.stats) stats->splits = a.stats_splits;
+    return true;
+}
+
 bool conv_backward_data_dma(const float* w, const float* dy, float* dx, const ConvShape& s) {
     if (!dma_supported(s, s.Cg, s.Mg, (size_t)s.N * s.F * s.OHOW)) return false;
     const int kk2 = s.pointwise ? 1 : s.ksz * s.ksz;
     DmaArgs a;
+    a.rowmode = 0;
     a.b_base = dy; a.out = dx; a.bias = nullptr; a.slopes = nullptr; a.s = s;
     a.mode = 1; a.act = BCNN_HIP_ACT_NONE; a.add_bias = 0; a.stats = nullptr; a.stats_splits = 0;
     a.M = s.Cg; a.J = s.Mg; a.Jpad = round_up(a.J, kDmaBK); a.Mpad = round_up(a.M, 128); a.kk2 = kk2;

@@ -32,7 +32,7 @@ for k in acc:
                "hbm_bytes_per_launch": (2 * f_raw + w) / n, "hbm_bytes_per_step": (2 * f_raw + w) / STEPS}
 def cls(pred):
     ks = [k for k in rows if pred(k)]
-    main = [k for k in ks if "finalize" not in k and "cache_prefetch" not in k]
+    main = [k for k in ks if not any(t in k for t in ("finalize", "cache_prefetch", "pack_weights", "transform", "finish", "accumulate", "bn_stats", "bn_bwd_finalize"))]
     launches = sum(rows[k]["launches_per_step"] for k in main)
     tot = sum(rows[k]["hbm_bytes_per_step"] for k in ks)
     return {"kernels": sorted(ks), "launches_per_step": launches, "hbm_bytes_per_step": tot,
@@ -42,10 +42,18 @@ out = {
  "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --workload $WL --steps 3 --warmup 1 (tools/exp/bench_pmc.sh), $ROUND",
  "correction": "hbm_bytes = 2 x FETCH_SIZE + WRITE_SIZE: gfx950 FETCH_SIZE reports 1/2 of wide coalesced reads (MI355X_MICROARCH.md, HBM section); the dword LDS-DMA gathers of the conv kernels are not separately calibrated, WRITE_SIZE as reported; both counters are in KiB",
  "classes": {
-   "conv_dw": cls(lambda k: "conv_dw" in k),
-   "conv_fwd": cls(lambda k: "conv_fwd_direct" in k or "cache_prefetch" in k),  # configs[1] only: the LDS-DMA GEMM serves forward AND dX
-   "conv_igemm_fwd_and_dx": cls(lambda k: "conv_igemm" in k),
-   "batchnorm": cls(lambda k: "Bn" in k or "bn_" in k or "chan_reduce" in k),
+   # keys = bench.py's kernel classes. The fused Winograd kernel serves forward AND dX; the LDS-DMA GEMMs serve the
+   # direct forward / dX layers and (as a 16-group GEMM) the three-kernel Winograd dW of the 14x14 / 7x7 stages.
+   "conv_dw": cls(lambda k: ("conv_dw" in k) and "wino" not in k),
+   "conv_fwd": cls(lambda k: "conv_fwd_direct" in k or "cache_prefetch" in k or "conv_igemm" in k or "conv_pack_weights" in k),
+   "conv_dx": cls(lambda k: "conv_igemm" in k or "conv_pack_weights" in k),
+   "conv_fwd_winograd": cls(lambda k: "wino_fused_kernel" in k or "wino_pack_weights" in k),
+   "conv_dx_winograd": cls(lambda k: "wino_fused_kernel" in k or "wino_pack_weights" in k),
+   "conv_dw_winograd": cls(lambda k: "wino_dw" in k or "wino_input_transform" in k or "wino_dy_transform" in k),
+   "bn_fwd": cls(lambda k: "BnApplyBody" in k or "bn_stats" in k or "StatsF" in k),
+   "bn_bwd": cls(lambda k: "BnBwd" in k or "bn_bwd" in k or "BwdSumsF" in k),
+   "depthwise_fwd": cls(lambda k: "dw3_fwd" in k or "dw_fwd" in k),
+   "depthwise_bwd": cls(lambda k: "dw3_bwd" in k or "dw_bwd" in k or "ActBwdSumF" in k or "dw_weight_accumulate" in k),
  },
  "kernels": {k[:120]: v for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["hbm_bytes_per_step"])[:24]},
  "total_hbm_bytes_per_step": sum(v["hbm_bytes_per_step"] for v in rows.values()),
