@@ -182,6 +182,13 @@ def roofline_of(prof, workload, traffic_ok):
     """roofline of the class that takes the most time inside the timed region"""
     if not prof:
         return None
+    # ONE kernel (wino_fused_kernel) serves the forward and the dX class of the Winograd layers: the dominant KERNEL is
+    # judged on both together (the per-class figures stay in `kernel_classes`)
+    prof = dict(prof)
+    fw, dx = prof.pop("conv_fwd_winograd", None), prof.pop("conv_dx_winograd", None)
+    if fw or dx:
+        parts = [p for p in (fw, dx) if p]
+        prof["conv_fwd_dx_winograd"] = {k: sum(p[k] for p in parts) for k in ("ms", "launches", "flops", "bytes")}
     name, d = max(prof.items(), key=lambda kv: kv[1]["ms"])
     avg_ms = d["ms"] / d["launches"]
     tf = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["flops"] else 0.0
@@ -194,7 +201,8 @@ def roofline_of(prof, workload, traffic_ok):
     else:
         roof = {"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
-    traffic, source = pmc_traffic(workload, name) if traffic_ok else (None, "non-default batch or variant: no PMC summary applies")
+    traffic, source = (pmc_traffic(workload, "conv_fwd_winograd" if name == "conv_fwd_dx_winograd" else name) if traffic_ok
+                       else (None, "non-default batch or variant: no PMC summary applies"))
     if "winograd" in name:
         # the class timers of the Winograd kernels carry the FLOPs the MFMAs really execute (16 instead of 36
         # multiplies per 2x2 outputs: DESIGN.md section 4.8); the direct-convolution count of the same layers is 2.25x that
