@@ -66,6 +66,7 @@ SIGNATURES = {
     "bcnn_hip_depthwise_backward": (None, [vp] * 7 + [i] * 9),
     "bcnn_hip_sgd_update": (None, [vp, vp, vp, vp, sz, sz, i, f, f, f]),
     "bcnn_hip_sgd_update_chunks": (None, [vp, i, i, f, f, f]),
+    "bcnn_hip_zero_chunks": (None, [vp, i]),
     "bcnn_hip_adam_update": (None, [vp, vp, vp, vp, vp, vp, sz, sz, i, i, f, f, f, f, f]),
     "bcnn_hip_eltwise_forward": (None, [vp, vp, vp, sz, sz, i]),
     "bcnn_hip_eltwise_backward": (None, [vp, vp, vp, vp, sz, sz, i, i]),

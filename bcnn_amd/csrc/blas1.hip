@@ -177,6 +177,21 @@ __global__ __launch_bounds__(256) void sgd_chunks_kernel(const bcnn_hip_sgd_chun
     }
 }
 
+// one workgroup per table entry (<= BCNN_HIP_FILL_CHUNK floats of one buffer): zero fill
+__global__ __launch_bounds__(256) void zero_chunks_kernel(const bcnn_hip_fill_chunk* __restrict__ chunks) {
+    const bcnn_hip_fill_chunk ch = chunks[blockIdx.x];
+    float* p = ch.p_d;
+    const unsigned n = ch.count;
+    // scalar head up to 16-byte alignment, 16-byte stores on the body, scalar tail
+    unsigned head = (unsigned)(((16 - (reinterpret_cast<uintptr_t>(p) & 15)) & 15) / 4);
+    if (head > n) head = n;
+    if (threadIdx.x < head) p[threadIdx.x] = 0.f;
+    float4* b4 = reinterpret_cast<float4*>(p + head);
+    const unsigned nb = n - head, n4 = nb / 4;
+    for (unsigned j = threadIdx.x; j < n4; j += 256) b4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (unsigned j = n4 * 4 + threadIdx.x; j < nb; j += 256) p[head + j] = 0.f;
+}
+
 }  // namespace bcnn_hip
 
 using namespace bcnn_hip;
@@ -289,6 +304,12 @@ void bcnn_hip_adam_update(float* w, float* b, float* dw, float* db, float* adam_
             -lr / batch_size * mu);
         KERNEL_CHECK();
     }
+}
+
+void bcnn_hip_zero_chunks(const bcnn_hip_fill_chunk* chunks_d, int num_chunks) {
+    if (num_chunks <= 0) return;
+    zero_chunks_kernel<<<num_chunks, 256, 0, current_stream()>>>(chunks_d);
+    KERNEL_CHECK();
 }
 
 void bcnn_hip_sgd_update_chunks(const bcnn_hip_sgd_chunk* chunks_d, int num_chunks, int batch_size, float lr,

@@ -171,6 +171,12 @@ static void invalidate_sgd_table(bcnn_net *net) {
         hc->sgd_chunks_gpu = NULL;
     }
     hc->num_sgd_chunks = 0;
+    if (hc->fill_chunks_gpu) {
+        bcnn_hip_sync();
+        bcnn_hip_free(hc->fill_chunks_gpu);
+        hc->fill_chunks_gpu = NULL;
+    }
+    hc->num_fill_chunks = -1; /* not built */
 }
 
 bcnn_status bcnn_net_add_node(bcnn_net *net, bcnn_node node) {
@@ -222,6 +228,7 @@ bcnn_status bcnn_init_net(bcnn_net **net, bcnn_mode mode) {
     p->hip_ctx = calloc(1, sizeof(bcnn_hip_context));
     if (!p->hip_ctx) { free(p); return BCNN_FAILED_ALLOC; }
     hctx(p)->dp_world = 1;
+    hctx(p)->num_fill_chunks = -1;
     /* tensor 0 = "input", tensor 1 = "label" (reference bcnn_net.c:66-76) */
     bcnn_tensor in = {0}, lab = {0};
     in.name = dup_name("input");
@@ -255,6 +262,7 @@ void bcnn_end_net(bcnn_net **pnet) {
         bcnn_hip_free(hc->param_arena_gpu);
         bcnn_hip_free(hc->grad_arena_gpu);
         bcnn_hip_free(hc->sgd_chunks_gpu);
+        bcnn_hip_free(hc->fill_chunks_gpu);
         free(hc->sgd_chunks_host);
         free(hc->grad_fill_dead);
         free(hc->node_grad_first);
@@ -436,6 +444,12 @@ bcnn_status bcnn_compile_net(bcnn_net *net) {
         comm_sync_parameters(net); /* communicator installed before the arena existed / new parameters appeared */
     }
     mark_dead_grad_fills(net);
+    if (hc->fill_chunks_gpu) { /* the table of live fills follows the dead-fill marks */
+        bcnn_hip_sync();
+        bcnn_hip_free(hc->fill_chunks_gpu);
+        hc->fill_chunks_gpu = NULL;
+    }
+    hc->num_fill_chunks = -1;
     bcnn_hip_sync();
     return BCNN_SUCCESS;
 }
@@ -448,22 +462,49 @@ bcnn_status bcnn_set_mode(bcnn_net *net, bcnn_mode mode) {
 /* ------------------------------------------------------------------------------------------------
  * executor loops
  * ---------------------------------------------------------------------------------------------- */
-void bcnn_forward(bcnn_net *net) {
-    for (int i = 0; i < net->num_nodes; ++i) {
-        bcnn_node *node = &net->nodes[i];
-        if (net->mode == BCNN_MODE_TRAIN) {
-            /* every dst gradient is zero-filled before the node runs (reference bcnn_net.c:361-375):
-             * pooling / eltwise / fc / softmax backward ACCUMULATE into it */
-            for (int d = 0; d < node->num_dst; ++d) {
-                bcnn_tensor *t = &net->tensors[node->dst[d]];
-                const bcnn_hip_context *hc = hctx(net);
-                /* tensors created after the last bcnn_compile_net have no entry: they are filled like the reference does */
-                if (hc->grad_fill_dead && node->dst[d] < hc->grad_fill_count && hc->grad_fill_dead[node->dst[d]]) continue;
-                if (t->grad_data_gpu) bcnn_hip_fill_f32(t->grad_data_gpu, (size_t)bcnn_tensor_size(t), 0.0f);
+/* Every dst gradient is zero-filled before its node runs (reference bcnn_net.c:361-375): pooling / eltwise / fc /
+ * softmax backward ACCUMULATE into it. No forward worker reads a gradient, so the fills that are not provably dead
+ * (mark_dead_grad_fills) are issued together, as ONE launch over a table, at the start of the pass. */
+static void build_fill_table(bcnn_net *net) {
+    bcnn_hip_context *hc = hctx(net);
+    int cap = 256, n = 0;
+    bcnn_hip_fill_chunk *tab = (bcnn_hip_fill_chunk *)malloc((size_t)cap * sizeof(*tab));
+    unsigned char *seen = (unsigned char *)calloc((size_t)net->num_tensors + 1, 1);
+    for (int i = 0; i < net->num_nodes; ++i)
+        for (int d = 0; d < net->nodes[i].num_dst; ++d) {
+            const int id = net->nodes[i].dst[d];
+            bcnn_tensor *t = &net->tensors[id];
+            if (seen[id] || !t->grad_data_gpu) continue;
+            seen[id] = 1;
+            if (hc->grad_fill_dead && id < hc->grad_fill_count && hc->grad_fill_dead[id]) continue;
+            const size_t sz = (size_t)bcnn_tensor_size(t);
+            for (size_t off = 0; off < sz; off += BCNN_HIP_FILL_CHUNK) {
+                if (n == cap) {
+                    cap *= 2;
+                    tab = (bcnn_hip_fill_chunk *)realloc(tab, (size_t)cap * sizeof(*tab));
+                }
+                tab[n].p_d = t->grad_data_gpu + off;
+                tab[n].count = (unsigned int)((sz - off < BCNN_HIP_FILL_CHUNK) ? (sz - off) : BCNN_HIP_FILL_CHUNK);
+                tab[n].reserved = 0;
+                ++n;
             }
         }
-        node->forward(net, node);
+    free(seen);
+    hc->num_fill_chunks = n;
+    if (n > 0) {
+        hc->fill_chunks_gpu = bcnn_hip_malloc_f32(((size_t)n * sizeof(*tab) + 3) / 4);
+        bcnn_hip_memcpy_h2d(hc->fill_chunks_gpu, tab, (size_t)n * sizeof(*tab));
     }
+    free(tab);
+}
+
+void bcnn_forward(bcnn_net *net) {
+    bcnn_hip_context *hc = hctx(net);
+    if (net->mode == BCNN_MODE_TRAIN) {
+        if (hc->num_fill_chunks < 0) build_fill_table(net);
+        bcnn_hip_zero_chunks((const bcnn_hip_fill_chunk *)hc->fill_chunks_gpu, hc->num_fill_chunks);
+    }
+    for (int i = 0; i < net->num_nodes; ++i) net->nodes[i].forward(net, &net->nodes[i]);
 }
 
 /* in-library data parallelism: the gradient-ready callback of bcnn_set_data_parallel_comm */

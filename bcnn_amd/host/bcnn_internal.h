@@ -142,6 +142,10 @@ typedef struct bcnn_hip_context {
     void *sgd_chunks_gpu;
     int num_sgd_chunks, cap_sgd_chunks;
     int sgd_collecting;
+    /* the gradient zero fills of a TRAIN-mode forward pass gathered into one launch (built by the first forward after
+     * a compile; dropped with the SGD table when the graph changes) */
+    void *fill_chunks_gpu;
+    int num_fill_chunks;
     /* RCCL inside the library (bcnn_set_data_parallel_comm): finished tail ranges of the gradient arena are gathered
      * into buckets of comm_bucket floats and all-reduced on the communicator's stream while backward continues */
     int comm_active;

@@ -242,6 +242,18 @@ typedef struct bcnn_hip_sgd_chunk {
 void bcnn_hip_sgd_update_chunks(const bcnn_hip_sgd_chunk *chunks_d, int num_chunks, int batch_size,
                                 float learning_rate, float momentum, float decay);
 
+/* Zero fill of MANY buffers in one launch: the executor resets every destination gradient before the node runs
+ * (bcnn_net.c:361-375), ~40 small hipMemset-sized launches per ResNet-18 step; nothing reads a gradient during the
+ * forward pass, so the fills that are not provably dead are issued together at its start. `chunks_d`: device array,
+ * each entry at most BCNN_HIP_FILL_CHUNK floats of one buffer. */
+#define BCNN_HIP_FILL_CHUNK 16384
+typedef struct bcnn_hip_fill_chunk {
+    float *p_d;
+    unsigned int count;
+    unsigned int reserved;
+} bcnn_hip_fill_chunk;
+void bcnn_hip_zero_chunks(const bcnn_hip_fill_chunk *chunks_d, int num_chunks);
+
 /* ---------------------------------------------------------------------------------------------
  * "Next" rows: the nodes either side of the hot path that a ResNet-style
  * graph needs, kept on the device so that a training step has no host round trip.
