@@ -93,7 +93,6 @@ template <int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(64 * WM * WN, ABL_LB) void conv_igemm_dma_kernel(const DmaArgs a) {
     constexpr int BK = kDmaBK;
     constexpr int NW = WM * WN;         // waves per workgroup (4, or 2 for the 64 x 32 tile)
-    constexpr int NT = 64 * NW;         // threads
     constexpr int RPW = BK / NW;        // K rows each wave stages per tile
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     // BN == 32: a B row is only half a DMA slab, so one DMA instruction fills TWO consecutive K rows (lanes

@@ -282,7 +282,11 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
                     }
             }
             float sv = 0.f, sq = 0.f;
+#ifdef WF_ABL_NOSTORE
+            if (tile_ok && o[0][0] == 123.456f) {
+#else
             if (tile_ok) {
+#endif
                 float* row = a.dst + ((size_t)(n * (unsigned)a.M + (unsigned)f) * (size_t)HW) + (size_t)(oh * a.W + ow);
                 if (vec2) {
                     *reinterpret_cast<float2*>(row) = make_float2(o[0][0], o[0][1]);
