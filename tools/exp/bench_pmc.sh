@@ -32,7 +32,9 @@ for k in acc:
                "hbm_bytes_per_launch": (2 * f_raw + w) / n, "hbm_bytes_per_step": (2 * f_raw + w) / STEPS}
 def cls(pred):
     ks = [k for k in rows if pred(k)]
-    main = [k for k in ks if not any(t in k for t in ("finalize", "cache_prefetch", "pack_weights", "transform", "finish", "accumulate", "bn_stats", "bn_bwd_finalize"))]
+    # launches of the class = its main kernels (one per layer call); helpers (packing, transforms, finalize) only add bytes.
+    # The three-kernel Winograd dW of a layer is counted through its dy transform (its GEMM is a conv_dw_dma launch).
+    main = [k for k in ks if "wino_dy_transform" in k or not any(t in k for t in ("finalize", "cache_prefetch", "pack_weights", "transform", "finish", "accumulate", "bn_stats", "bn_bwd_finalize"))]
     launches = sum(rows[k]["launches_per_step"] for k in main)
     tot = sum(rows[k]["hbm_bytes_per_step"] for k in ks)
     return {"kernels": sorted(ks), "launches_per_step": launches, "hbm_bytes_per_step": tot,
