@@ -47,13 +47,32 @@ struct WinoFusedArgs {
     unsigned src_bytes, upk_bytes;
 };
 
+#ifdef WF_ABL_CLOCK
+__device__ unsigned long long g_wf_clk[8][40];
+extern "C" void bcnn_hip_debug_read_wf_clock(unsigned long long* out) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wf_clk), sizeof(g_wf_clk));
+}
+#define WF_STAMP(i) do { if (stamp_on && lane == 0) g_wf_clk[wid][i] = clock64(); } while (0)
+#else
+#define WF_STAMP(i) do { } while (0)
+#endif
+
 // EPI: 0 = plain store, 1 = bias + ReLU, 2 = bias + any other cheap activation (runtime switch)
 //
 // Persistent: one workgroup per CU (128 KB of LDS) walks the (tile block, channel block) pairs with stride gridDim.x,
-// so no CU waits for a dispatch between blocks. The two halves of the workgroup run the chunk's phases in opposite
-// order -- waves 0-3 transform the NEXT chunk's patches first and multiply afterwards, waves 4-7 multiply first --
-// so that on every SIMD (which hosts one wave of each half) the vector-ALU / LDS-store work of one wave runs beside
-// the MFMAs of the other instead of both waves doing the same thing at the same time.
+// so no CU waits for a dispatch between blocks. Per chunk every wave "produces" once (transforms the NEXT chunk's
+// patches into V, requests the patches of the chunk after that, DMAs its share of the next U slab) and multiplies
+// (32 MFMAs). Vector-ALU work and fp32 MFMAs do not overlap on a SIMD, but each SIMD hosts one
+// wave of each half of the workgroup and the halves produce at different times -- waves 0-3 before their MFMAs,
+// waves 4-7 between their second and third k-step -- so that whenever one wave stalls in its produce step (memory
+// latency, LDS stores) the other one has MFMAs to issue (cycle stamps: tools/exp/wf_clock.py).
+//
+// Patch loads: a patch row is the pair of columns (2 tw, 2 tw + 1) -- ONE 8-byte load per lane, contiguous over the
+// wave's tiles -- plus its left / right neighbour columns, which are the neighbouring lanes' pairs (wave shifts; only
+// lanes 0 and 63 fetch theirs from memory). 8 load instructions and ~1/4 of the L1 line traffic of 16 stride-2 dword
+// loads, whose issue was measured to stall the requesting waves ~1250 cycles per chunk. (Raw buffer loads of 8 bytes
+// need 4-byte alignment only and are range-checked per dword: tools/micro/bufload_probe.hip.)
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[2 * WF_STAGE];  // 128 KB: two stages; the epilogue's S[4][2][64][64]
@@ -63,7 +82,7 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
     const int HW = a.H * a.W;
     const int wrow = wid >> 1, fh = wid & 1;  // this wave's row of positions and its half of the 64 channels
     const bool early = wid < 4;               // transforms at the head of a chunk (see above)
-    const auto rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.src), 0, (int)a.src_bytes, 0x00020000);
+    const rsrc_i4 rs_src = make_rsrc(a.src, a.src_bytes);
     const rsrc_i4 rs_u = make_rsrc(a.upk, a.upk_bytes);
     const unsigned lds0 = lds_offset(&lds[0]);
     // LDS-DMA of U: 4 rows (k) x 64 floats per instruction; lane -> row lane / 16, floats 4 * (lane % 16) ..
@@ -79,33 +98,45 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
         const int half = whole ? 0 : ((unit - a.nfull) & 1);
         const int mb = blk % a.mblocks, tb = blk / a.mblocks;  // channel blocks of one tile block run together
         const int m0 = mb * WF_BF;
+#ifdef WF_ABL_CLOCK
+        const bool stamp_on = blockIdx.x == 37 && unit == (int)blockIdx.x + (int)gridDim.x;
+#endif
+        WF_STAMP(0);
         if (unit != (int)blockIdx.x) __syncthreads();  // the previous unit's epilogue has read S
+        WF_STAMP(1);
 
         // ---- this lane's tile (the same one for the input transform and for the output transform) -------
         const unsigned t = (unsigned)tb * WF_BT + (unsigned)(half * 32) + (unsigned)lane;
         const bool tile_ok = t < a.T && (whole || lane < 32);
-        const unsigned n = tile_ok ? t / per_img : 0u;
-        const unsigned rr = tile_ok ? t - n * per_img : 0u;
+        // lanes 32-63 of a half block load their (real) tiles too: lane 31 takes its right column from lane 32
+        const bool addr_ok = t < a.T;
+        const unsigned n = addr_ok ? t / per_img : 0u;
+        const unsigned rr = addr_ok ? t - n * per_img : 0u;
         const int th = (int)(rr / (unsigned)a.TW), tw = (int)(rr - (unsigned)th * (unsigned)a.TW);
-        const int ih0 = 2 * th - 1, iw0 = 2 * tw - 1;
-        unsigned voff[4][4];
+        const int ih0 = 2 * th - 1;
+        unsigned voff[4], voff_edge[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int ih = ih0 + i, iw = iw0 + j;
-                const bool ok = tile_ok && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
-                voff[i][j] = ok ? ((n * (unsigned)a.J * (unsigned)HW) + (unsigned)(ih * a.W + iw)) * 4u : kOOB;
-            }
+        for (int i = 0; i < 4; ++i) {
+            const int ih = ih0 + i;
+            const bool row_ok = addr_ok && (unsigned)ih < (unsigned)a.H;
+            const unsigned row = ((n * (unsigned)a.J * (unsigned)HW) + (unsigned)(ih * a.W)) * 4u;
+            voff[i] = row_ok ? row + (unsigned)(8 * tw) : kOOB;
+            const bool want_l = lane == 0 && tw > 0, want_r = lane == 63 && tw + 1 < a.TW;
+            voff_edge[i] = (row_ok && (want_l || want_r)) ? row + (unsigned)(want_l ? 8 * tw - 4 : 8 * tw + 8) : kOOB;
+        }
+        const bool pad_l = tw == 0, pad_r = tw + 1 == a.TW;
+        const bool odd_w = (a.W & 1) != 0;  // then the last tile's column 2 tw + 1 == W is padding as well
 
+        // d[i][1..2] = the pair, d[i][0] = the neighbour column fetched by lanes 0 / 63 (0.0 in all other lanes)
         float d[4][4];
         auto load_patch = [&](int kc) {  // channel kc*8 + wid of this lane's tile
             const unsigned soff = (unsigned)(kc * WF_KC + wid) * (unsigned)HW * 4u;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    d[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_src, (int)voff[i][j], (int)soff, 0));
+            for (int i = 0; i < 4; ++i) {
+                const buf_f32x2 m = buffer_load_f32x2(rs_src, (int)voff[i], (int)soff, 0);
+                d[i][1] = m[0]; d[i][2] = m[1];
+                d[i][0] = buffer_load_f32(rs_src, (int)voff_edge[i], (int)soff, 0);
+            }
         };
         auto dma_u = [&](int kc, int stage) {  // each wave brings in two positions: 2 x 8 rows of 64 floats
 #pragma unroll
@@ -116,6 +147,15 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
             }
         };
         auto write_v = [&](int stage) {  // B^T d B -> V[xi][wid][lane]
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {  // lane l - 1's right element / lane l + 1's left element; lanes 0 / 63 keep `old`
+                const int e = __builtin_bit_cast(int, d[i][0]);
+                const int l = __builtin_amdgcn_update_dpp(e, __builtin_bit_cast(int, d[i][2]), 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+                const int r = __builtin_amdgcn_update_dpp(e, __builtin_bit_cast(int, d[i][1]), 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+                d[i][0] = pad_l ? 0.f : __builtin_bit_cast(float, l);
+                d[i][3] = pad_r ? 0.f : __builtin_bit_cast(float, r);
+                if (odd_w) d[i][2] = pad_r ? 0.f : d[i][2];  // uniform
+            }
             float tt[4][4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -142,7 +182,17 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[j][tt][r] = 0.f;
 
-        auto multiply = [&](int cur) {  // 32 MFMAs on stage `cur`
+        // everything chunk kc contributes to the chunks after it: V of chunk kc + 1 from the patches requested a whole
+        // chunk ago, the patch requests of chunk kc + 2 into the registers this frees, the U slab of chunk kc + 1
+        auto produce = [&](int kc) {
+#ifndef WF_ABL_NOXFORM
+            if (kc + 1 < nchunks) write_v((kc & 1) ^ 1);
+            if (kc + 2 < nchunks) load_patch(kc + 2);
+#endif
+            if (kc + 1 < nchunks) dma_u(kc + 1, (kc & 1) ^ 1);
+        };
+        // 32 MFMAs on stage `cur`; the late half produces (see above) between the second and the third k-step
+        auto multiply = [&](int cur, int produce_kc, int kc_stamp) {
             const float* us = lds + cur * WF_STAGE + (4 * wrow) * WF_KC * WF_BF + fh * 32 + l31;
             const float* vs = lds + cur * WF_STAGE + 16 * WF_KC * WF_BF + (4 * wrow) * WF_KC * WF_BT + l31;
             // fragments of k-step ks + 1 are fetched from LDS before the MFMAs of k-step ks are issued
@@ -176,6 +226,13 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
 #endif
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if (ks == 1 && produce_kc >= 0) {  // uniform
+                    produce(produce_kc);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#ifdef WF_ABL_CLOCK
+                if (kc_stamp == 3 || kc_stamp == 4) WF_STAMP(32 + 4 * (kc_stamp - 3) + ks);
+#endif
             }
         };
 
@@ -184,36 +241,23 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
         load_patch(0);
         write_v(0);
 #ifndef WF_ABL_NOXFORM
-        if (early && nchunks > 1) load_patch(1);  // the early half always holds the next chunk's patches in registers
+        if (nchunks > 1) load_patch(1);  // every wave holds the next chunk's patches in registers
 #endif
+        WF_STAMP(2);
         dma_wait();
         __syncthreads();
+        WF_STAMP(3);
         for (int kc = 0; kc < nchunks; ++kc) {
-            const int cur = kc & 1, nxt = cur ^ 1;
-            const bool more = kc + 1 < nchunks;
+            const int cur = kc & 1;
+            if (kc < 8) WF_STAMP(4 + 3 * kc);
             // stage `nxt` was last read before the barrier that ended iteration kc - 1
-#ifndef WF_ABL_NOXFORM
-            if (early && more) write_v(nxt);         // patches of chunk kc + 1: requested during chunk kc - 1
-#endif
-            if (more) dma_u(kc + 1, nxt);
-#ifndef WF_ABL_NOXFORM
-            if (!early && more) load_patch(kc + 1);
-#endif
-            __builtin_amdgcn_sched_barrier(0);       // requests first, then the MFMAs they fly under
-            multiply(cur);
+            if (early) produce(kc);
+            __builtin_amdgcn_sched_barrier(0);  // requests first, then the MFMAs they fly under
+            if (kc < 8) WF_STAMP(5 + 3 * kc);
+            multiply(cur, early ? -1 : kc, kc);
             __builtin_amdgcn_sched_barrier(0);
-            if (early) {
-#ifndef WF_ABL_NOXFORM
-                if (kc + 2 < nchunks) load_patch(kc + 2);
-#endif
-                __builtin_amdgcn_sched_barrier(0);
-                dma_wait_n<16>();                    // the 4 LDS-DMAs are older than the 16 patch loads: those may fly on
-            } else {
-#ifndef WF_ABL_NOXFORM
-                if (more) write_v(nxt);
-#endif
-                dma_wait();
-            }
+            if (kc < 8) WF_STAMP(6 + 3 * kc);
+            dma_wait();
             __syncthreads();
         }
 
@@ -231,6 +275,7 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
         }
 #endif
         // ---- epilogue -----------------------------------------------------------------------------------
+        WF_STAMP(28);
         // (1) column half of A^T m A on the accumulators: S[b] = sum_j m[j] * A[j][b], A^T = [1 1 1 0; 0 1 -1 -1];
         //     S[wrow][b][f][t] -> LDS (the K loop's last barrier has retired every read of the stages)
 #pragma unroll
@@ -245,7 +290,9 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
                 p[WF_BF * WF_BT] = m1v - m2v - m3v;
             }
         }
+        WF_STAMP(29);
         __syncthreads();
+        WF_STAMP(30);
         // (2) one (channel, tile) per lane: the row half, bias / activation, stores, statistics
         const int oh = 2 * th, ow = 2 * tw;
         const bool two_cols = ow + 1 < a.W, two_rows = oh + 1 < a.H;
@@ -318,6 +365,7 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
                 }
             }
         }
+        WF_STAMP(31);
     }
 }
 
@@ -501,7 +549,6 @@ __global__ __launch_bounds__(512, 2) void wino_dw_fused_kernel(const WinoDwArgs 
     unsigned tend = tbeg + a.tiles_per_split;
     if (tend > a.T) tend = a.T;
     const int nchunks = tbeg < tend ? (int)((tend - tbeg + WD_KT - 1) / WD_KT) : 0;
-    const int HW = a.H * a.W;
 
     // this thread's transform item in every chunk: channel ch (of both the f block and the c block), tile tl
     const int tl = lane & 7, ch = wid * 8 + (lane >> 3);

@@ -17,6 +17,12 @@ __device__ __forceinline__ rsrc_i4 make_rsrc(const void* p, unsigned bytes) {
     return r;
 }
 
+// 4 / 8 bytes per lane into registers, out-of-range voffset -> 0.0. Declared on the LLVM intrinsic because hipcc 7.2
+// narrows element reads of `__builtin_amdgcn_raw_buffer_load_b64/_b128` to one dword (tools/micro/bufload_probe.hip).
+typedef float buf_f32x2 __attribute__((ext_vector_type(2)));
+__device__ float buffer_load_f32(rsrc_i4 rs, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+__device__ buf_f32x2 buffer_load_f32x2(rsrc_i4 rs, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f32");
+
 __device__ __forceinline__ unsigned lds_offset(const void* p) { return (unsigned)(size_t)(lds_void_ptr)p; }
 
 // One LDS-DMA slab: 64 lanes x 4 B from rsrc[voff + soff] to LDS[lds_base + 4*lane]; an out-of-range voff
