@@ -44,7 +44,7 @@ struct WinoFusedArgs {
     int nfull;         // units [0, nfull) are whole 64-tile blocks, the rest are the two 32-tile halves of the last blocks
     int nunits;
     int act, add_bias;
-    unsigned src_bytes, upk_bytes;
+    unsigned src_bytes, upk_bytes, dst_bytes, stats_bytes;
 };
 
 #ifdef WF_ABL_CLOCK
@@ -58,7 +58,8 @@ extern "C" void bcnn_hip_debug_read_wf_clock(unsigned long long* out) {
 #define WF_STAMP(i) do { } while (0)
 #endif
 
-// EPI: 0 = plain store, 1 = bias + ReLU, 2 = bias + any other cheap activation (runtime switch)
+// EPI: 0 = plain store, 1 = bias + ReLU, 2 = bias + any other cheap activation (runtime switch); STATS: per-channel
+// sum / sum of squares of the raw outputs for a batch-norm that follows (EPI == 0 only)
 //
 // Persistent: one workgroup per CU (128 KB of LDS) walks the (tile block, channel block) pairs with stride gridDim.x,
 // so no CU waits for a dispatch between blocks. Per chunk every wave "produces" once (transforms the NEXT chunk's
@@ -73,9 +74,9 @@ extern "C" void bcnn_hip_debug_read_wf_clock(unsigned long long* out) {
 // lanes 0 and 63 fetch theirs from memory). 8 load instructions and ~1/4 of the L1 line traffic of 16 stride-2 dword
 // loads, whose issue was measured to stall the requesting waves ~1250 cycles per chunk. (Raw buffer loads of 8 bytes
 // need 4-byte alignment only and are range-checked per dword: tools/micro/bufload_probe.hip.)
-template <int EPI>
+template <int EPI, bool STATS>
 __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs a) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * WF_STAGE];  // 128 KB: two stages; the epilogue's S[4][2][64][64]
+    __shared__ __attribute__((aligned(16))) float lds[2 * WF_STAGE];  // 128 KB: two stages; the epilogue's S in the second one
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lhi = lane >> 5;
@@ -84,37 +85,39 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
     const bool early = wid < 4;               // transforms at the head of a chunk (see above)
     const rsrc_i4 rs_src = make_rsrc(a.src, a.src_bytes);
     const rsrc_i4 rs_u = make_rsrc(a.upk, a.upk_bytes);
+    const rsrc_i4 rs_dst = make_rsrc(a.dst, a.dst_bytes);
+    const rsrc_i4 rs_stats = make_rsrc(a.stats, STATS ? a.stats_bytes : 0u);
     const unsigned lds0 = lds_offset(&lds[0]);
     // LDS-DMA of U: 4 rows (k) x 64 floats per instruction; lane -> row lane / 16, floats 4 * (lane % 16) ..
     const unsigned u_voff = ((unsigned)(lane >> 4) * (unsigned)a.Mpad + (unsigned)(lane & 15) * 4u) * 4u;
     const unsigned per_img = (unsigned)(a.TH * a.TW);
     const int nchunks = a.Jpad / WF_KC;
 
+    // ---- per-unit state: of the unit being multiplied and, from the end of its K loop on, of the NEXT unit ----------
     // Work units: whole blocks first; when the last round would leave most CUs idle, its blocks are split into
     // two 32-tile halves (second t-tile of the accumulators unused) so that twice as many CUs share that round.
-    for (int unit = blockIdx.x; unit < a.nunits; unit += gridDim.x) {
-        const bool whole = unit < a.nfull;
+    bool whole = false, tile_ok = false, pad_l = false, pad_r = false;
+    int m0 = 0, tb = 0, half = 0, th = 0, tw = 0;
+    unsigned n = 0;
+    unsigned voff[4], voff_edge[4];
+    const bool odd_w = (a.W & 1) != 0;  // then the last tile's column 2 tw + 1 == W is padding as well
+    auto decode = [&](int unit) {
+        whole = unit < a.nfull;
         const int blk = whole ? unit : a.nfull + ((unit - a.nfull) >> 1);
-        const int half = whole ? 0 : ((unit - a.nfull) & 1);
-        const int mb = blk % a.mblocks, tb = blk / a.mblocks;  // channel blocks of one tile block run together
-        const int m0 = mb * WF_BF;
-#ifdef WF_ABL_CLOCK
-        const bool stamp_on = blockIdx.x == 37 && unit == (int)blockIdx.x + (int)gridDim.x;
-#endif
-        WF_STAMP(0);
-        if (unit != (int)blockIdx.x) __syncthreads();  // the previous unit's epilogue has read S
-        WF_STAMP(1);
-
-        // ---- this lane's tile (the same one for the input transform and for the output transform) -------
+        half = whole ? 0 : ((unit - a.nfull) & 1);
+        const int mb = blk % a.mblocks;  // channel blocks of one tile block run together
+        tb = blk / a.mblocks;
+        m0 = mb * WF_BF;
+        // this lane's tile (the same one for the input transform and for the output transform)
         const unsigned t = (unsigned)tb * WF_BT + (unsigned)(half * 32) + (unsigned)lane;
-        const bool tile_ok = t < a.T && (whole || lane < 32);
+        tile_ok = t < a.T && (whole || lane < 32);
         // lanes 32-63 of a half block load their (real) tiles too: lane 31 takes its right column from lane 32
         const bool addr_ok = t < a.T;
-        const unsigned n = addr_ok ? t / per_img : 0u;
+        n = addr_ok ? t / per_img : 0u;
         const unsigned rr = addr_ok ? t - n * per_img : 0u;
-        const int th = (int)(rr / (unsigned)a.TW), tw = (int)(rr - (unsigned)th * (unsigned)a.TW);
+        th = (int)(rr / (unsigned)a.TW);
+        tw = (int)(rr - (unsigned)th * (unsigned)a.TW);
         const int ih0 = 2 * th - 1;
-        unsigned voff[4], voff_edge[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int ih = ih0 + i;
@@ -124,63 +127,87 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
             const bool want_l = lane == 0 && tw > 0, want_r = lane == 63 && tw + 1 < a.TW;
             voff_edge[i] = (row_ok && (want_l || want_r)) ? row + (unsigned)(want_l ? 8 * tw - 4 : 8 * tw + 8) : kOOB;
         }
-        const bool pad_l = tw == 0, pad_r = tw + 1 == a.TW;
-        const bool odd_w = (a.W & 1) != 0;  // then the last tile's column 2 tw + 1 == W is padding as well
+        pad_l = tw == 0;
+        pad_r = tw + 1 == a.TW;
+    };
 
-        // d[i][1..2] = the pair, d[i][0] = the neighbour column fetched by lanes 0 / 63 (0.0 in all other lanes)
-        float d[4][4];
-        auto load_patch = [&](int kc) {  // channel kc*8 + wid of this lane's tile
-            const unsigned soff = (unsigned)(kc * WF_KC + wid) * (unsigned)HW * 4u;
+    // d[i][1..2] = the pair, d[i][0] = the neighbour column fetched by lanes 0 / 63 (0.0 in all other lanes)
+    float d[4][4];
+    auto load_patch = [&](int kc) {  // channel kc*8 + wid of this lane's tile
+        const unsigned soff = (unsigned)(kc * WF_KC + wid) * (unsigned)HW * 4u;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const buf_f32x2 m = buffer_load_f32x2(rs_src, (int)voff[i], (int)soff, 0);
-                d[i][1] = m[0]; d[i][2] = m[1];
-                d[i][0] = buffer_load_f32(rs_src, (int)voff_edge[i], (int)soff, 0);
-            }
-        };
-        auto dma_u = [&](int kc, int stage) {  // each wave brings in two positions: 2 x 8 rows of 64 floats
+        for (int i = 0; i < 4; ++i) {
+            const buf_f32x2 m = buffer_load_f32x2(rs_src, (int)voff[i], (int)soff, 0);
+            d[i][1] = m[0]; d[i][2] = m[1];
+            d[i][0] = buffer_load_f32(rs_src, (int)voff_edge[i], (int)soff, 0);
+        }
+    };
+    auto dma_u = [&](int kc, int stage) {  // each wave brings in two positions: 2 x 8 rows of 64 floats
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int xi = 2 * wid + (q >> 1), r0 = (q & 1) * 4;
-                const unsigned soff = (((unsigned)xi * (unsigned)a.Jpad + (unsigned)(kc * WF_KC + r0)) * (unsigned)a.Mpad + (unsigned)m0) * 4u;
-                dma_row_x4(rs_u, lds0 + (unsigned)((stage * WF_STAGE + (xi * WF_KC + r0) * WF_BF) * 4), u_voff, soff);
-            }
-        };
-        auto write_v = [&](int stage) {  // B^T d B -> V[xi][wid][lane]
+        for (int q = 0; q < 4; ++q) {
+            const int xi = 2 * wid + (q >> 1), r0 = (q & 1) * 4;
+            const unsigned soff = (((unsigned)xi * (unsigned)a.Jpad + (unsigned)(kc * WF_KC + r0)) * (unsigned)a.Mpad + (unsigned)m0) * 4u;
+            dma_row_x4(rs_u, lds0 + (unsigned)((stage * WF_STAGE + (xi * WF_KC + r0) * WF_BF) * 4), u_voff, soff);
+        }
+    };
+    auto write_v = [&](int stage) {  // B^T d B -> V[xi][wid][lane]
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {  // lane l - 1's right element / lane l + 1's left element; lanes 0 / 63 keep `old`
-                const int e = __builtin_bit_cast(int, d[i][0]);
-                const int l = __builtin_amdgcn_update_dpp(e, __builtin_bit_cast(int, d[i][2]), 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-                const int r = __builtin_amdgcn_update_dpp(e, __builtin_bit_cast(int, d[i][1]), 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-                d[i][0] = pad_l ? 0.f : __builtin_bit_cast(float, l);
-                d[i][3] = pad_r ? 0.f : __builtin_bit_cast(float, r);
-                if (odd_w) d[i][2] = pad_r ? 0.f : d[i][2];  // uniform
-            }
-            float tt[4][4];
+        for (int i = 0; i < 4; ++i) {  // lane l - 1's right element / lane l + 1's left element; lanes 0 / 63 keep `old`
+            const int e = __builtin_bit_cast(int, d[i][0]);
+            const int l = __builtin_amdgcn_update_dpp(e, __builtin_bit_cast(int, d[i][2]), 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+            const int r = __builtin_amdgcn_update_dpp(e, __builtin_bit_cast(int, d[i][1]), 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+            d[i][0] = pad_l ? 0.f : __builtin_bit_cast(float, l);
+            d[i][3] = pad_r ? 0.f : __builtin_bit_cast(float, r);
+            if (odd_w) d[i][2] = pad_r ? 0.f : d[i][2];  // uniform
+        }
+        float tt[4][4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                tt[0][j] = d[0][j] - d[2][j];
-                tt[1][j] = d[1][j] + d[2][j];
-                tt[2][j] = d[2][j] - d[1][j];
-                tt[3][j] = d[1][j] - d[3][j];
-            }
-            float* v = lds + stage * WF_STAGE + 16 * WF_KC * WF_BF + wid * WF_BT + lane;
+        for (int j = 0; j < 4; ++j) {
+            tt[0][j] = d[0][j] - d[2][j];
+            tt[1][j] = d[1][j] + d[2][j];
+            tt[2][j] = d[2][j] - d[1][j];
+            tt[3][j] = d[1][j] - d[3][j];
+        }
+        float* v = lds + stage * WF_STAGE + 16 * WF_KC * WF_BF + wid * WF_BT + lane;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                v[(4 * i + 0) * WF_KC * WF_BT] = tt[i][0] - tt[i][2];
-                v[(4 * i + 1) * WF_KC * WF_BT] = tt[i][1] + tt[i][2];
-                v[(4 * i + 2) * WF_KC * WF_BT] = tt[i][2] - tt[i][1];
-                v[(4 * i + 3) * WF_KC * WF_BT] = tt[i][1] - tt[i][3];
-            }
-        };
+        for (int i = 0; i < 4; ++i) {
+            v[(4 * i + 0) * WF_KC * WF_BT] = tt[i][0] - tt[i][2];
+            v[(4 * i + 1) * WF_KC * WF_BT] = tt[i][1] + tt[i][2];
+            v[(4 * i + 2) * WF_KC * WF_BT] = tt[i][2] - tt[i][1];
+            v[(4 * i + 3) * WF_KC * WF_BT] = tt[i][1] - tt[i][3];
+        }
+    };
+    // chunk 0 of a unit: U and V into stage 0, the patches of chunk 1 into the registers. The first unit's is issued
+    // here, every later unit's during the previous unit's epilogue (which keeps its S in stage 1 only).
+    auto start_unit = [&](int unit) {
+        decode(unit);
+        dma_u(0, 0);
+#ifndef WF_ABL_NOXFORM
+        load_patch(0);
+#endif
+    };
+    auto finish_start = [&]() {
+#ifndef WF_ABL_NOXFORM
+        write_v(0);
+        if (nchunks > 1) load_patch(1);  // every wave holds the next chunk's patches in registers
+#endif
+    };
 
-        f32x16 acc[4][2];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[j][tt][r] = 0.f;
+    start_unit(blockIdx.x);
+    finish_start();
+    for (int unit = blockIdx.x; unit < a.nunits; unit += gridDim.x) {
+#ifdef WF_ABL_CLOCK
+        const bool stamp_on = blockIdx.x == 37 && unit == (int)blockIdx.x + (int)gridDim.x;
+#endif
+        WF_STAMP(0);
+        WF_STAMP(1);
+        WF_STAMP(2);
+        // U(0) is older than the (up to) 8 patch requests of chunk 1, which may fly on
+        if (nchunks > 1) dma_wait_n<8>(); else dma_wait();
+        __syncthreads();  // stage 0 holds chunk 0 of this unit; the previous unit's epilogue has read its S (stage 1)
+        WF_STAMP(3);
+
+        f32x16 acc[4][2];  // not cleared: the first k-step of chunk 0 multiplies onto a literal zero
 
         // everything chunk kc contributes to the chunks after it: V of chunk kc + 1 from the patches requested a whole
         // chunk ago, the patch requests of chunk kc + 2 into the registers this frees, the U slab of chunk kc + 1
@@ -192,7 +219,7 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
             if (kc + 1 < nchunks) dma_u(kc + 1, (kc & 1) ^ 1);
         };
         // 32 MFMAs on stage `cur`; the late half produces (see above) between the second and the third k-step
-        auto multiply = [&](int cur, int produce_kc, int kc_stamp) {
+        auto multiply = [&](int cur, int produce_kc, bool first, int kc_stamp) {
             const float* us = lds + cur * WF_STAGE + (4 * wrow) * WF_KC * WF_BF + fh * 32 + l31;
             const float* vs = lds + cur * WF_STAGE + 16 * WF_KC * WF_BF + (4 * wrow) * WF_KC * WF_BT + l31;
             // fragments of k-step ks + 1 are fetched from LDS before the MFMAs of k-step ks are issued
@@ -215,15 +242,24 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if (ks == 0 && first) {  // uniform
+                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < 4; ++j) {
+                        acc[j][0] = mfma32(af[fc][j], bf[fc][j][0], zero);
+                        if (whole) acc[j][1] = mfma32(af[fc][j], bf[fc][j][1], zero);  // uniform
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
 #ifndef WF_ABL_NOMFMA
-                    acc[j][0] = mfma32(af[fc][j], bf[fc][j][0], acc[j][0]);
-                    if (whole) acc[j][1] = mfma32(af[fc][j], bf[fc][j][1], acc[j][1]);  // uniform
+                        acc[j][0] = mfma32(af[fc][j], bf[fc][j][0], acc[j][0]);
+                        if (whole) acc[j][1] = mfma32(af[fc][j], bf[fc][j][1], acc[j][1]);  // uniform
 #else
-                    acc[j][0][0] += af[fc][j] * bf[fc][j][0];
-                    acc[j][1][0] += af[fc][j] * bf[fc][j][1];
+                        acc[j][0][0] += af[fc][j] * bf[fc][j][0];
+                        acc[j][1][0] += af[fc][j] * bf[fc][j][1];
 #endif
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (ks == 1 && produce_kc >= 0) {  // uniform
@@ -237,30 +273,27 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
         };
 
         // ---- K loop -------------------------------------------------------------------------------------
-        dma_u(0, 0);
-        load_patch(0);
-        write_v(0);
-#ifndef WF_ABL_NOXFORM
-        if (nchunks > 1) load_patch(1);  // every wave holds the next chunk's patches in registers
-#endif
-        WF_STAMP(2);
-        dma_wait();
-        __syncthreads();
-        WF_STAMP(3);
         for (int kc = 0; kc < nchunks; ++kc) {
             const int cur = kc & 1;
             if (kc < 8) WF_STAMP(4 + 3 * kc);
-            // stage `nxt` was last read before the barrier that ended iteration kc - 1
+            // the other stage was last read before the barrier that ended iteration kc - 1
             if (early) produce(kc);
             __builtin_amdgcn_sched_barrier(0);  // requests first, then the MFMAs they fly under
             if (kc < 8) WF_STAMP(5 + 3 * kc);
-            multiply(cur, early ? -1 : kc, kc);
+            multiply(cur, early ? -1 : kc, kc == 0, kc);
             __builtin_amdgcn_sched_barrier(0);
             if (kc < 8) WF_STAMP(6 + 3 * kc);
             dma_wait();
             __syncthreads();
         }
 
+        // ---- epilogue, with the next unit's chunk 0 started underneath it ---------------------------------
+        WF_STAMP(28);
+        const bool e_whole = whole, e_tile_ok = tile_ok;
+        const int e_m0 = m0, e_tb = tb, e_half = half, oh = 2 * th, ow = 2 * tw;
+        const unsigned e_n = n;
+        const bool has_next = unit + (int)gridDim.x < a.nunits;
+        if (has_next) start_unit(unit + (int)gridDim.x);  // both stages are free: the K loop ended with a barrier
 #ifdef WF_ABL_NOEPI
         {
             float sum = 0.f;
@@ -271,99 +304,102 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
 #pragma unroll
                     for (int r = 0; r < 16; ++r) sum += acc[j][tt][r];
             if (sum == 123.456f) a.dst[0] = sum;
+            if (has_next) finish_start();
             continue;
         }
 #endif
-        // ---- epilogue -----------------------------------------------------------------------------------
-        WF_STAMP(28);
-        // (1) column half of A^T m A on the accumulators: S[b] = sum_j m[j] * A[j][b], A^T = [1 1 1 0; 0 1 -1 -1];
-        //     S[wrow][b][f][t] -> LDS (the K loop's last barrier has retired every read of the stages)
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            if (tt == 1 && !whole) break;  // uniform
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float m0v = acc[0][tt][r], m1v = acc[1][tt][r], m2v = acc[2][tt][r], m3v = acc[3][tt][r];
-                const int f = fh * 32 + mfma_row(r, lane);
-                float* p = lds + ((wrow * 2) * WF_BF + f) * WF_BT + tt * 32 + l31;
-                p[0] = m0v + m1v + m2v;
-                p[WF_BF * WF_BT] = m1v - m2v - m3v;
-            }
-        }
-        WF_STAMP(29);
-        __syncthreads();
-        WF_STAMP(30);
-        // (2) one (channel, tile) per lane: the row half, bias / activation, stores, statistics
-        const int oh = 2 * th, ow = 2 * tw;
         const bool two_cols = ow + 1 < a.W, two_rows = oh + 1 < a.H;
-        const bool vec2 = (a.W & 1) == 0;  // rows start 8-byte aligned, ow is even
+        // byte offsets of this lane's 2 x 2 outputs in channel 0 of its image; out of range = not stored
+        const unsigned o00 = e_tile_ok ? (e_n * (unsigned)a.M * (unsigned)HW + (unsigned)(oh * a.W + ow)) * 4u : kOOB;
+        const unsigned o10 = (e_tile_ok && two_rows) ? o00 + (unsigned)a.W * 4u : kOOB;
+        const unsigned o01 = two_cols ? o00 + 4u : kOOB, o11 = two_cols ? o10 + 4u : kOOB;  // used when W is odd
+        const float w00 = e_tile_ok ? 1.f : 0.f, w10 = (e_tile_ok && two_rows) ? 1.f : 0.f, w01 = two_cols ? 1.f : 0.f;
+        const unsigned st_voff = lane == 63 ? 0u : kOOB, st_voff2 = (lane == 63 && e_whole) ? 8u : kOOB;
+        float* const S = lds + WF_STAGE;   // [4 rows of positions][2][32 channels][64 tiles]: stage 1 only
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int fl = q * 8 + wid;  // wave-uniform channel
-            const int f = m0 + fl;
-            if (f >= a.M) continue;      // uniform
-            float sb[4][2];
+        for (int ph = 0; ph < 2; ++ph) {   // the 64 channels in two halves of 32
+            if (ph == 1) __syncthreads();  // the first half's readers are done with S
+            // (1) column half of A^T m A on the accumulators: S[b] = sum_j m[j] * A[j][b], A^T = [1 1 1 0; 0 1 -1 -1]
+            if (fh == ph) {                // uniform: the four waves that hold this half
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int tt = 0; tt < 2; ++tt) {
+                    if (tt == 1 && !e_whole) break;  // uniform
 #pragma unroll
-                for (int b = 0; b < 2; ++b) sb[i][b] = lds[((i * 2 + b) * WF_BF + fl) * WF_BT + lane];
-            float o[2][2];
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                o[0][b] = sb[0][b] + sb[1][b] + sb[2][b];
-                o[1][b] = sb[1][b] - sb[2][b] - sb[3][b];
-            }
-            if (EPI != 0) {
-                float bv = a.add_bias ? a.bias[f] : 0.f;
-                if (bv == 1.0f) bv = 0.f;  // bcnn_add_scalar of the AVX build adds nothing for exactly 1.0f (quirk 2)
-                const float sl = (EPI == 2 && a.act == BCNN_HIP_ACT_PRELU && a.slopes) ? a.slopes[f] : 0.f;
-#pragma unroll
-                for (int r = 0; r < 2; ++r)
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) {
-                        float vv = o[r][c];
-                        if (bv != 0.0f) vv += bv;
-                        if (EPI == 1) vv = vv * (float)(vv > 0);  // RELU as the reference's multiply (-0.0f, NaN propagate)
-                        else if (a.act != BCNN_HIP_ACT_NONE) vv = act_fwd_cheap(vv, a.act, sl);
-                        o[r][c] = vv;
+                    for (int r = 0; r < 16; r += 2) {  // register pairs: packed fp32 adds
+                        const buf_f32x2 m0v = {acc[0][tt][r], acc[0][tt][r + 1]}, m1v = {acc[1][tt][r], acc[1][tt][r + 1]};
+                        const buf_f32x2 m2v = {acc[2][tt][r], acc[2][tt][r + 1]}, m3v = {acc[3][tt][r], acc[3][tt][r + 1]};
+                        const buf_f32x2 s0 = m0v + m1v + m2v, s1 = m1v - m2v - m3v;
+                        float* p = S + ((wrow * 2) * 32 + mfma_row(r, lane)) * WF_BT + tt * 32 + l31;  // rows r, r + 1 are adjacent
+                        p[0] = s0[0];
+                        p[WF_BT] = s0[1];
+                        p[32 * WF_BT] = s1[0];
+                        p[33 * WF_BT] = s1[1];
                     }
+                }
             }
-            float sv = 0.f, sq = 0.f;
-#ifdef WF_ABL_NOSTORE
-            if (tile_ok && o[0][0] == 123.456f) {
-#else
-            if (tile_ok) {
-#endif
-                float* row = a.dst + ((size_t)(n * (unsigned)a.M + (unsigned)f) * (size_t)HW) + (size_t)(oh * a.W + ow);
-                if (vec2) {
-                    *reinterpret_cast<float2*>(row) = make_float2(o[0][0], o[0][1]);
-                    if (two_rows) *reinterpret_cast<float2*>(row + a.W) = make_float2(o[1][0], o[1][1]);
+            if (ph == 0) WF_STAMP(29);
+            __syncthreads();
+            if (ph == 0) WF_STAMP(30);
+            // (2) one (channel, tile) per lane: the row half, bias / activation, stores, statistics. Branch-free (stores are
+            //     masked by address) so that the four channels of a wave overlap their LDS reads, adds and stores.
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int fl = q * 8 + wid;  // wave-uniform channel of this half
+                const int f = e_m0 + ph * 32 + fl;
+                const bool f_ok = f < a.M;   // uniform
+                float sb[4][2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) sb[i][b] = S[((i * 2 + b) * 32 + fl) * WF_BT + lane];
+                float o[2][2];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    o[0][b] = sb[0][b] + sb[1][b] + sb[2][b];
+                    o[1][b] = sb[1][b] - sb[2][b] - sb[3][b];
+                }
+                if (EPI != 0) {
+                    float bv = (a.add_bias && f_ok) ? a.bias[f] : 0.f;
+                    if (bv == 1.0f) bv = 0.f;  // bcnn_add_scalar of the AVX build adds nothing for exactly 1.0f (quirk 2)
+                    const float sl = (EPI == 2 && a.act == BCNN_HIP_ACT_PRELU && a.slopes && f_ok) ? a.slopes[f] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            float vv = o[r][c];
+                            if (bv != 0.0f) vv += bv;
+                            if (EPI == 1) vv = vv * (float)(vv > 0);  // RELU as the reference's multiply (-0.0f, NaN propagate)
+                            else if (a.act != BCNN_HIP_ACT_NONE) vv = act_fwd_cheap(vv, a.act, sl);
+                            o[r][c] = vv;
+                        }
+                }
+                const int soff = f_ok ? f * HW * 4 : 0;  // wave-uniform; soffset is not range-checked,
+                const unsigned kill = f_ok ? 0u : kOOB;  // ... the voffset is: channels past M are dropped through it
+#ifndef WF_ABL_NOSTORE
+                if (!odd_w) {  // uniform; rows start 8-byte aligned and ow is even
+                    buffer_store_f32x2(buf_f32x2{o[0][0], o[0][1]}, rs_dst, (int)(o00 | kill), soff, 0);
+                    buffer_store_f32x2(buf_f32x2{o[1][0], o[1][1]}, rs_dst, (int)(o10 | kill), soff, 0);
                 } else {
-                    row[0] = o[0][0];
-                    if (two_cols) row[1] = o[0][1];
-                    if (two_rows) {
-                        row[a.W] = o[1][0];
-                        if (two_cols) row[a.W + 1] = o[1][1];
-                    }
+                    buffer_store_f32(o[0][0], rs_dst, (int)(o00 | kill), soff, 0);
+                    buffer_store_f32(o[0][1], rs_dst, (int)(o01 | kill), soff, 0);
+                    buffer_store_f32(o[1][0], rs_dst, (int)(o10 | kill), soff, 0);
+                    buffer_store_f32(o[1][1], rs_dst, (int)(o11 | kill), soff, 0);
                 }
-                if (a.stats) {
-                    sv = o[0][0]; sq = o[0][0] * o[0][0];
-                    if (two_cols) { sv += o[0][1]; sq += o[0][1] * o[0][1]; }
-                    if (two_rows) {
-                        sv += o[1][0]; sq += o[1][0] * o[1][0];
-                        if (two_cols) { sv += o[1][1]; sq += o[1][1] * o[1][1]; }
-                    }
-                }
-            }
-            if (a.stats) {  // this wave holds channel f for the workgroup's 64 tiles
-                sv = wave_sum(sv);
-                sq = wave_sum(sq);
-                if (lane == 0) {  // slot per half block; a whole block owns both and zeroes the second
-                    float* p = a.stats + ((size_t)f * (2 * a.tblocks) + 2 * tb + half) * 2;
-                    p[0] = sv; p[1] = sq;
-                    if (whole) { p[2] = 0.f; p[3] = 0.f; }
+#endif
+                if (STATS) {  // this wave holds channel f for the workgroup's 64 tiles
+                    // masked by multiplication: lanes without a tile / a second row / a second column add 0.0
+                    const float sv0 = (o[0][0] + o[0][1] * w01) * w00, sv1 = (o[1][0] + o[1][1] * w01) * w10;
+                    const float sq0 = (o[0][0] * o[0][0] + o[0][1] * o[0][1] * w01) * w00;
+                    const float sq1 = (o[1][0] * o[1][0] + o[1][1] * o[1][1] * w01) * w10;
+                    const float sv = wave_sum_dpp(sv0 + sv1), sq = wave_sum_dpp(sq0 + sq1);
+                    // slot per half block; a whole block owns both and zeroes the second (lane 63 holds the sums)
+                    const int st_soff = f_ok ? (f * (2 * a.tblocks) + 2 * e_tb + e_half) * 8 : 0;
+                    buffer_store_f32x2(buf_f32x2{sv, sq}, rs_stats, (int)(st_voff | kill), st_soff, 0);
+                    buffer_store_f32x2(buf_f32x2{0.f, 0.f}, rs_stats, (int)(st_voff2 | kill), st_soff, 0);
                 }
             }
+            // the next unit's first patches have had the first half of the epilogue to arrive
+            if (ph == 0 && has_next) finish_start();
         }
         WF_STAMP(31);
     }
@@ -464,6 +500,7 @@ static void wino_fused_run(const float* src, const float* w, float* dst, const C
     a.tblocks = (int)((a.T + WF_BT - 1) / WF_BT);
     a.act = act; a.add_bias = add_bias;
     a.src_bytes = (unsigned)((size_t)s.N * a.J * s.HW * 4);
+    a.dst_bytes = (unsigned)((size_t)s.N * a.M * s.HW * 4);
     const size_t u_floats = (size_t)16 * a.Jpad * a.Mpad;
     a.upk_bytes = (unsigned)(u_floats * 4);
     float* U = wf_scratch(u_floats);
@@ -479,9 +516,15 @@ static void wino_fused_run(const float* src, const float* w, float* dst, const C
     a.nfull = (rem > 0 && 2 * rem <= (int)grid && nblocks > (int)grid) ? nblocks - rem : nblocks;
     a.nunits = a.nfull + 2 * (nblocks - a.nfull);
     const bool plain = !a.add_bias && a.act == BCNN_HIP_ACT_NONE;
-    if (plain) wino_fused_kernel<0><<<grid, 512, 0, current_stream()>>>(a);
-    else if (a.act == BCNN_HIP_ACT_RELU) wino_fused_kernel<1><<<grid, 512, 0, current_stream()>>>(a);
-    else wino_fused_kernel<2><<<grid, 512, 0, current_stream()>>>(a);
+    a.stats_bytes = a.stats ? (unsigned)((size_t)a.M * 2 * a.tblocks * 2 * sizeof(float)) : 0u;
+    if (a.stats && !plain) {
+        fprintf(stderr, "[bcnn_hip] fused Winograd: output statistics are taken on the raw convolution output only\n");
+        abort();
+    }
+    if (a.stats) wino_fused_kernel<0, true><<<grid, 512, 0, current_stream()>>>(a);
+    else if (plain) wino_fused_kernel<0, false><<<grid, 512, 0, current_stream()>>>(a);
+    else if (a.act == BCNN_HIP_ACT_RELU) wino_fused_kernel<1, false><<<grid, 512, 0, current_stream()>>>(a);
+    else wino_fused_kernel<2, false><<<grid, 512, 0, current_stream()>>>(a);
     KERNEL_CHECK();
     if (stats) stats->splits = a.stats ? 2 * a.tblocks : 0;
 }

@@ -22,6 +22,9 @@ __device__ __forceinline__ rsrc_i4 make_rsrc(const void* p, unsigned bytes) {
 typedef float buf_f32x2 __attribute__((ext_vector_type(2)));
 __device__ float buffer_load_f32(rsrc_i4 rs, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
 __device__ buf_f32x2 buffer_load_f32x2(rsrc_i4 rs, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f32");
+// stores with an out-of-range voffset are dropped: masking by address instead of by branch
+__device__ void buffer_store_f32(float v, rsrc_i4 rs, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.store.f32");
+__device__ void buffer_store_f32x2(buf_f32x2 v, rsrc_i4 rs, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.store.v2f32");
 
 __device__ __forceinline__ unsigned lds_offset(const void* p) { return (unsigned)(size_t)(lds_void_ptr)p; }
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time one conv layer's forward / dW+dX through the C-ABI (per-class HIP-event timers).
-usage: prof_layer.py N C H W F K S P [iters]"""
+usage: [PROF_BN=1] prof_layer.py N C H W F K S P [iters]   (PROF_BN: forward is conv + batch-norm + ReLU, the ResNet form)"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -17,9 +17,13 @@ y = torch.empty((n, f, oh, ow), device=dev)
 dy = (torch.rand((n, f, oh, ow), device=dev) * 2 - 1) * 1e-2
 dx = torch.empty_like(x); dw = torch.zeros_like(wt); db = torch.zeros_like(bias)
 ws = torch.zeros(max(1, ops.conv_workspace_size(n, c, h, w, f, k, s, p, 1)), device=dev)
+bn = None
+if os.environ.get("PROF_BN") == "1":
+    Z = lambda: torch.zeros(f, device=dev)
+    bn = dict(run_mean=Z(), run_var=Z() + 1, scales=Z() + 1, saved_mean=Z(), saved_var=Z(), workspace=torch.empty_like(y))
 torch.cuda.synchronize()
 def run():
-    ops.conv_forward(x, wt, bias, y, k, s, p, 1, 2)
+    ops.conv_forward(x, wt, bias, y, k, s, p, 1, 2, bn=bn)
     ops.conv_backward(x, wt, y, dy, dx, dw, db, k, s, p, 1, 0, ws)
 run(); L.bcnn_hip_sync()
 L.bcnn_hip_profile_reset(); L.bcnn_hip_profile_enable(1)
