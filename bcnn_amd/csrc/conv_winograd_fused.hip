@@ -47,8 +47,12 @@ struct WinoFusedArgs {
     unsigned src_bytes, upk_bytes, dst_bytes, stats_bytes;
 };
 
+#ifndef WF_LATE_AFTER
+#define WF_LATE_AFTER 1  // the late half produces after this k-step (0..3) of its multiply
+#endif
+
 #ifdef WF_ABL_CLOCK
-__device__ unsigned long long g_wf_clk[8][40];
+__device__ unsigned long long g_wf_clk[8][48];
 extern "C" void bcnn_hip_debug_read_wf_clock(unsigned long long* out) {
     (void)hipDeviceSynchronize();
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wf_clk), sizeof(g_wf_clk));
@@ -212,11 +216,23 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
         // everything chunk kc contributes to the chunks after it: V of chunk kc + 1 from the patches requested a whole
         // chunk ago, the patch requests of chunk kc + 2 into the registers this frees, the U slab of chunk kc + 1
         auto produce = [&](int kc) {
+#ifdef WF_ABL_CLOCK
+            if (kc == 3) { WF_STAMP(40); dma_wait(); WF_STAMP(44); }
+#endif
 #ifndef WF_ABL_NOXFORM
             if (kc + 1 < nchunks) write_v((kc & 1) ^ 1);
+#ifdef WF_ABL_CLOCK
+            if (kc == 3) WF_STAMP(41);
+#endif
             if (kc + 2 < nchunks) load_patch(kc + 2);
+#ifdef WF_ABL_CLOCK
+            if (kc == 3) WF_STAMP(42);
+#endif
 #endif
             if (kc + 1 < nchunks) dma_u(kc + 1, (kc & 1) ^ 1);
+#ifdef WF_ABL_CLOCK
+            if (kc == 3) WF_STAMP(43);
+#endif
         };
         // 32 MFMAs on stage `cur`; the late half produces (see above) between the second and the third k-step
         auto multiply = [&](int cur, int produce_kc, bool first, int kc_stamp) {
@@ -262,7 +278,7 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (ks == 1 && produce_kc >= 0) {  // uniform
+                if (ks == WF_LATE_AFTER && produce_kc >= 0) {  // uniform
                     produce(produce_kc);
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -580,6 +596,7 @@ struct WinoDwArgs {
     unsigned x_bytes, dy_bytes;
 };
 
+template <bool ODDW>
 __global__ __launch_bounds__(512, 2) void wino_dw_fused_kernel(const WinoDwArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[2 * 2 * WD_OP];  // two stages of (dM, V): 147 KB
     const int tid = threadIdx.x, lane = tid & 63;
@@ -596,24 +613,26 @@ __global__ __launch_bounds__(512, 2) void wino_dw_fused_kernel(const WinoDwArgs 
     // this thread's transform item in every chunk: channel ch (of both the f block and the c block), tile tl
     const int tl = lane & 7, ch = wid * 8 + (lane >> 3);
     const bool f_ok = f0 + ch < a.F, c_ok = c0 + ch < a.C;
-    // tile coordinates of (tbeg + tl), advanced by 8 tiles per chunk (TW >= 8: one carry at most)
+    // tile coordinates of (tbeg + tl), advanced by 8 tiles per chunk
     unsigned t = tbeg + (unsigned)tl;
     const unsigned per_img = (unsigned)(a.TH * a.TW);
     int n = (int)(t / per_img);
     const unsigned rr = t - (unsigned)n * per_img;
     int th = (int)(rr / (unsigned)a.TW), tw = (int)(rr - (unsigned)th * (unsigned)a.TW);
 
+    constexpr bool odd_w = ODDW;
     float d[4][4], g[2][2];
     auto load_items = [&]() {
         const bool live = t < tend;
         // x patch: rows 2th-1 .. 2th+2, columns 2tw-1 .. 2tw+2 of channel c0 + ch; zero outside the image.
-        // One 16-byte buffer load per row (4-byte aligned) that never leaves the row (W is even here): from column
-        // 2tw-1 in general, from column 0 for the first tile of a row (its column -1 is padding), from column W-4
-        // for the last one (its column 2tw+2 = W is padding); the vector is shifted accordingly. A row outside the
-        // image or a channel past the block gets an out-of-range offset and comes back as zeros.
+        // One 16-byte load per row (4-byte aligned) that never leaves the row: from column 2tw-1 in general, from
+        // column 0 for the first tile of a row (its column -1 is padding), from column W-4 for the last one (its
+        // columns from W on are padding); the vector is shifted accordingly.
         const int ih0 = 2 * th - 1, iw0 = 2 * tw - 1;
-        const bool first = tw == 0, last = iw0 + 3 >= a.W;
-        const int sc = iw0 + (first ? 1 : 0) - (last ? 1 : 0);
+        // `last`: the patch's right end is past the row. Even W: column iw0 + 3 == W only; odd W: iw0 + 2 == W as well
+        // (then the load starts two columns early instead of one).
+        const bool first = tw == 0, last = iw0 + 3 >= a.W, last2 = iw0 + 2 >= a.W;
+        const int sc = iw0 + (first ? 1 : 0) - (last ? (last2 ? 2 : 1) : 0);
         const unsigned xb = (unsigned)(((n * a.C + c0 + ch) * a.H + ih0) * a.W + sc);  // elements
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -624,27 +643,44 @@ __global__ __launch_bounds__(512, 2) void wino_dw_fused_kernel(const WinoDwArgs 
             const unsigned off = rok ? xb + (unsigned)(i * a.W) : 0u;
             const WdF4 q = *reinterpret_cast<const WdF4*>(a.x + off);
             const float q0 = rok ? q.x : 0.f, q1 = rok ? q.y : 0.f, q2 = rok ? q.z : 0.f, q3 = rok ? q.w : 0.f;
-            d[i][0] = first ? 0.f : (last ? q1 : q0);
-            d[i][1] = first ? q0 : (last ? q2 : q1);
-            d[i][2] = first ? q1 : (last ? q3 : q2);
-            d[i][3] = first ? q2 : (last ? 0.f : q3);
+            if (!odd_w) {  // uniform
+                d[i][0] = first ? 0.f : (last ? q1 : q0);
+                d[i][1] = first ? q0 : (last ? q2 : q1);
+                d[i][2] = first ? q1 : (last ? q3 : q2);
+                d[i][3] = first ? q2 : (last ? 0.f : q3);
+            } else {       // the last tile of a row ends two columns past it
+                d[i][0] = first ? 0.f : (last ? (last2 ? q2 : q1) : q0);
+                d[i][1] = first ? q0 : (last ? (last2 ? q3 : q2) : q1);
+                d[i][2] = first ? q1 : (last ? (last2 ? 0.f : q3) : q2);
+                d[i][3] = first ? q2 : (last ? 0.f : q3);
+            }
         }
-        // dy block: rows 2th, 2th+1, columns 2tw, 2tw+1 of channel f0 + ch (8-byte aligned: W is even); zero outside
-        // the image / for tiles past the range
+        // dy block: rows 2th, 2th+1, columns 2tw, 2tw+1 of channel f0 + ch; zero outside the image / for tiles past the
+        // range. Even W: one 8-byte load per row; odd W: two scalar loads (column 2tw+1 == W is padding and must not be
+        // read: it is the next row's first element, or past the tensor).
         const unsigned yb = (unsigned)(((n * a.F + f0 + ch) * a.H + 2 * th) * a.W + 2 * tw);
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const bool rok = live && f_ok && 2 * th + r < a.H;
             const unsigned off = rok ? yb + (unsigned)(r * a.W) : 0u;
-            const float2 q = *reinterpret_cast<const float2*>(a.dy + off);
-            g[r][0] = rok ? q.x : 0.f;
-            g[r][1] = rok ? q.y : 0.f;
+            if (!odd_w) {
+                const float2 q = *reinterpret_cast<const float2*>(a.dy + off);
+                g[r][0] = rok ? q.x : 0.f;
+                g[r][1] = rok ? q.y : 0.f;
+            } else {
+                const bool cok = rok && 2 * tw + 1 < a.W;
+                const float q0 = a.dy[off], q1 = a.dy[cok ? off + 1 : 0u];
+                g[r][0] = rok ? q0 : 0.f;
+                g[r][1] = cok ? q1 : 0.f;
+            }
         }
     };
-    auto advance = [&]() {
+    auto advance = [&]() {  // 8 tiles on: at most two row carries (TW >= 4) and one image carry (TH >= 2)
         t += WD_KT;
         tw += WD_KT;
-        if (tw >= a.TW) { tw -= a.TW; ++th; }
+        const int rows = tw >= 2 * a.TW ? 2 : (tw >= a.TW ? 1 : 0);
+        tw -= rows * a.TW;
+        th += rows;
         if (th >= a.TH) { th -= a.TH; ++n; }
     };
     auto write_items = [&](int stage) {
@@ -811,7 +847,7 @@ static WinoDwPlan wino_dw_fused_plan(const ConvShape& s) {
     p.ok = false; p.partial_floats = 0;
     if (s.ksz != 3 || s.stride != 1 || s.pad != 1 || s.groups != 1) return p;
     const int TW = (s.W + 1) / 2, TH = (s.H + 1) / 2;
-    if (TW < WD_KT || (s.W & 1) || s.C < 32 || s.F < 32) return p;  // one carry per chunk at most; 16-byte row loads
+    if (TW < 4 || TH < 2 || s.C < 32 || s.F < 32) return p;  // the tile walk's carries; 16-byte row loads (W >= 7)
     if ((size_t)s.N * s.C * s.HW * 4 >= 0x7ffffff0ull || (size_t)s.N * s.F * s.HW * 4 >= 0x7ffffff0ull) return p;
     if (g_wd_force < 0) {
         const char* e = BCNN_EXP_ENV("BCNN_HIP_WINOGRAD_DW_FUSED");
@@ -855,7 +891,8 @@ bool conv_backward_weights_winograd_fused(const float* x, const float* dy, float
     a.x_bytes = (unsigned)((size_t)s.N * s.C * s.HW * 4);
     a.dy_bytes = (unsigned)((size_t)s.N * s.F * s.HW * 4);
     const int nob = p.fblocks * p.cblocks;
-    wino_dw_fused_kernel<<<(unsigned)(p.splits * nob), 512, 0, current_stream()>>>(a);
+    if (s.W & 1) wino_dw_fused_kernel<true><<<(unsigned)(p.splits * nob), 512, 0, current_stream()>>>(a);
+    else wino_dw_fused_kernel<false><<<(unsigned)(p.splits * nob), 512, 0, current_stream()>>>(a);
     KERNEL_CHECK();
     wino_dw_fused_finalize_kernel<<<(unsigned)(nob * 256), 256, 0, current_stream()>>>(workspace, p.splits, p.fblocks, p.cblocks,
                                                                                       s.F, s.C, dw);

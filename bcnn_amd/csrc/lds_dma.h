@@ -25,6 +25,12 @@ __device__ buf_f32x2 buffer_load_f32x2(rsrc_i4 rs, int voff, int soff, int aux) 
 // stores with an out-of-range voffset are dropped: masking by address instead of by branch
 __device__ void buffer_store_f32(float v, rsrc_i4 rs, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.store.f32");
 __device__ void buffer_store_f32x2(buf_f32x2 v, rsrc_i4 rs, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.store.v2f32");
+typedef float buf_f32x4 __attribute__((ext_vector_type(4)));
+__device__ buf_f32x4 buffer_load_f32x4(rsrc_i4 rs, int voff, int soff, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+// NOTE: there is deliberately no 16-byte buffer STORE here. hipcc 7.2 schedules a vector-ALU write of the data registers
+// directly behind a `buffer_store_dwordx4` on gfx950 without the wait states the hardware needs, and the store then sends
+// the NEW register contents for its last lanes (seen as element 0 of lanes 12-15 of every 16 replaced by the next
+// instruction's voffset). A 16-byte store has to be inline assembly that carries its own `s_nop 1`.
 
 __device__ __forceinline__ unsigned lds_offset(const void* p) { return (unsigned)(size_t)(lds_void_ptr)p; }
 
@@ -46,6 +52,9 @@ __device__ __forceinline__ void dma_row_x4(rsrc_i4 rs, unsigned lds_base, unsign
                  : "s"(lds_base), "v"(voff), "s"(rs), "s"(soff)
                  : "memory", "m0");
 }
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. every global load the wave
+// has in flight -- fatal for a pipeline that keeps operand requests flying across the barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // wait until at most N of this wave's loads are outstanding (vmcnt retires in order: the N youngest may fly)
 template <int N>

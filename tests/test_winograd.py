@@ -26,6 +26,8 @@ SHAPES = [  # n, c, h, w, f, act, bn
     (3, 40, 17, 19, 72, 0, 0),   # odd extents, channel blocks that are not full (40 of 64, 72 = 64 + 8)
     (1, 64, 32, 32, 128, 5, 0),
     (2, 40, 18, 16, 72, 2, 0),   # even width (16-byte row loads of the fused dW kernel), ragged channel blocks
+    (2, 64, 6, 8, 64, 0, 0),     # 4 tiles per row: the fused dW kernel's 8-tile step carries two rows every chunk
+    (3, 64, 10, 12, 64, 2, 1),   # 6 tiles per row, 5 rows: one or two row carries, image carries in mid-chunk
 ]
 
 

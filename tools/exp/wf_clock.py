@@ -17,11 +17,11 @@ ws = torch.zeros(max(1, ops.conv_workspace_size(n, c, h, w, f, 3, 1, 1, 1)), dev
 for _ in range(3):
     ops.conv_backward(x, wt, y, dy, dx, dw, db, 3, 1, 1, 1, 0, ws)
 L.bcnn_hip_sync()
-buf = (C.c_ulonglong * 320)()
+buf = (C.c_ulonglong * 384)()
 lib = C.CDLL(os.environ["BCNN_HIP_LIB"])
 lib.bcnn_hip_debug_read_wf_clock(buf)
 for half, name in ((0, "wave 0 (transforms first)"), (4, "wave 4 (multiplies first)")):
-    t = [buf[half * 40 + i] for i in range(40)]
+    t = [buf[half * 48 + i] for i in range(40)]
     print(name)
     print("  wait for previous epilogue readers %6d | prologue (decode, DMA, patch loads, transform) %6d | wait + barrier %6d"
           % (t[1] - t[0], t[2] - t[1], t[3] - t[2]))
@@ -39,6 +39,10 @@ for half, name in ((0, "wave 0 (transforms first)"), (4, "wave 4 (multiplies fir
 base = buf[4 + 9]
 print("all waves, chunk 3, cycles vs wave 0's head stamp: head | mfma start | k-step ends | mfma end | next head")
 for w in range(8):
-    t = [buf[w * 40 + i] for i in range(40)]
+    t = [buf[w * 48 + i] for i in range(48)]
     print("  wave %d: %5d | %5d | %s | %5d | %5d" % (w, t[13] - base, t[14] - base, " ".join("%5d" % (t[32 + k] - base) for k in range(4)),
                                                   t[15] - base, t[16] - base))
+print("produce step of chunk 3, cycles vs wave 0's head stamp: start | V written | patches requested | U DMA issued | (patches of this chunk had arrived)")
+for w in range(8):
+    t = [buf[w * 48 + i] for i in range(48)]
+    print("  wave %d: %s" % (w, " ".join("%5d" % (t[40 + k] - base) for k in (0, 1, 2, 3, 4))))
