@@ -584,7 +584,6 @@ constexpr int WD_KT = 8;                 // tiles per chunk
 constexpr int WD_ROW = WD_KT + 1;        // padded LDS row
 constexpr int WD_OP = 16 * 64 * WD_ROW;  // floats per operand and stage
 
-struct WdF4 { float x, y, z, w; } __attribute__((packed, aligned(4)));  // 16-byte load, 4-byte aligned
 
 struct WinoDwArgs {
     const float* x;    // [N][C][H][W]
@@ -613,77 +612,98 @@ __global__ __launch_bounds__(512, 2) void wino_dw_fused_kernel(const WinoDwArgs 
     // this thread's transform item in every chunk: channel ch (of both the f block and the c block), tile tl
     const int tl = lane & 7, ch = wid * 8 + (lane >> 3);
     const bool f_ok = f0 + ch < a.F, c_ok = c0 + ch < a.C;
-    // tile coordinates of (tbeg + tl), advanced by 8 tiles per chunk
+    const bool is_l = tl == 0, is_r = tl == 7;  // the lanes whose left / right neighbour tile sits in no lane of the wave
+    // tile coordinates of (tbeg + tl), advanced by 8 tiles per chunk; xo / yo = byte offsets of x[n][c0+ch][2th][2tw] and
+    // dy[n][f0+ch][2th][2tw], advanced with them (no multiplications in the loop)
     unsigned t = tbeg + (unsigned)tl;
     const unsigned per_img = (unsigned)(a.TH * a.TW);
-    int n = (int)(t / per_img);
-    const unsigned rr = t - (unsigned)n * per_img;
-    int th = (int)(rr / (unsigned)a.TW), tw = (int)(rr - (unsigned)th * (unsigned)a.TW);
+    int th, tw;
+    unsigned xo, yo;
+    {
+        const int n = (int)(t / per_img);
+        const unsigned rr = t - (unsigned)n * per_img;
+        th = (int)(rr / (unsigned)a.TW);
+        tw = (int)(rr - (unsigned)th * (unsigned)a.TW);
+        xo = (unsigned)(((n * a.C + c0 + ch) * a.H + 2 * th) * a.W + 2 * tw) * 4u;
+        yo = (unsigned)(((n * a.F + f0 + ch) * a.H + 2 * th) * a.W + 2 * tw) * 4u;
+    }
+    const unsigned W4 = (unsigned)a.W * 4u;
+    const unsigned step_row = (unsigned)(2 * a.W - 2 * a.TW) * 4u;                      // one row carry
+    const unsigned step_img_x = (unsigned)(a.C * a.H * a.W - 2 * a.W * a.TH) * 4u;      // one image carry
+    const unsigned step_img_y = (unsigned)(a.F * a.H * a.W - 2 * a.W * a.TH) * 4u;
+    const rsrc_i4 rs_x = make_rsrc(a.x, a.x_bytes), rs_y = make_rsrc(a.dy, a.dy_bytes);
 
     constexpr bool odd_w = ODDW;
-    float d[4][4], g[2][2];
+    // x patch rows as requested: the pair of columns (2tw, 2tw+1), the left neighbour column (lanes tl == 0 only) and the
+    // right one (lanes tl == 7 only); dy block rows as pairs
+    buf_f32x2 xm[4], gy[2];
+    float xl[4], xr[4];
+    bool sel_l = false, sel_r = false, pair_y_ok = true;
     auto load_items = [&]() {
+        // Rows 2th-1 .. 2th+2, columns 2tw-1 .. 2tw+2 of channel c0 + ch, zero outside the image: every load is a raw
+        // buffer load whose voffset is out of range (-> 0.0, no memory access) when the row, the channel or the tile
+        // does not exist; a pair never leaves its row (for odd W its second element can, and is then masked). The
+        // neighbour columns of tiles 1..6 of the 8-tile group are the neighbouring lanes' pairs (DPP row shifts in
+        // write_items); only the group's first / last lane fetch theirs.
         const bool live = t < tend;
-        // x patch: rows 2th-1 .. 2th+2, columns 2tw-1 .. 2tw+2 of channel c0 + ch; zero outside the image.
-        // One 16-byte load per row (4-byte aligned) that never leaves the row: from column 2tw-1 in general, from
-        // column 0 for the first tile of a row (its column -1 is padding), from column W-4 for the last one (its
-        // columns from W on are padding); the vector is shifted accordingly.
-        const int ih0 = 2 * th - 1, iw0 = 2 * tw - 1;
-        // `last`: the patch's right end is past the row. Even W: column iw0 + 3 == W only; odd W: iw0 + 2 == W as well
-        // (then the load starts two columns early instead of one).
-        const bool first = tw == 0, last = iw0 + 3 >= a.W, last2 = iw0 + 2 >= a.W;
-        const int sc = iw0 + (first ? 1 : 0) - (last ? (last2 ? 2 : 1) : 0);
-        const unsigned xb = (unsigned)(((n * a.C + c0 + ch) * a.H + ih0) * a.W + sc);  // elements
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            // Global (not buffer) loads: hipcc 7.2 lowers element reads of __builtin_amdgcn_raw_buffer_load_b64 / _b128
-            // to ONE dword load replicated (tools/micro/bufload_probe.hip). A row outside the image reads the tensor's
-            // first elements instead and is zeroed afterwards -- no exec branches.
-            const bool rok = c_ok && live && (unsigned)(ih0 + i) < (unsigned)a.H;
-            const unsigned off = rok ? xb + (unsigned)(i * a.W) : 0u;
-            const WdF4 q = *reinterpret_cast<const WdF4*>(a.x + off);
-            const float q0 = rok ? q.x : 0.f, q1 = rok ? q.y : 0.f, q2 = rok ? q.z : 0.f, q3 = rok ? q.w : 0.f;
-            if (!odd_w) {  // uniform
-                d[i][0] = first ? 0.f : (last ? q1 : q0);
-                d[i][1] = first ? q0 : (last ? q2 : q1);
-                d[i][2] = first ? q1 : (last ? q3 : q2);
-                d[i][3] = first ? q2 : (last ? 0.f : q3);
-            } else {       // the last tile of a row ends two columns past it
-                d[i][0] = first ? 0.f : (last ? (last2 ? q2 : q1) : q0);
-                d[i][1] = first ? q0 : (last ? (last2 ? q3 : q2) : q1);
-                d[i][2] = first ? q1 : (last ? (last2 ? 0.f : q3) : q2);
-                d[i][3] = first ? q2 : (last ? 0.f : q3);
-            }
-        }
-        // dy block: rows 2th, 2th+1, columns 2tw, 2tw+1 of channel f0 + ch; zero outside the image / for tiles past the
-        // range. Even W: one 8-byte load per row; odd W: two scalar loads (column 2tw+1 == W is padding and must not be
-        // read: it is the next row's first element, or past the tensor).
-        const unsigned yb = (unsigned)(((n * a.F + f0 + ch) * a.H + 2 * th) * a.W + 2 * tw);
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const bool rok = live && f_ok && 2 * th + r < a.H;
-            const unsigned off = rok ? yb + (unsigned)(r * a.W) : 0u;
-            if (!odd_w) {
-                const float2 q = *reinterpret_cast<const float2*>(a.dy + off);
-                g[r][0] = rok ? q.x : 0.f;
-                g[r][1] = rok ? q.y : 0.f;
-            } else {
-                const bool cok = rok && 2 * tw + 1 < a.W;
-                const float q0 = a.dy[off], q1 = a.dy[cok ? off + 1 : 0u];
-                g[r][0] = rok ? q0 : 0.f;
-                g[r][1] = cok ? q1 : 0.f;
-            }
-        }
+        const bool x_ok = live && c_ok, y_ok = live && f_ok;
+        const bool r0 = th > 0, r2 = 2 * th + 1 < a.H, r3 = 2 * th + 2 < a.H;
+        const bool has_l = tw > 0, has_r = tw + 1 < a.TW;
+        sel_l = !is_l && has_l;
+        sel_r = !is_r && has_r;
+        if (odd_w) pair_y_ok = 2 * tw + 1 < a.W;
+        const bool el = x_ok && is_l && has_l, er = x_ok && is_r && has_r;
+        const unsigned up = xo - W4;
+        xm[0] = buffer_load_f32x2(rs_x, (int)((x_ok && r0) ? up : kOOB), 0, 0);
+        xm[1] = buffer_load_f32x2(rs_x, (int)(x_ok ? xo : kOOB), 0, 0);
+        xm[2] = buffer_load_f32x2(rs_x, (int)((x_ok && r2) ? xo : kOOB), (int)W4, 0);
+        xm[3] = buffer_load_f32x2(rs_x, (int)((x_ok && r3) ? xo : kOOB), (int)(2u * W4), 0);
+        xl[0] = buffer_load_f32(rs_x, (int)((el && r0) ? up - 4u : kOOB), 0, 0);
+        xl[1] = buffer_load_f32(rs_x, (int)(el ? xo - 4u : kOOB), 0, 0);
+        xl[2] = buffer_load_f32(rs_x, (int)((el && r2) ? xo - 4u : kOOB), (int)W4, 0);
+        xl[3] = buffer_load_f32(rs_x, (int)((el && r3) ? xo - 4u : kOOB), (int)(2u * W4), 0);
+        xr[0] = buffer_load_f32(rs_x, (int)((er && r0) ? up + 8u : kOOB), 0, 0);
+        xr[1] = buffer_load_f32(rs_x, (int)(er ? xo + 8u : kOOB), 0, 0);
+        xr[2] = buffer_load_f32(rs_x, (int)((er && r2) ? xo + 8u : kOOB), (int)W4, 0);
+        xr[3] = buffer_load_f32(rs_x, (int)((er && r3) ? xo + 8u : kOOB), (int)(2u * W4), 0);
+        // dy block: rows 2th, 2th+1, columns 2tw, 2tw+1 of channel f0 + ch
+        gy[0] = buffer_load_f32x2(rs_y, (int)(y_ok ? yo : kOOB), 0, 0);
+        gy[1] = buffer_load_f32x2(rs_y, (int)((y_ok && r2) ? yo : kOOB), (int)W4, 0);
     };
     auto advance = [&]() {  // 8 tiles on: at most two row carries (TW >= 4) and one image carry (TH >= 2)
         t += WD_KT;
         tw += WD_KT;
-        const int rows = tw >= 2 * a.TW ? 2 : (tw >= a.TW ? 1 : 0);
+        const bool c1 = tw >= a.TW, c2 = tw >= 2 * a.TW;
+        const int rows = (c1 ? 1 : 0) + (c2 ? 1 : 0);
         tw -= rows * a.TW;
         th += rows;
-        if (th >= a.TH) { th -= a.TH; ++n; }
+        const bool ci = th >= a.TH;
+        if (ci) th -= a.TH;
+        const unsigned d = 64u + (c1 ? step_row : 0u) + (c2 ? step_row : 0u);
+        xo += d + (ci ? step_img_x : 0u);
+        yo += d + (ci ? step_img_y : 0u);
+    };
+    float d[4][4], g[2][2];
+    auto assemble = [&]() {  // the requested registers -> the 4 x 4 patch and the 2 x 2 dy block
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float m0 = xm[i][0], m1 = xm[i][1];
+            if (odd_w) m1 = pair_y_ok ? m1 : 0.f;
+            const float fromleft = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m1), 0x111 /* row_shr:1 */, 0xf, 0xf, false));
+            const float fromright = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m0), 0x101 /* row_shl:1 */, 0xf, 0xf, false));
+            d[i][0] = sel_l ? fromleft : xl[i];
+            d[i][1] = m0;
+            d[i][2] = m1;
+            d[i][3] = sel_r ? fromright : xr[i];
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            g[r][0] = gy[r][0];
+            g[r][1] = odd_w ? (pair_y_ok ? gy[r][1] : 0.f) : gy[r][1];
+        }
     };
     auto write_items = [&](int stage) {
+        assemble();
         float* pm = lds + stage * 2 * WD_OP + ch * WD_ROW + tl;
         float* pv = pm + WD_OP;
         // dM = A g A^T, A = [1 0; 1 1; 1 -1; 0 -1]
