@@ -466,19 +466,26 @@ __global__ __launch_bounds__(512, 2) void wino_bf16_kernel(const WinoFusedArgs a
     const int nchunks = a.Jpad / WB_KC;
     const bool odd_w = (a.W & 1) != 0;
 
-    for (int unit = blockIdx.x; unit < a.nunits; unit += gridDim.x) {
-        const bool whole = unit < a.nfull;
+    // per-unit state: of the unit being multiplied and, from the end of its K loop on, of the NEXT unit (whose first
+    // patches are requested before the epilogue of the current one)
+    bool whole = false, tile_ok = false, pad_l = false, pad_r = false;
+    int m0 = 0, tb = 0, half = 0, th = 0, tw = 0;
+    unsigned n = 0;
+    unsigned voff[4], voff_edge[4];
+    auto decode = [&](int unit) {
+        whole = unit < a.nfull;
         const int blk = whole ? unit : a.nfull + ((unit - a.nfull) >> 1);
-        const int half = whole ? 0 : ((unit - a.nfull) & 1);
-        const int mb = blk % a.mblocks, tb = blk / a.mblocks;
-        const int m0 = mb * WF_BF;
+        half = whole ? 0 : ((unit - a.nfull) & 1);
+        const int mb = blk % a.mblocks;
+        tb = blk / a.mblocks;
+        m0 = mb * WF_BF;
         const unsigned t = (unsigned)tb * WF_BT + (unsigned)(half * 32) + (unsigned)lane;
-        const bool tile_ok = t < a.T && (whole || lane < 32);
+        tile_ok = t < a.T && (whole || lane < 32);
         const bool addr_ok = t < a.T;  // lanes 32-63 of a half block load their (real) tiles too (neighbour columns)
-        const unsigned n = addr_ok ? t / per_img : 0u;
+        n = addr_ok ? t / per_img : 0u;
         const unsigned rr = addr_ok ? t - n * per_img : 0u;
-        const int th = (int)(rr / (unsigned)a.TW), tw = (int)(rr - (unsigned)th * (unsigned)a.TW);
-        unsigned voff[4], voff_edge[4];
+        th = (int)(rr / (unsigned)a.TW);
+        tw = (int)(rr - (unsigned)th * (unsigned)a.TW);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int ih = 2 * th - 1 + i;
@@ -487,55 +494,66 @@ __global__ __launch_bounds__(512, 2) void wino_bf16_kernel(const WinoFusedArgs a
             voff[i] = row_ok ? row + (unsigned)(8 * tw) : kOOB;
             const bool want_l = lane == 0 && tw > 0, want_r = lane == 63 && tw + 1 < a.TW;
             voff_edge[i] = (row_ok && (want_l || want_r)) ? row + (unsigned)(want_l ? 8 * tw - 4 : 8 * tw + 8) : kOOB;
+#ifdef WB_ABL_LOADS_OOB  // timing experiment: no patch load touches memory
+            voff[i] = kOOB; voff_edge[i] = kOOB;
+#endif
         }
-        const bool pad_l = tw == 0, pad_r = tw + 1 == a.TW;
-
-        // raw patches of this wave's two channels: per row the pair (columns 2tw, 2tw+1) and the neighbour column that
-        // lanes 0 / 63 fetch themselves
-        buf_f32x2 pm[2][4];
-        float pe[2][4];
-        auto load_patches = [&](int kc, unsigned kill) {  // kill = kOOB: request nothing (past the last chunk)
+        pad_l = tw == 0;
+        pad_r = tw + 1 == a.TW;
+    };
+    // raw patches of this wave's two channels: per row the pair (columns 2tw, 2tw+1) and the neighbour column that
+    // lanes 0 / 63 fetch themselves
+    buf_f32x2 pm[2][4];
+    float pe[2][4];
+    auto load_patches = [&](int kc, unsigned kill) {  // kill = kOOB: request nothing (past the last chunk)
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const unsigned soff = (unsigned)(kc * WB_KC + 2 * wid + c) * (unsigned)HW * 4u;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    pm[c][i] = buffer_load_f32x2(rs_src, (int)(voff[i] | kill), (int)soff, 0);
-                    pe[c][i] = buffer_load_f32(rs_src, (int)(voff_edge[i] | kill), (int)soff, 0);
-                }
-            }
-        };
-        auto transform = [&](int c, float (&v)[16]) {  // B^T d B of channel c of the pair
-            float d[4][4];
+        for (int c = 0; c < 2; ++c) {
+            const unsigned soff = (unsigned)(kc * WB_KC + 2 * wid + c) * (unsigned)HW * 4u;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int e = __builtin_bit_cast(int, pe[c][i]);
-                float m1 = pm[c][i][1];
-                if (odd_w) m1 = pad_r ? 0.f : m1;  // uniform
-                const int l = __builtin_amdgcn_update_dpp(e, __builtin_bit_cast(int, m1), 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-                const int r = __builtin_amdgcn_update_dpp(e, __builtin_bit_cast(int, pm[c][i][0]), 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-                d[i][0] = pad_l ? 0.f : __builtin_bit_cast(float, l);
-                d[i][1] = pm[c][i][0];
-                d[i][2] = m1;
-                d[i][3] = pad_r ? 0.f : __builtin_bit_cast(float, r);
+                pm[c][i] = buffer_load_f32x2(rs_src, (int)(voff[i] | kill), (int)soff, 0);
+                pe[c][i] = buffer_load_f32(rs_src, (int)(voff_edge[i] | kill), (int)soff, 0);
             }
-            float tt[4][4];
+        }
+    };
+    auto transform = [&](int c, float (&v)[16]) {  // B^T d B of channel c of the pair
+        float d[4][4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                tt[0][j] = d[0][j] - d[2][j];
-                tt[1][j] = d[1][j] + d[2][j];
-                tt[2][j] = d[2][j] - d[1][j];
-                tt[3][j] = d[1][j] - d[3][j];
-            }
+        for (int i = 0; i < 4; ++i) {
+            const int e = __builtin_bit_cast(int, pe[c][i]);
+            float m1 = pm[c][i][1];
+            if (odd_w) m1 = pad_r ? 0.f : m1;  // uniform
+            const int l = __builtin_amdgcn_update_dpp(e, __builtin_bit_cast(int, m1), 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+            const int r = __builtin_amdgcn_update_dpp(e, __builtin_bit_cast(int, pm[c][i][0]), 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+            d[i][0] = pad_l ? 0.f : __builtin_bit_cast(float, l);
+            d[i][1] = pm[c][i][0];
+            d[i][2] = m1;
+            d[i][3] = pad_r ? 0.f : __builtin_bit_cast(float, r);
+        }
+        float tt[4][4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                v[4 * i + 0] = tt[i][0] - tt[i][2];
-                v[4 * i + 1] = tt[i][1] + tt[i][2];
-                v[4 * i + 2] = tt[i][2] - tt[i][1];
-                v[4 * i + 3] = tt[i][1] - tt[i][3];
-            }
-        };
+        for (int j = 0; j < 4; ++j) {
+            tt[0][j] = d[0][j] - d[2][j];
+            tt[1][j] = d[1][j] + d[2][j];
+            tt[2][j] = d[2][j] - d[1][j];
+            tt[3][j] = d[1][j] - d[3][j];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[4 * i + 0] = tt[i][0] - tt[i][2];
+            v[4 * i + 1] = tt[i][1] + tt[i][2];
+            v[4 * i + 2] = tt[i][2] - tt[i][1];
+            v[4 * i + 3] = tt[i][1] - tt[i][3];
+        }
+    };
 
+    decode(blockIdx.x);
+    load_patches(0, 0u);
+    for (int unit = blockIdx.x; unit < a.nunits; unit += gridDim.x) {
+#ifdef WF_ABL_CLOCK
+        const bool stamp_on = blockIdx.x == 37 && unit == (int)blockIdx.x + (int)gridDim.x;
+#endif
+        WF_STAMP(0);
         f32x16 acc[4][2];  // not cleared: the first MFMA of chunk 0 multiplies onto a literal zero
         // U operands of this wave: lane (channel fh*32 + l31, k group lhi) reads 8 consecutive k of one part: 16 bytes
         const unsigned u_voff = ((unsigned)lhi * (unsigned)a.Mpad + (unsigned)(m0 + fh * 32 + l31)) * 16u;
@@ -544,6 +562,7 @@ __global__ __launch_bounds__(512, 2) void wino_bf16_kernel(const WinoFusedArgs a
         load_patches(0, 0u);
         for (int kc = 0; kc < nchunks; ++kc) {
             // ---- phase A ---------------------------------------------------------------------------------
+            if (kc < 6) WF_STAMP(4 + 4 * kc);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -555,6 +574,7 @@ __global__ __launch_bounds__(512, 2) void wino_bf16_kernel(const WinoFusedArgs a
                 float v0[16], v1[16];
                 transform(0, v0);
                 transform(1, v1);
+                if (NP == 2) load_patches(kc + 1, kc + 1 < nchunks ? 0u : kOOB);  // the registers are free again
                 unsigned* vw = ldsw + wid * 64 + lane;
 #pragma unroll
                 for (int xi = 0; xi < 16; ++xi) {
@@ -570,8 +590,10 @@ __global__ __launch_bounds__(512, 2) void wino_bf16_kernel(const WinoFusedArgs a
                     }
                 }
             }
-            load_patches(kc + 1, kc + 1 < nchunks ? 0u : kOOB);
+            if (NP != 2) load_patches(kc + 1, kc + 1 < nchunks ? 0u : kOOB);  // (three parts: too few registers to go earlier)
+            if (kc < 6) WF_STAMP(5 + 4 * kc);
             lds_barrier();
+            if (kc < 6) WF_STAMP(6 + 4 * kc);
             // ---- phase B ---------------------------------------------------------------------------------
             const unsigned* vr = ldsw + (4 * lhi) * 64 + l31;
 #pragma unroll
@@ -604,10 +626,12 @@ __global__ __launch_bounds__(512, 2) void wino_bf16_kernel(const WinoFusedArgs a
                     acc[j][tt] = c;
                 }
             }
+            if (kc < 6) WF_STAMP(7 + 4 * kc);
             lds_barrier();  // every wave is done with V (the next phase A, or the epilogue's S, overwrites it)
         }
 
-        // ---- epilogue (as in wino_fused_kernel; S in the V space) ------------------------------------------
+        // ---- epilogue (as in wino_fused_kernel; S in the V space); the next unit's first patches fly under it ------
+        WF_STAMP(28);
         const int oh = 2 * th, ow = 2 * tw;
         const bool two_cols = ow + 1 < a.W, two_rows = oh + 1 < a.H;
         const unsigned o00 = tile_ok ? (n * (unsigned)a.M * (unsigned)HW + (unsigned)(oh * a.W + ow)) * 4u : kOOB;
@@ -615,6 +639,12 @@ __global__ __launch_bounds__(512, 2) void wino_bf16_kernel(const WinoFusedArgs a
         const unsigned o01 = two_cols ? o00 + 4u : kOOB, o11 = two_cols ? o10 + 4u : kOOB;
         const float w00 = tile_ok ? 1.f : 0.f, w10 = (tile_ok && two_rows) ? 1.f : 0.f, w01 = two_cols ? 1.f : 0.f;
         const unsigned st_voff = lane == 63 ? 0u : kOOB, st_voff2 = (lane == 63 && whole) ? 8u : kOOB;
+        const bool e_whole = whole;
+        const int e_m0 = m0, e_tb = tb, e_half = half;
+        if (unit + (int)gridDim.x < a.nunits) {
+            decode(unit + (int)gridDim.x);
+            load_patches(0, 0u);
+        }
         float* const S = lds;  // [4 rows of positions][2][32 channels][64 tiles]
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph) {
@@ -622,7 +652,7 @@ __global__ __launch_bounds__(512, 2) void wino_bf16_kernel(const WinoFusedArgs a
             if (fh == ph) {
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt) {
-                    if (tt == 1 && !whole) break;
+                    if (tt == 1 && !e_whole) break;
 #pragma unroll
                     for (int r = 0; r < 16; r += 2) {
                         const buf_f32x2 m0v = {acc[0][tt][r], acc[0][tt][r + 1]}, m1v = {acc[1][tt][r], acc[1][tt][r + 1]};
@@ -640,7 +670,7 @@ __global__ __launch_bounds__(512, 2) void wino_bf16_kernel(const WinoFusedArgs a
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int fl = q * 8 + wid;
-                const int f = m0 + ph * 32 + fl;
+                const int f = e_m0 + ph * 32 + fl;
                 const bool f_ok = f < a.M;
                 float sb[4][2];
 #pragma unroll
@@ -684,12 +714,13 @@ __global__ __launch_bounds__(512, 2) void wino_bf16_kernel(const WinoFusedArgs a
                     const float sq0 = (o[0][0] * o[0][0] + o[0][1] * o[0][1] * w01) * w00;
                     const float sq1 = (o[1][0] * o[1][0] + o[1][1] * o[1][1] * w01) * w10;
                     const float sv = wave_sum_dpp(sv0 + sv1), sq = wave_sum_dpp(sq0 + sq1);
-                    const int st_soff = f_ok ? (f * (2 * a.tblocks) + 2 * tb + half) * 8 : 0;
+                    const int st_soff = f_ok ? (f * (2 * a.tblocks) + 2 * e_tb + e_half) * 8 : 0;
                     buffer_store_f32x2(buf_f32x2{sv, sq}, rs_stats, (int)(st_voff | kill), st_soff, 0);
                     buffer_store_f32x2(buf_f32x2{0.f, 0.f}, rs_stats, (int)(st_voff2 | kill), st_soff, 0);
                 }
             }
         }
+        WF_STAMP(31);
         lds_barrier();  // S has been read: the next unit's V may be written
     }
 }
