@@ -421,6 +421,99 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
     }
 }
 
+// Output transform + stores of one unit from the accumulators (wave (wrow, fh) holds row wrow of the 4 x 4 position matrix
+// for 32 of the 64 channels): the column half on the registers, S[4][2][32][64] through LDS in two halves of 32
+// channels, then one (channel, tile) per lane for the row half, bias / activation, masked raw buffer stores and the
+// batch-norm statistics -- the epilogue of wino_fused_kernel as a function (used by the split-bf16 kernels).
+template <int EPI, bool STATS>
+__device__ __forceinline__ void wino_store_unit(const WinoFusedArgs& a, f32x16 (&acc)[4][2], float* S, rsrc_i4 rs_dst, rsrc_i4 rs_stats,
+                                                int wid, int lane, bool e_whole, bool tile_ok, unsigned n, int th, int tw,
+                                                int e_m0, int e_tb, int e_half) {
+    const int l31 = lane & 31, wrow = wid >> 1, fh = wid & 1, HW = a.H * a.W;
+    const bool odd_w = (a.W & 1) != 0;
+    const int oh = 2 * th, ow = 2 * tw;
+    const bool two_cols = ow + 1 < a.W, two_rows = oh + 1 < a.H;
+    const unsigned o00 = tile_ok ? (n * (unsigned)a.M * (unsigned)HW + (unsigned)(oh * a.W + ow)) * 4u : kOOB;
+    const unsigned o10 = (tile_ok && two_rows) ? o00 + (unsigned)a.W * 4u : kOOB;
+    const unsigned o01 = two_cols ? o00 + 4u : kOOB, o11 = two_cols ? o10 + 4u : kOOB;
+    const float w00 = tile_ok ? 1.f : 0.f, w10 = (tile_ok && two_rows) ? 1.f : 0.f, w01 = two_cols ? 1.f : 0.f;
+    const unsigned st_voff = lane == 63 ? 0u : kOOB, st_voff2 = (lane == 63 && e_whole) ? 8u : kOOB;
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph) {
+        if (ph == 1) lds_barrier();
+        if (fh == ph) {
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                if (tt == 1 && !e_whole) break;
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const buf_f32x2 m0v = {acc[0][tt][r], acc[0][tt][r + 1]}, m1v = {acc[1][tt][r], acc[1][tt][r + 1]};
+                    const buf_f32x2 m2v = {acc[2][tt][r], acc[2][tt][r + 1]}, m3v = {acc[3][tt][r], acc[3][tt][r + 1]};
+                    const buf_f32x2 s0 = m0v + m1v + m2v, s1 = m1v - m2v - m3v;
+                    float* p = S + ((wrow * 2) * 32 + mfma_row(r, lane)) * WF_BT + tt * 32 + l31;
+                    p[0] = s0[0];
+                    p[WF_BT] = s0[1];
+                    p[32 * WF_BT] = s1[0];
+                    p[33 * WF_BT] = s1[1];
+                }
+            }
+        }
+        lds_barrier();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int fl = q * 8 + wid;
+            const int f = e_m0 + ph * 32 + fl;
+            const bool f_ok = f < a.M;
+            float sb[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) sb[i][b] = S[((i * 2 + b) * 32 + fl) * WF_BT + lane];
+            float o[2][2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                o[0][b] = sb[0][b] + sb[1][b] + sb[2][b];
+                o[1][b] = sb[1][b] - sb[2][b] - sb[3][b];
+            }
+            if (EPI != 0) {
+                float bv = (a.add_bias && f_ok) ? a.bias[f] : 0.f;
+                if (bv == 1.0f) bv = 0.f;  // quirk 2
+                const float sl = (EPI == 2 && a.act == BCNN_HIP_ACT_PRELU && a.slopes && f_ok) ? a.slopes[f] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        float vv = o[r][c];
+                        if (bv != 0.0f) vv += bv;
+                        if (EPI == 1) vv = vv * (float)(vv > 0);
+                        else if (a.act != BCNN_HIP_ACT_NONE) vv = act_fwd_cheap(vv, a.act, sl);
+                        o[r][c] = vv;
+                    }
+            }
+            const int soff = f_ok ? f * HW * 4 : 0;
+            const unsigned kill = f_ok ? 0u : kOOB;
+            if (!odd_w) {
+                buffer_store_f32x2(buf_f32x2{o[0][0], o[0][1]}, rs_dst, (int)(o00 | kill), soff, 0);
+                buffer_store_f32x2(buf_f32x2{o[1][0], o[1][1]}, rs_dst, (int)(o10 | kill), soff, 0);
+            } else {
+                buffer_store_f32(o[0][0], rs_dst, (int)(o00 | kill), soff, 0);
+                buffer_store_f32(o[0][1], rs_dst, (int)(o01 | kill), soff, 0);
+                buffer_store_f32(o[1][0], rs_dst, (int)(o10 | kill), soff, 0);
+                buffer_store_f32(o[1][1], rs_dst, (int)(o11 | kill), soff, 0);
+            }
+            if (STATS) {
+                const float sv0 = (o[0][0] + o[0][1] * w01) * w00, sv1 = (o[1][0] + o[1][1] * w01) * w10;
+                const float sq0 = (o[0][0] * o[0][0] + o[0][1] * o[0][1] * w01) * w00;
+                const float sq1 = (o[1][0] * o[1][0] + o[1][1] * o[1][1] * w01) * w10;
+                const float sv = wave_sum_dpp(sv0 + sv1), sq = wave_sum_dpp(sq0 + sq1);
+                const int st_soff = f_ok ? (f * (2 * a.tblocks) + 2 * e_tb + e_half) * 8 : 0;
+                buffer_store_f32x2(buf_f32x2{sv, sq}, rs_stats, (int)(st_voff | kill), st_soff, 0);
+                buffer_store_f32x2(buf_f32x2{0.f, 0.f}, rs_stats, (int)(st_voff2 | kill), st_soff, 0);
+            }
+        }
+    }
+}
+
 // =============================================================================================================
 // The same fused forward / dX algorithm on the bf16 matrix pipe with fp32-equivalent accuracy ("split" arithmetic):
 // every fp32 operand is the sum of NP bf16 parts (round to nearest: x = x0 + x1 [+ x2], |x - sum| <= 2^-17 |x| for two
@@ -630,95 +723,17 @@ __global__ __launch_bounds__(512, 2) void wino_bf16_kernel(const WinoFusedArgs a
             lds_barrier();  // every wave is done with V (the next phase A, or the epilogue's S, overwrites it)
         }
 
-        // ---- epilogue (as in wino_fused_kernel; S in the V space); the next unit's first patches fly under it ------
+        // ---- epilogue (S in the V space); the next unit's first patches fly under it ------------------------------
         WF_STAMP(28);
-        const int oh = 2 * th, ow = 2 * tw;
-        const bool two_cols = ow + 1 < a.W, two_rows = oh + 1 < a.H;
-        const unsigned o00 = tile_ok ? (n * (unsigned)a.M * (unsigned)HW + (unsigned)(oh * a.W + ow)) * 4u : kOOB;
-        const unsigned o10 = (tile_ok && two_rows) ? o00 + (unsigned)a.W * 4u : kOOB;
-        const unsigned o01 = two_cols ? o00 + 4u : kOOB, o11 = two_cols ? o10 + 4u : kOOB;
-        const float w00 = tile_ok ? 1.f : 0.f, w10 = (tile_ok && two_rows) ? 1.f : 0.f, w01 = two_cols ? 1.f : 0.f;
-        const unsigned st_voff = lane == 63 ? 0u : kOOB, st_voff2 = (lane == 63 && whole) ? 8u : kOOB;
-        const bool e_whole = whole;
-        const int e_m0 = m0, e_tb = tb, e_half = half;
-        if (unit + (int)gridDim.x < a.nunits) {
-            decode(unit + (int)gridDim.x);
-            load_patches(0, 0u);
-        }
-        float* const S = lds;  // [4 rows of positions][2][32 channels][64 tiles]
-#pragma unroll
-        for (int ph = 0; ph < 2; ++ph) {
-            if (ph == 1) lds_barrier();
-            if (fh == ph) {
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
-                    if (tt == 1 && !e_whole) break;
-#pragma unroll
-                    for (int r = 0; r < 16; r += 2) {
-                        const buf_f32x2 m0v = {acc[0][tt][r], acc[0][tt][r + 1]}, m1v = {acc[1][tt][r], acc[1][tt][r + 1]};
-                        const buf_f32x2 m2v = {acc[2][tt][r], acc[2][tt][r + 1]}, m3v = {acc[3][tt][r], acc[3][tt][r + 1]};
-                        const buf_f32x2 s0 = m0v + m1v + m2v, s1 = m1v - m2v - m3v;
-                        float* p = S + ((wrow * 2) * 32 + mfma_row(r, lane)) * WF_BT + tt * 32 + l31;
-                        p[0] = s0[0];
-                        p[WF_BT] = s0[1];
-                        p[32 * WF_BT] = s1[0];
-                        p[33 * WF_BT] = s1[1];
-                    }
-                }
+        {
+            const bool e_whole = whole, e_tile_ok = tile_ok;
+            const int e_m0 = m0, e_tb = tb, e_half = half, e_th = th, e_tw = tw;
+            const unsigned e_n = n;
+            if (unit + (int)gridDim.x < a.nunits) {
+                decode(unit + (int)gridDim.x);
+                load_patches(0, 0u);
             }
-            lds_barrier();
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int fl = q * 8 + wid;
-                const int f = e_m0 + ph * 32 + fl;
-                const bool f_ok = f < a.M;
-                float sb[4][2];
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int b = 0; b < 2; ++b) sb[i][b] = S[((i * 2 + b) * 32 + fl) * WF_BT + lane];
-                float o[2][2];
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    o[0][b] = sb[0][b] + sb[1][b] + sb[2][b];
-                    o[1][b] = sb[1][b] - sb[2][b] - sb[3][b];
-                }
-                if (EPI != 0) {
-                    float bv = (a.add_bias && f_ok) ? a.bias[f] : 0.f;
-                    if (bv == 1.0f) bv = 0.f;  // quirk 2
-                    const float sl = (EPI == 2 && a.act == BCNN_HIP_ACT_PRELU && a.slopes && f_ok) ? a.slopes[f] : 0.f;
-#pragma unroll
-                    for (int r = 0; r < 2; ++r)
-#pragma unroll
-                        for (int c = 0; c < 2; ++c) {
-                            float vv = o[r][c];
-                            if (bv != 0.0f) vv += bv;
-                            if (EPI == 1) vv = vv * (float)(vv > 0);
-                            else if (a.act != BCNN_HIP_ACT_NONE) vv = act_fwd_cheap(vv, a.act, sl);
-                            o[r][c] = vv;
-                        }
-                }
-                const int soff = f_ok ? f * HW * 4 : 0;
-                const unsigned kill = f_ok ? 0u : kOOB;
-                if (!odd_w) {
-                    buffer_store_f32x2(buf_f32x2{o[0][0], o[0][1]}, rs_dst, (int)(o00 | kill), soff, 0);
-                    buffer_store_f32x2(buf_f32x2{o[1][0], o[1][1]}, rs_dst, (int)(o10 | kill), soff, 0);
-                } else {
-                    buffer_store_f32(o[0][0], rs_dst, (int)(o00 | kill), soff, 0);
-                    buffer_store_f32(o[0][1], rs_dst, (int)(o01 | kill), soff, 0);
-                    buffer_store_f32(o[1][0], rs_dst, (int)(o10 | kill), soff, 0);
-                    buffer_store_f32(o[1][1], rs_dst, (int)(o11 | kill), soff, 0);
-                }
-                if (STATS) {
-                    const float sv0 = (o[0][0] + o[0][1] * w01) * w00, sv1 = (o[1][0] + o[1][1] * w01) * w10;
-                    const float sq0 = (o[0][0] * o[0][0] + o[0][1] * o[0][1] * w01) * w00;
-                    const float sq1 = (o[1][0] * o[1][0] + o[1][1] * o[1][1] * w01) * w10;
-                    const float sv = wave_sum_dpp(sv0 + sv1), sq = wave_sum_dpp(sq0 + sq1);
-                    const int st_soff = f_ok ? (f * (2 * a.tblocks) + 2 * e_tb + e_half) * 8 : 0;
-                    buffer_store_f32x2(buf_f32x2{sv, sq}, rs_stats, (int)(st_voff | kill), st_soff, 0);
-                    buffer_store_f32x2(buf_f32x2{0.f, 0.f}, rs_stats, (int)(st_voff2 | kill), st_soff, 0);
-                }
-            }
+            wino_store_unit<EPI, STATS>(a, acc, lds, rs_dst, rs_stats, wid, lane, e_whole, e_tile_ok, e_n, e_th, e_tw, e_m0, e_tb, e_half);
         }
         WF_STAMP(31);
         lds_barrier();  // S has been read: the next unit's V may be written
