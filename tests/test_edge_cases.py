@@ -108,3 +108,34 @@ def test_tensor_above_2gib_takes_the_fallback_kernels_and_agrees_with_the_dma_ke
     assert rel(dx, torch.cat([q[1] for q in parts])) < 1e-5
     assert rel(dw, parts[0][2] + parts[1][2]) < 1e-4
     assert rel(db, parts[0][3] + parts[1][3]) < 1e-4
+
+
+@pytest.mark.parametrize("hw", [(7, 8), (5, 12), (16, 16), (9, 72), (3, 260)])
+def test_maxpool_3x3_s2_backward_pair_kernel_small_and_ragged(hw):
+    """SAME-padded 3x3 / stride-2 pooling with OW == W / 2: the pair-load backward kernel (pool.hip) on odd heights, rows
+    shorter / longer than a wave, ties -- bit-exact against the oracle, accumulate and assign-zero-plus-sums modes"""
+    import torch
+    from bcnn_amd import ops
+    from oracle import orc_bind as ob
+    h, w = hw
+    n, c, k, s = 3, 5, 3, 2
+    oh, ow = (h + s - 1) // s, (w + s - 1) // s
+    rs = np.random.RandomState(h * 1000 + w)
+    x = rs.uniform(-1, 1, (n, c, h, w)).astype(np.float32)
+    x[:, :, : min(h, 4), 2:6] = 0.25  # a plateau: ties resolve to the first maximum
+    dy = rs.uniform(-1, 1, (n, c, oh, ow)).astype(np.float32)
+    dx0 = rs.uniform(-1, 1, (n, c, h, w)).astype(np.float32)
+    xg, dyg = torch.from_numpy(x).cuda(), torch.from_numpy(dy).cuda()
+    y = torch.empty((n, c, oh, ow), device="cuda")
+    idx = torch.empty((n, c, oh, ow), dtype=torch.int32, device="cuda")
+    ops.maxpool_forward(xg, y, idx, k, s)
+    dx = torch.from_numpy(dx0).cuda()
+    ops.maxpool_backward(dyg, idx, dx, k, s)
+    dxo = torch.full((n, c, h, w), 7.0, device="cuda")
+    ops.maxpool_backward(dyg, idx, dxo, k, s, overwrite=True)
+    torch.cuda.synchronize()
+    exp = ob.orc_maxpool(dict(n=n, c=c, h=h, w=w, k=k, s=s, padding=0, x=x, dx0=dx0.copy()), dy)
+    assert np.array_equal(idx.cpu().numpy(), exp["indexes"])
+    assert np.array_equal(dx.cpu().numpy(), exp["dx"])
+    expz = ob.orc_maxpool(dict(n=n, c=c, h=h, w=w, k=k, s=s, padding=0, x=x, dx0=np.zeros_like(dx0)), dy)
+    assert np.array_equal(dxo.cpu().numpy().view(np.int32), expz["dx"].view(np.int32))
