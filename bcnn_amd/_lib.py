@@ -76,6 +76,9 @@ SIGNATURES = {
     "bcnn_hip_softmax_forward": (None, [vp, vp, i, i, i]),
     "bcnn_hip_comm_init": (None, [i, i, C.c_char_p]),
     "bcnn_hip_comm_destroy": (None, []),
+    "bcnn_hip_comm_retain": (None, []),
+    "bcnn_hip_rendezvous_publish": (i, [C.c_char_p, vp, sz, i]),
+    "bcnn_hip_rendezvous_fetch": (i, [C.c_char_p, vp, sz, i, i]),
     "bcnn_hip_comm_world": (i, []),
     "bcnn_hip_comm_rank": (i, []),
     "bcnn_hip_allreduce_sum": (None, [vp, sz]),

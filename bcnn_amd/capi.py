@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libbcnn.so")
+LIB_PATH = os.environ.get("BCNN_LIB", os.path.join(_HERE, "lib", "libbcnn.so"))  # override: experiment build
 
 MODE_PREDICT, MODE_TRAIN, MODE_VALID = 0, 1, 2
 (ACT_NONE, ACT_TANH, ACT_RELU, ACT_RAMP, ACT_SOFTPLUS, ACT_LRELU, ACT_ABS, ACT_CLAMP, ACT_PRELU,

@@ -120,10 +120,16 @@ void bcnn_hip_conv_forward(const float* x, const float* w, const float* bias, fl
     float* raw = (bn_workspace && mode != BCNN_HIP_MODE_PREDICT) ? bn_workspace : y;
     // TRAIN: the convolution epilogue also emits the per-channel sum / sum of squares of what it stores
     ConvStats st;
-    st.partials = nullptr; st.splits = 0;
+    st.partials = nullptr; st.splits = 0; st.capacity = 0;
     static const int fuse_stats = BCNN_EXP_ENV("BCNN_HIP_NO_FUSED_STATS") ? 0 : 1;  // A/B switch for profiling
-    if (fuse_stats && mode == BCNN_HIP_MODE_TRAIN && s.total_q < 0x7fffffffLL)
-        st.partials = reduce_scratch((size_t)f * (size_t)ceil_div(s.total_q, 64) * 2);
+    if (fuse_stats && mode == BCNN_HIP_MODE_TRAIN && s.total_q < 0x7fffffffLL) {
+        // slots per channel: one per 64 output pixels on the GEMM paths; the fused Winograd kernel writes two per block
+        // of 64 2x2 tiles, which is MORE than that when a tile covers fewer than two real pixels (H == 1 or W == 1)
+        const long long tiles = (long long)n * ((s.OH + 1) / 2) * ((s.OW + 1) / 2);
+        const long long slots_gemm = ceil_div(s.total_q, 64), slots_wino = 2 * ceil_div(tiles, 64);
+        st.capacity = (size_t)f * (size_t)(slots_gemm > slots_wino ? slots_gemm : slots_wino) * 2;
+        st.partials = reduce_scratch(st.capacity);
+    }
     conv_fwd_any(x, w, nullptr, nullptr, raw, s, BCNN_HIP_ACT_NONE, /*raw=*/1, st.partials ? &st : nullptr);
     const int fused_act = (act == BCNN_HIP_ACT_PRELU) ? BCNN_HIP_ACT_NONE : act;
     // x_norm is not materialised on this path: the backward pass recomputes it from the raw convolution

@@ -33,6 +33,7 @@ inline ConvShape make_conv_shape(int n, int c, int h, int w, int f, int k, int s
 struct ConvStats {
     float* partials;
     int splits;
+    size_t capacity;  // floats behind `partials`; every forward path checks its own slot count against it
 };
 
 #ifdef __HIPCC__

@@ -932,6 +932,11 @@ static void wino_fused_run(const float* src, const float* w, float* dst, const C
     a.nunits = a.nfull + 2 * (nblocks - a.nfull);
     const bool plain = !a.add_bias && a.act == BCNN_HIP_ACT_NONE;
     a.stats_bytes = a.stats ? (unsigned)((size_t)a.M * 2 * a.tblocks * 2 * sizeof(float)) : 0u;
+    if (a.stats && (size_t)a.stats_bytes > stats->capacity * sizeof(float)) {
+        fprintf(stderr, "[bcnn_hip] fused Winograd: statistics need %u bytes, the caller's buffer holds %zu\n",
+                a.stats_bytes, stats->capacity * sizeof(float));
+        abort();
+    }
     if (a.stats && !plain) {
         fprintf(stderr, "[bcnn_hip] fused Winograd: output statistics are taken on the raw convolution output only\n");
         abort();

@@ -188,6 +188,10 @@ bcnn_status bcnn_net_add_node(bcnn_net *net, bcnn_node node) {
     if (hctx(net)) { /* per-node arena offsets are rebuilt by the next bcnn_compile_net; until then one final range */
         free(hctx(net)->node_grad_first);
         hctx(net)->node_grad_first = NULL;
+        /* the dead-fill / sole-writer marks were proven on the OLD graph: the new node may be a second writer of a
+         * gradient whose fill was elided (its contribution would be overwritten by the `0 + sum` assignment of the
+         * former sole writer). Until the next compile every fill is live and nobody is a sole writer. */
+        hctx(net)->grad_fill_count = 0;
     }
     return BCNN_SUCCESS;
 }
@@ -848,8 +852,15 @@ bcnn_status bcnn_set_data_parallel_comm(bcnn_net *net, int rank, int world_size,
     if (world_size < 1 || rank < 0 || rank >= world_size) return BCNN_INVALID_PARAMETER;
     if (world_size > 1 && (!id_path || !id_path[0])) return BCNN_INVALID_PARAMETER;
     bcnn_hip_context *hc = hctx(net);
-    if (bcnn_hip_comm_world() == 0) bcnn_hip_comm_init(rank, world_size, id_path); /* fatal on failure */
-    if (bcnn_hip_comm_world() != world_size || bcnn_hip_comm_rank() != rank) return BCNN_INVALID_PARAMETER;
+    if (hc->comm_active) /* second call on the same net: it already holds the communicator */
+        return (bcnn_hip_comm_world() == world_size && bcnn_hip_comm_rank() == rank) ? BCNN_SUCCESS
+                                                                                       : BCNN_INVALID_PARAMETER;
+    if (bcnn_hip_comm_world() == 0) {
+        bcnn_hip_comm_init(rank, world_size, id_path); /* fatal on failure; this net is the first holder */
+    } else {
+        if (bcnn_hip_comm_world() != world_size || bcnn_hip_comm_rank() != rank) return BCNN_INVALID_PARAMETER;
+        bcnn_hip_comm_retain(); /* one communicator per process, shared by its nets; the last bcnn_end_net destroys it */
+    }
     hc->dp_rank = rank;
     hc->dp_world = world_size;
     hc->comm_active = 1;

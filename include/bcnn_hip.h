@@ -290,9 +290,18 @@ void bcnn_hip_softmax_forward(const float *x_d, float *y_d, int n, int c, int hw
  * Data-parallel exchange (RCCL over xGMI).  No reference counterpart (the reference is single-device); process
  * model = the reference's one device per process (bcnn_cuda_set_device once in main, src/cli/bcnn_cl.c:281-285,
  * src/bcnn_utils.c:201): N processes, each after bcnn_hip_set_device(local rank), form one communicator.
- *   comm_init     : rank 0 creates the RCCL unique id and publishes it at `id_path` (a file all ranks can see, unique
- *                   per job; atomic rename), the others wait for it (<= 120 s), then ncclCommInitRank on the current
- *                   device. world == 1 may pass NULL. RCCL is dlopen'ed here, not linked. One communicator per process.
+ *   comm_init     : rank 0 creates the RCCL unique id and publishes it at `id_path` (a file all ranks can see;
+ *                   atomic rename), the others wait for it (<= 120 s), then ncclCommInitRank on the current device;
+ *                   rank 0 unlinks the file once that collective call has returned. A record left behind by a job
+ *                   that died in between is told from this job's by BCNN_HIP_JOB_NONCE (environment, any string,
+ *                   the same on every rank of a job and different per job: records with another nonce are ignored)
+ *                   and by its age (older than BCNN_HIP_ID_MAX_AGE_S, default 600 s, when the wait starts = stale).
+ *                   world == 1 may pass NULL. RCCL is dlopen'ed here, not linked. One communicator per process,
+ *                   reference-counted: comm_retain adds a holder, comm_destroy drops one and tears the
+ *                   communicator down with the last (two nets of one process may train over it).
+ *   rendezvous_publish / _fetch : the file rendezvous by itself (what comm_init uses for the ncclUniqueId): publish
+ *                   stores up to 256 bytes + world size + nonce + time at `path` (0 = ok, -1 = I/O error); fetch
+ *                   polls for a record of this job (0 = fetched, 1 = timed out, 2 = published for another world size).
  *   allreduce_sum : in-place sum of n floats across the ranks, queued on the communicator's own stream AFTER the
  *                   work queued so far on the calling thread's stream (event ordering, no host block). Every rank
  *                   must issue the same sequence of calls.
@@ -302,7 +311,10 @@ void bcnn_hip_softmax_forward(const float *x_d, float *y_d, int n, int c, int hw
  * Any RCCL / HIP failure prints and exit()s like every other device error.
  * ------------------------------------------------------------------------------------------- */
 void bcnn_hip_comm_init(int rank, int world, const char *id_path);
+void bcnn_hip_comm_retain(void);
 void bcnn_hip_comm_destroy(void);
+int bcnn_hip_rendezvous_publish(const char *path, const void *blob, size_t n, int world);
+int bcnn_hip_rendezvous_fetch(const char *path, void *blob, size_t n, int world, int timeout_ms);
 int bcnn_hip_comm_world(void);   /* 0 while no communicator exists */
 int bcnn_hip_comm_rank(void);
 void bcnn_hip_allreduce_sum(float *buf_d, size_t n);

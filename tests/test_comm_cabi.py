@@ -120,3 +120,131 @@ def test_net_level_comm_buckets_cover_the_arena_once(tmp_path):
         return params
     a, b = run(False), run(True)
     assert torch.equal(a, b)
+
+
+# ---- the file rendezvous by itself (no GPU, no RCCL): what keeps a stale id file of an earlier job from being used ----
+_FETCH = r"""
+import ctypes as C, os, sys
+sys.path.insert(0, %r)
+from bcnn_amd import _lib
+L = _lib.load()
+buf = C.create_string_buffer(128)
+r = L.bcnn_hip_rendezvous_fetch(sys.argv[1].encode(), buf, 128, int(sys.argv[2]), int(sys.argv[3]))
+print(r, buf.raw[:8].decode("latin1"))
+""" % ROOT
+
+
+def _publish(path, payload, world, nonce=None):
+    import ctypes as C
+    from bcnn_amd import _lib
+    L = _lib.load()
+    old = os.environ.pop("BCNN_HIP_JOB_NONCE", None)
+    if nonce is not None:
+        os.environ["BCNN_HIP_JOB_NONCE"] = nonce
+    try:
+        blob = payload.ljust(128, b"\0")
+        return L.bcnn_hip_rendezvous_publish(str(path).encode(), blob, 128, world)
+    finally:
+        os.environ.pop("BCNN_HIP_JOB_NONCE", None)
+        if old is not None:
+            os.environ["BCNN_HIP_JOB_NONCE"] = old
+
+
+def _fetch(path, world, timeout_ms, nonce=None, max_age=None, wait=True):
+    env = dict(os.environ)
+    env.pop("BCNN_HIP_JOB_NONCE", None)
+    env.pop("BCNN_HIP_ID_MAX_AGE_S", None)
+    if nonce is not None:
+        env["BCNN_HIP_JOB_NONCE"] = nonce
+    if max_age is not None:
+        env["BCNN_HIP_ID_MAX_AGE_S"] = str(max_age)
+    p = subprocess.Popen([sys.executable, "-c", _FETCH, str(path), str(world), str(timeout_ms)], env=env,
+                         stdout=subprocess.PIPE, text=True)
+    if not wait:
+        return p
+    out = p.communicate(timeout=120)[0].split()
+    return int(out[0]), (out[1] if len(out) > 1 else "")
+
+
+def test_rendezvous_fresh_record_is_fetched_and_world_mismatch_is_reported(tmp_path):
+    path = tmp_path / "job.id"
+    assert _publish(path, b"PAYLOAD1", 2) == 0
+    assert _fetch(path, 2, 200) == (0, "PAYLOAD1")
+    assert _fetch(path, 4, 200)[0] == 2
+    assert _publish(tmp_path / "no" / "such" / "dir" / "id", b"x", 2) == -1
+    assert not [f for f in os.listdir(tmp_path) if ".tmp." in f]      # the temporary was renamed, not left behind
+
+
+def test_rendezvous_ignores_a_record_of_another_job(tmp_path):
+    """with a fixed id path a re-run used to read the PREVIOUS job's id before rank 0 had renamed the
+    new one into place. A record with another nonce, or one that is older than the age bound, is now waited out."""
+    import time
+    path = tmp_path / "job.id"
+    assert _publish(path, b"OLDJOB__", 2, nonce="job-41") == 0
+    assert _fetch(path, 2, 300, nonce="job-42")[0] == 1                 # other nonce: as if no file existed
+    assert _fetch(path, 2, 300, nonce="job-41") == (0, "OLDJOB__")
+    assert _fetch(path, 2, 300)[0] == 1                                 # unset nonce != "job-41"
+    # the waiting rank is started BEFORE rank 0 publishes and with the stale file in place: it must return the new id
+    waiter = _fetch(path, 2, 20000, nonce="job-42", wait=False)
+    time.sleep(1.0)
+    assert waiter.poll() is None
+    assert _publish(path, b"NEWJOB__", 2, nonce="job-42") == 0
+    out = waiter.communicate(timeout=60)[0].split()
+    assert (int(out[0]), out[1]) == (0, "NEWJOB__")
+    # age bound: a record published 3 s ago is stale under a 1 s bound, fresh under the default
+    time.sleep(3.0)
+    assert _fetch(path, 2, 200, nonce="job-42", max_age=1)[0] == 1
+    assert _fetch(path, 2, 200, nonce="job-42") == (0, "NEWJOB__")
+
+
+@pytest.mark.gpu
+def test_comm_init_removes_the_id_file_and_the_communicator_is_reference_counted(tmp_path):
+    from bcnn_amd import _lib
+    L = _lib.load()
+    path = tmp_path / "job.id"
+    L.bcnn_hip_comm_init(0, 1, str(path).encode())
+    try:
+        assert not path.exists()             # unlinked after the (collective) ncclCommInitRank
+        L.bcnn_hip_comm_retain()
+        L.bcnn_hip_comm_destroy()
+        assert L.bcnn_hip_comm_world() == 1  # the second holder keeps it alive
+    finally:
+        L.bcnn_hip_comm_destroy()
+    assert L.bcnn_hip_comm_world() == 0
+
+
+@pytest.mark.gpu
+def test_two_nets_share_the_communicator(tmp_path):
+    """bcnn_end_net of one comm-active net must not tear the communicator down under the other."""
+    import numpy as np
+    from bcnn_amd import _lib, capi
+    L = _lib.load()
+    nets = []
+    for k in range(2):
+        net = capi.Net(mode=capi.MODE_TRAIN, w=8, h=8, c=3, n=2)
+        net.conv(4, 3, 1, 1, act=capi.ACT_RELU, src="input", dst="c%d" % k)
+        net.compile()
+        net.set_data_parallel_comm(0, 1, str(tmp_path / "two.id"))
+        nets.append(net)
+    nets[0].close()
+    assert L.bcnn_hip_comm_world() == 1
+    nets[1].forward()
+    nets[1].sync()
+    nets[1].close()
+    assert L.bcnn_hip_comm_world() == 0
+
+
+@pytest.mark.gpu
+def test_plain_c_program_trains_data_parallel_world2(tmp_path):
+    """Two processes, two GPUs, the library's own RCCL path: both ranks end with the same parameters."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (the pool hands out one)")
+    exe = _build_example(tmp_path)
+    env = dict(os.environ, BCNN_HIP_JOB_NONCE="w2-%d" % os.getpid())
+    procs = [subprocess.Popen([exe, str(r), "2", str(tmp_path / "w2.id"), "6"], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True, env=env) for r in (1, 0)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    sums = sorted(ln.split("checksum")[-1] for o in outs for ln in o[0].splitlines() if ln.startswith("rank "))
+    assert len(sums) == 2 and sums[0] == sums[1], outs

@@ -193,3 +193,46 @@ def test_nodes_added_after_compile_are_trained_after_the_next_compile():
             assert np.abs(whole.data(i) - before).max() > 0
     whole.close()
     grown.close()
+
+
+def test_second_consumer_added_after_compile_keeps_its_gradient_without_a_recompile():
+    """bcnn_net_add_node kept the sole-writer marks of the last compile. conv -> maxpool makes the
+    max-pool the only writer of d(conv output), so its backward ASSIGNS 0 + sum and the zero fill is skipped. A second
+    consumer of the same tensor (a global avg-pool here) appended afterwards accumulates first (reverse node order) and
+    was then overwritten. With the marks dropped in add_node the un-recompiled net equals the net built in one go."""
+    from bcnn_amd import capi
+
+    def head(net):
+        net.conv(8, 3, 1, 1, 1, 0, capi.ACT_RELU, "input", "c1")
+        net.maxpool(2, 2, capi.PADDING_SAME, "c1", "p1")
+
+    def tail(net):
+        net.avgpool("c1", "gap")           # second reader of c1, behind the max-pool in node order
+
+    def grads(net, x):
+        rs = np.random.RandomState(9)
+        net.data(0)[...] = x; net.upload(0)
+        net.forward()
+        for name in ("p1", "gap"):
+            i = net.index(name)
+            net.download(i)
+            net.grad(i)[...] = rs.uniform(-1, 1, net.shape(i)).astype(np.float32)
+            net.upload(i, with_grad=True)
+        net.backward(); net.sync()
+        i = net.index("input_w")
+        assert i >= 0
+        net.download(i, with_grad=True)
+        return net.grad(i).copy()
+
+    shp = dict(w=12, h=12, c=3, n=2)
+    x = np.random.RandomState(1).uniform(-1, 1, (2, 3, 12, 12)).astype(np.float32)
+    C.CDLL(None).srand(5)
+    whole = capi.Net(mode=capi.MODE_TRAIN, **shp)
+    head(whole); tail(whole); whole.compile()
+    C.CDLL(None).srand(5)
+    grown = capi.Net(mode=capi.MODE_TRAIN, **shp)
+    head(grown); grown.compile(); tail(grown)          # NOT recompiled
+    a, b = grads(whole, x), grads(grown, x)
+    assert np.abs(a).max() > 0
+    assert np.array_equal(a, b)
+    whole.close(); grown.close()

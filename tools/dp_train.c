@@ -2,7 +2,7 @@
  * gradient all-reduce INSIDE the library (bcnn_set_data_parallel_comm: RCCL over xGMI behind the C-ABI).
  *
  *   gcc -std=gnu99 -DBCNN_USE_HIP -Iinclude tools/dp_train.c -Lbcnn_amd/lib -lbcnn -lbcnn_hip -lm -o dp_train
- *   for r in 0 1 ... N-1:  ./dp_train $r N /tmp/job42.id 20 &        (rank r uses GPU r of the node)
+ *   for r in 0 1 ... N-1:  BCNN_HIP_JOB_NONCE=$$ ./dp_train $r N /tmp/job.id 20 &   (rank r uses GPU r; the nonce marks THIS job's id file)
  *   ./dp_train 0 1 - 20 nocomm                                        (single process, no communicator)
  *
  * Every rank builds the same net from the same seed (identical initial parameters), feeds its own shard of a synthetic
