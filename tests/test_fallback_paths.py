@@ -27,3 +27,44 @@ def test_golden_suite_on_the_other_code_path(env):
                        timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+_TRAIN = r"""
+import ctypes, hashlib, sys
+sys.path.insert(0, %r)
+import numpy as np, torch
+import bench
+from bcnn_amd import capi
+ctypes.CDLL(None).srand(11)
+net = capi.Net(mode=capi.MODE_TRAIN, w=32, h=32, c=3, n=4)
+bench.build_resnet18(net, capi, classes=10, base=16)
+net.compile(); net.set_sgd(0.01, 0.9, 5e-4)
+rs = np.random.RandomState(3)
+for _ in range(3):
+    net.data(0)[...] = rs.uniform(-1, 1, net.shape(0))
+    lab = np.zeros(net.shape(1), np.float32); lab[np.arange(4), rs.randint(0, 10, 4)] = 1
+    net.data(1)[...] = lab.reshape(net.shape(1))
+    net.upload(0); net.upload(1)
+    net.forward(); net.backward(); net.update()
+net.sync()
+p, n = net.parameter_arena()
+print("SHA", hashlib.sha256(torch.as_tensor(capi.DeviceArray(p, n), device="cuda:0").cpu().numpy().tobytes()).hexdigest())
+""" % ROOT
+
+
+@pytest.mark.gpu
+def test_experiment_host_runtime_with_every_gradient_fill_kept_trains_bit_identically():
+    """bcnn_amd/lib/libbcnn_exp.so (host runtime with -DBCNN_HIP_EXPERIMENT, selected with BCNN_LIB) is the only build
+    that reads BCNN_KEEP_ALL_GRAD_FILLS: with it every dst gradient is zeroed like in the reference (bcnn_net.c:361-375)
+    and no backward worker is a 'sole writer'. Skipping the provably dead fills must not change a single bit of a
+    ResNet-18-shaped training run (max-pool, eltwise, 1x1/s2 and Winograd layers all present)."""
+    lib = os.path.join(ROOT, "bcnn_amd", "lib")
+    assert os.path.exists(os.path.join(lib, "libbcnn_exp.so")), "experiment host runtime missing: build() makes it"
+    shas = []
+    for env in ({}, {"BCNN_LIB": os.path.join(lib, "libbcnn_exp.so"), "BCNN_HIP_LIB": os.path.join(lib, "libbcnn_hip_exp.so"),
+                     "BCNN_KEEP_ALL_GRAD_FILLS": "1"}):
+        e = dict(os.environ); e.update(env)
+        r = subprocess.run([sys.executable, "-c", _TRAIN], cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        shas.append([ln for ln in r.stdout.splitlines() if ln.startswith("SHA")][0])
+    assert shas[0] == shas[1]
