@@ -527,6 +527,15 @@ __global__ __launch_bounds__(256) void conv_dw_direct_finalize_kernel(const floa
     }
 }
 
+// shared with conv_window.hip (same partial layout)
+void conv_dw_direct_finalize(const float* partials, int nparts, int groups, int Mg, int K, int MP, int bias_col, float* dw,
+                             float* dbias) {
+    const int total = groups * Mg * (K + bias_col);
+    conv_dw_direct_finalize_kernel<<<ceil_div(total, 16), 256, 0, current_stream()>>>(partials, nparts, groups, Mg, K, MP,
+                                                                                       bias_col, dw, dbias);
+    KERNEL_CHECK();
+}
+
 static bool dw_direct_ok(const ConvShape& s) {
     return !s.pointwise && s.K < 32 && s.Mg <= 64 && s.stride == 1 && (s.OW % 16) == 0 && s.total_q > 0 &&
            (long long)s.N * s.F * s.OHOW < (1LL << 32) && (long long)s.N * s.C * s.HW < (1LL << 32) &&
@@ -574,10 +583,7 @@ bool conv_backward_weights_direct(const float* x, const float* dy, float* dw, fl
     if (tm == 1) conv_dw_direct_kernel<1><<<grid, 256, 0, current_stream()>>>(a);
     else conv_dw_direct_kernel<2><<<grid, 256, 0, current_stream()>>>(a);
     KERNEL_CHECK();
-    const int total = s.groups * s.Mg * (s.K + a.bias_col);
-    conv_dw_direct_finalize_kernel<<<ceil_div(total, 16), 256, 0, current_stream()>>>(
-        workspace, blocks, s.groups, s.Mg, s.K, tm * 32, a.bias_col, dw, dbias);
-    KERNEL_CHECK();
+    conv_dw_direct_finalize(workspace, blocks, s.groups, s.Mg, s.K, tm * 32, a.bias_col, dw, dbias);
     return true;
 }
 
