@@ -313,6 +313,15 @@ __global__ __launch_bounds__(256) void cache_prefetch_kernel(const float4* __res
     if (acc == 123456.789f) *sink = acc;  // never true for finite data; keeps the loads alive
 }
 
+// input small enough for the Infinity Cache and dwarfed by the output: pull it in first, so that the kernel's HBM traffic
+// is a pure write stream (shared with conv_window.hip)
+void conv_prefetch_input(const float* x, const ConvShape& s, float* sink) {
+    const size_t xb = (size_t)s.N * s.C * s.HW * 4, yb = (size_t)s.N * s.F * s.OHOW * 4;
+    static const bool pf_on = [] { const char* e = BCNN_EXP_ENV("BCNN_HIP_NO_PREFETCH"); return !(e && e[0] == '1'); }();
+    if (pf_on && xb <= (128u << 20) && yb >= 4 * xb && yb >= (256u << 20) && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
+        cache_prefetch_kernel<<<kCUs * 8, 256, 0, current_stream()>>>(reinterpret_cast<const float4*>(x), xb / 16, sink);
+}
+
 bool conv_forward_direct(const float* x, const float* w, const float* bias, const float* slopes, float* y,
                          const ConvShape& s, int act, int raw) {
     if (s.pointwise || s.K > 32 || s.Mg > 64 || s.total_q == 0) return false;
@@ -333,12 +342,7 @@ bool conv_forward_direct(const float* x, const float* w, const float* bias, cons
     const int tm = (s.Mg <= 32) ? 1 : 2;
     KTimer kt(K_CONV_FWD, 2.0 * (double)s.total_q * s.Mg * s.K * s.groups,
               4.0 * ((double)s.N * s.C * s.HW + (double)s.F * s.K + (double)s.N * s.F * s.OHOW));
-    {   // input small enough for the Infinity Cache and dwarfed by the output: make the kernel's HBM traffic write-only
-        const size_t xb = (size_t)s.N * s.C * s.HW * 4, yb = (size_t)s.N * s.F * s.OHOW * 4;
-        static const bool pf_on = [] { const char* e = BCNN_EXP_ENV("BCNN_HIP_NO_PREFETCH"); return !(e && e[0] == '1'); }();
-        if (pf_on && xb <= (128u << 20) && yb >= 4 * xb && yb >= (256u << 20) && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
-            cache_prefetch_kernel<<<kCUs * 8, 256, 0, current_stream()>>>(reinterpret_cast<const float4*>(x), xb / 16, y);
-    }
+    conv_prefetch_input(x, s, y);
     const int actm = (a.act == BCNN_HIP_ACT_NONE) ? 0 : (a.act == BCNN_HIP_ACT_RELU ? 1 : 2);
 #define LAUNCH(TMv, KSv, KZ)                                                                            \
     do {                                                                                                \

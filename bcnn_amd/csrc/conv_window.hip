@@ -13,13 +13,34 @@
 //      (pixel + hi * delta) + immediate -- the reduction index is ordered so that the two taps of a step lie a constant
 //      distance apart (1 element, 1 row or 1 channel plane), hence four address registers per tile serve all 14 steps
 //      and the only global-memory instructions left in the loop are the result stores;
-//      dW: the im2col operand of a 16-pixel window is eight ds_read_b32 off one address register; dy is loaded in
-//      fragment order with 16-byte buffer loads as before.
+//      dW: see the second half of the file -- dy reaches LDS by LDS-DMA, one filter-plane row per instruction.
 // The weights live in MFMA A-operand registers (forward) for the life of the workgroup. Reference semantics:
 // bcnn_forward_conv_layer_cpu / bcnn_backward_conv_layer_cpu, bcnn_conv_layer.c:367-587 (im2col + gemm, add_bias quirk).
 #include "conv_common.h"
 #include "lds_dma.h"
 
+// Timing experiments (tools/exp/win_variants.sh builds the file with -DWABL_*; normal builds define none of them):
+// WABL_NOSTORE / WABL_NOMFMA (forward), WABL_FWD_R (strip height), WABL_WAVES (launch bound), WABL_PREFETCH, ROWS_TM,
+// ROWS_INTERLEAVE, DY_DMA_PLAIN (dW).
+#ifndef WABL_FWD_R
+#define WABL_FWD_R 8
+#endif
+#ifndef WABL_WAVES
+#define WABL_WAVES 4
+#endif
+// Measured on configs[1] (tools/exp/win_variants.sh): one 8-wave workgroup per CU with both filter blocks 0.387 ms, two
+// independent 4-wave workgroups (one filter block each) 0.345; requests issued in one burst at the top of a row beat
+// requests spread behind the windows' MFMAs (0.345 / 0.415); non-temporal dy requests leave the dW time alone and keep
+// the layer input in the Infinity Cache for the next forward pass (0.37 -> 0.34 ms).
+#ifndef ROWS_TM
+#define ROWS_TM 1
+#endif
+#ifndef ROWS_INTERLEAVE
+#define ROWS_BURST 1
+#endif
+#ifndef DY_DMA_PLAIN
+#define DY_DMA_NT 1
+#endif
 #ifndef STORE_AUX
 #define STORE_AUX 2  // nt: the result stream must not displace the input in L2 / Infinity Cache (conv_direct.hip)
 #endif
@@ -45,6 +66,8 @@ struct WinSteps {
         if (CG & 1) st[n++] = WinStep{CG - 1, 2, 2, WD_NONE, 0};                        // the odd one out
     }
 };
+
+void conv_prefetch_input(const float* x, const ConvShape& s, float* sink);  // conv_direct.hip
 
 struct ConvWindowFwdArgs {
     const float* x;
@@ -76,7 +99,7 @@ __device__ __forceinline__ void window_fill(float* win, rsrc_i4 rx, const ConvSh
 // forward
 // ================================================================================================
 template <int CG, int R, int PITCH, int TM, int ACTM>
-__global__ __launch_bounds__(256, 4) void conv_fwd_window_kernel(const ConvWindowFwdArgs a) {
+__global__ __launch_bounds__(256, WABL_WAVES) void conv_fwd_window_kernel(const ConvWindowFwdArgs a) {
     constexpr int ROWS = R + 2, PLANE = ROWS * PITCH;
     constexpr WinSteps<CG> steps{};
     constexpr int NT = WinSteps<CG>::N;        // steps that read taps
@@ -174,7 +197,23 @@ __global__ __launch_bounds__(256, 4) void conv_fwd_window_kernel(const ConvWindo
 #pragma unroll
         for (int st = 0; st < KS; ++st)
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) acc[tm] = mfma32(areg[tm][st], b[st], acc[tm]);
+            for (int tm = 0; tm < TM; ++tm) {
+#ifdef WABL_NOMFMA
+                if (st > 0) { acc[tm][st & 15] += areg[tm][st] * b[st]; continue; }
+#endif
+                acc[tm] = mfma32(areg[tm][st], b[st], acc[tm]);
+            }
+#ifdef WABL_NOSTORE
+        if (a.act != 12345) {
+            float sink = 0.f;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sink += acc[tm][r];
+            if (sink == 123456.789f) buffer_store_f32(sink, ry, (int)ycur, 0, 0);
+            return;
+        }
+#endif
         unsigned fs = fstride;
         asm volatile("" : "+s"(fs));  // recompute the 32 scalar channel offsets per tile instead of pinning 32 SGPRs
 #pragma unroll
@@ -249,7 +288,7 @@ static bool window_ok(const ConvShape& s) {
 bool conv_forward_window(const float* x, const float* w, const float* bias, const float* slopes, float* y, const ConvShape& s,
                          int act, int raw) {
     if (!window_ok(s)) return false;
-    constexpr int R = 8;
+    constexpr int R = WABL_FWD_R;
     ConvWindowFwdArgs a;
     a.x = x; a.w = w; a.bias = bias; a.slopes = slopes; a.y = y; a.s = s;
     a.act = raw ? BCNN_HIP_ACT_NONE : act;
@@ -261,6 +300,9 @@ bool conv_forward_window(const float* x, const float* w, const float* bias, cons
     const int pitch = window_pitch(s);
     KTimer kt(K_CONV_FWD, 2.0 * (double)s.total_q * s.Mg * s.K * s.groups,
               4.0 * ((double)s.N * s.C * s.HW + (double)s.F * s.K + (double)s.N * s.F * s.OHOW));
+#ifdef WABL_PREFETCH
+    conv_prefetch_input(x, s, y);
+#endif
 #define LAUNCH4(CGv, Pv, TMv, Av) conv_fwd_window_kernel<CGv, R, Pv, TMv, Av><<<grid, 256, 0, current_stream()>>>(a)
 #define LAUNCH3(CGv, Pv, TMv) do { if (actm == 0) LAUNCH4(CGv, Pv, TMv, 0); else if (actm == 1) LAUNCH4(CGv, Pv, TMv, 1); \
                                    else LAUNCH4(CGv, Pv, TMv, 2); } while (0)
@@ -278,122 +320,173 @@ bool conv_forward_window(const float* x, const float* w, const float* bias, cons
 }
 
 // ================================================================================================
-// dW (+ bias gradient)
+// dW (+ bias gradient), row-streamed: dy through LDS by LDS-DMA
 // ================================================================================================
-struct ConvWindowDwArgs {
+// A first version kept the LDS-free kernel's dy path (conv_direct.hip: 16-byte loads in MFMA fragment order) next to the
+// input window in LDS: one such load instruction touches 32 filter planes with 2 x 16 bytes each, HBM sees 64-byte pieces
+// scattered over 64 pages, and the kernel took 0.41 ms where the same bytes read as contiguous 1 KB runs took 0.33 and
+// cache hits 0.26 (timing-only variants). Here ONE instruction moves one output row of one filter plane -- up to 1 KB
+// contiguous -- straight into LDS (`buffer_load_dwordx4 ... lds`: no registers, no vector ALU, any number in flight), and
+// the fragments are read back with conflict-free ds_read_b128 (row pitch = 4 x odd floats). A persistent workgroup of four
+// waves owns 32 filters and a share of the N*OH output rows, which it walks through a two-stage ring: {32 dy rows, the
+// 3 x C/g input rows} of row r + 1 are requested -- two instructions behind every window's MFMAs -- while row r is
+// multiplied; the 8-pixel windows of a row are dealt to the four waves. Two such workgroups fit a CU (75 KB of LDS each)
+// and run out of phase: one's wait for its last rows to land is the other's multiply time.
+struct ConvRowsDwArgs {
     const float* x;
     const float* dy;
-    float* partials;  // [nblocks][groups][TM*32][32]
+    float* partials;  // [nblocks][groups][MP][32], MP = 32 * filter blocks
     ConvShape s;
-    int strips;             // per image
-    int total_strips;       // N * strips
-    int strips_per_block;
+    int total_rows;      // N * OH
+    int rows_per_block;
     int bias_col;
+    int mp;
 };
 
-// Reduction over output pixels q; MFMA step e of a 16-pixel window pairs q0 + e (lower half-wave) with q0 + 8 + e
-// (upper): a lane's eight dy values are 32 contiguous bytes (two 16-byte loads), its eight im2col values eight
-// consecutive LDS floats. Column l31 = tap k (natural order), column K = all ones (bias gradient), beyond = zeros.
-template <int CG, int R, int PITCH, int TM>
-__global__ __launch_bounds__(256, 4) void conv_dw_window_kernel(const ConvWindowDwArgs a) {
-    constexpr int ROWS = R + 2, PLANE = ROWS * PITCH;
-    constexpr int RED = 3 * TM * 32 * 33;
-    constexpr int WINF = CG * PLANE + 16;  // + eight ones, eight zeros
-    __shared__ __attribute__((aligned(16))) float smem[WINF > RED ? WINF : RED];
-    float* win = smem;
+template <int CG, int PD, int PX, int TM>
+__global__ __launch_bounds__(256 * TM, 1) void conv_dw_rows_kernel(const ConvRowsDwArgs a) {
+    constexpr int NF = 32 * TM, NW = 4 * TM;        // filters per workgroup, waves (4 per block of 32 filters)
+    constexpr int DYS = NF * PD, XS = CG * 3 * PX;  // floats per stage
+    constexpr int XREQ = (CG * 3 + NW - 1) / NW, NREQ = 8 + XREQ;  // LDS-DMA instructions per wave and row
+    constexpr int RED = TM * 3 * 32 * 33;
+    static_assert(2 * DYS >= RED, "the final reduction aliases the dy stages");
+    __shared__ __attribute__((aligned(16))) float lds[2 * DYS + 2 * XS + 16];
+    float* xS = lds + 2 * DYS;
+    float* cst = xS + 2 * XS;  // eight ones, eight zeros
     const ConvShape& s = a.s;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     const int g = blockIdx.y;
+    const int fh = wid >> 2, slot = wid & 3;         // filter block inside the workgroup, window slot
+    const int fb = blockIdx.z * TM + fh;             // block of 32 filters inside the group
     const rsrc_i4 rx = make_rsrc(a.x, (unsigned)((long long)s.N * s.C * s.HW * 4));
     const rsrc_i4 rdy = make_rsrc(a.dy, (unsigned)((long long)s.N * s.F * s.OHOW * 4));
 
-    // this lane's im2col column
+    // the input stages' padding columns are never written again: zero them (and everything else) once
+    for (int i = tid; i < 2 * XS; i += 256 * TM) xS[i] = 0.f;
+    if (tid < 16) cst[tid] = tid < 8 ? 1.0f : 0.0f;
+    __syncthreads();
+
+    // lane constants (byte offsets into lds[])
     const int K = CG * 9;
     const bool tap = l31 < K;
-    int lds_lane;  // byte offset for window row 0, output column 0 (taps) or of the constant run (others)
+    const unsigned a_lane = (unsigned)(((fh * 32 + l31) * PD + 4 * hi) * 4);
+    unsigned b_lane, b_step;  // taps follow the window, the constant columns do not
     {
         const int c = l31 / 9, r9 = l31 - c * 9, kr = r9 / 3, kc = r9 - kr * 3;
-        lds_lane = tap ? c * PLANE + kr * PITCH + kc + (kWinOrg - s.pad) + 8 * hi
-                       : CG * PLANE + ((l31 == K && a.bias_col) ? 0 : 8);
-        lds_lane *= 4;  // bytes
+        b_lane = tap ? (unsigned)((2 * DYS + (c * 3 + kr) * PX + kc + (kWinOrg - s.pad) + 4 * hi) * 4)
+                     : (unsigned)((2 * DYS + 2 * XS + ((l31 == K && a.bias_col) ? 0 : 8)) * 4);
+        b_step = tap ? 1u : 0u;
     }
-    const char* winb = reinterpret_cast<const char*>(win);
-    const unsigned moves = tap ? 1u : 0u;  // constant columns do not follow the window
-    const unsigned fstride = (unsigned)s.OHOW * 4u;
-    // dy: rows beyond F/groups are out of range for good (kOOB + anything below 2^31 stays out of range)
-    unsigned dy_lane[TM];
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-        dy_lane[tm] = (tm * 32 + l31 < s.Mg) ? (unsigned)(tm * 32 + l31) * fstride + 32u * (unsigned)hi : kOOB;
+    const char* ldsb = reinterpret_cast<const char*>(lds);
+    const unsigned lds0 = lds_offset(lds);
+    const unsigned dma_lane = (unsigned)lane * 16u;
+    const bool dy_lane_on = lane * 4 < s.OW, x_lane_on = lane * 4 < s.W;
 
-    f32x16 acc[TM];
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[tm][r] = 0.f;
-
-    const int wpr = (s.OW + 15) >> 4;  // 16-pixel windows per output row
-    int sidx = blockIdx.x * a.strips_per_block;
-    int s_end = sidx + a.strips_per_block;
-    if (s_end > a.total_strips) s_end = a.total_strips;
-    for (; sidx < s_end; ++sidx) {
-        const int n = sidx / a.strips, strip = sidx - n * a.strips;
-        const int oh0 = strip * R;
-        const int rows_here = (s.OH - oh0 < R) ? s.OH - oh0 : R;
-        __syncthreads();  // the previous strip's readers are done with the window
-        window_fill<CG, R, PITCH>(win, rx, s, (unsigned)(n * s.C + g * s.Cg), oh0, tid);
-        if (tid < 16) win[CG * PLANE + tid] = tid < 8 ? 1.0f : 0.0f;
-        __syncthreads();
-        const unsigned dy_img = ((unsigned)(n * s.F + g * s.Mg) * (unsigned)s.OHOW + (unsigned)(oh0 * s.OW)) * 4u;
-        const int nwin = rows_here * wpr;
-        int row = 0, cw = wid;
-        while (cw >= wpr) { cw -= wpr; ++row; }
-        for (int wdx = wid; wdx < nwin; wdx += 4) {
-            const int ow0 = cw * 16;
-            // a half window beyond OW (OW % 16 == 8) reads dy as zeros
-            const unsigned dsc = dy_img + (unsigned)(row * s.OW + ow0) * 4u;
-            const bool half_ok = ow0 + 8 * hi < s.OW;
-            buf_f32x4 av[TM][2];
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm) {
-                const unsigned off = half_ok ? dy_lane[tm] + dsc : kOOB;
-                av[tm][0] = buffer_load_f32x4(rdy, (int)off, 0, 0);
-                av[tm][1] = buffer_load_f32x4(rdy, (int)off + 16, 0, 0);
+    // request number k (wave-uniform, 0 .. NREQ-1) of this wave for output row (n, oh) -> stage `buf`:
+    // k < 8: filter row wid*8 + k of the workgroup's dy rows; k >= 8: input row (c, rr) number wid + NW*(k-8), clamped (a repeat writes the
+    // same bytes to the same place, which keeps the instruction count per wave and row constant for the vmcnt waits)
+    auto request = [&](int k, int n, int oh, int buf) {
+        if (k < 8) {
+            const int f = blockIdx.z * NF + wid * 8 + k;
+            const bool fok = f < s.Mg;
+            const unsigned soff = __builtin_amdgcn_readfirstlane(
+                fok ? ((unsigned)(n * s.F + g * s.Mg + f) * (unsigned)s.OHOW + (unsigned)(oh * s.OW)) * 4u : 0u);
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((buf * DYS + (wid * 8 + k) * PD) * 4));
+            const unsigned voff = fok ? dma_lane : kOOB;
+            if (dy_lane_on) {
+#ifdef DY_DMA_NT
+                dma_row_x4_nt(rdy, dst, voff, soff);
+#else
+                dma_row_x4(rdy, dst, voff, soff);
+#endif
             }
-            const int vb = lds_lane + (int)__umul24(moves, (unsigned)(4 * (row * PITCH + ow0)));
-            float bv[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) bv[e] = *reinterpret_cast<const float*>(winb + vb + 4 * e);
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm) acc[tm] = mfma32(av[tm][e >> 2][e & 3], bv[e], acc[tm]);
-            cw += 4;
-            while (cw >= wpr) { cw -= wpr; ++row; }
+        } else {
+            const int i0 = wid + NW * (k - 8), i = i0 < CG * 3 ? i0 : CG * 3 - 1;
+            const int c = i / 3, rr = i - c * 3;
+            const int ih = oh - s.pad + rr;
+            const bool ok = (unsigned)ih < (unsigned)s.H;
+            const unsigned soff = __builtin_amdgcn_readfirstlane(
+                ((unsigned)(n * s.C + g * s.Cg + c) * (unsigned)s.HW + (unsigned)((ok ? ih : 0) * s.W)) * 4u);
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((2 * DYS + buf * XS + i * PX + kWinOrg) * 4));
+            const unsigned voff = ok ? dma_lane : kOOB;
+            if (x_lane_on) dma_row_x4(rx, dst, voff, soff);
         }
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int nwin = s.OW >> 3;  // 8-pixel windows per row: step e pairs pixel w*8 + e with w*8 + 4 + e
+    const int r0 = blockIdx.x * a.rows_per_block;
+    int r1 = r0 + a.rows_per_block;
+    if (r1 > a.total_rows) r1 = a.total_rows;
+
+    if (r0 < r1) {
+        const int n = r0 / s.OH, oh = r0 - n * s.OH;
+        for (int k = 0; k < NREQ; ++k) request(k, n, oh, 0);
+    }
+    dma_wait();
+    lds_barrier();
+    for (int r = r0; r < r1; ++r) {
+        const int buf = (r - r0) & 1;
+        const int nn = (r + 1) / s.OH, noh = (r + 1) - nn * s.OH;  // the row requested during this one
+        const int kend = (r + 1 < r1) ? NREQ : 0;
+        int k = 0;
+#ifdef ROWS_BURST
+        while (k < kend) { request(k, nn, noh, buf ^ 1); ++k; }
+#endif
+        unsigned va = a_lane + (unsigned)(buf * DYS * 4) + (unsigned)(slot * 32);
+        unsigned vb = b_lane + b_step * (unsigned)(buf * XS * 4 + slot * 32);
+        auto read_window = [&](buf_f32x4& av, float (&bv)[4]) {
+            av = *reinterpret_cast<const buf_f32x4*>(ldsb + va);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[e] = *reinterpret_cast<const float*>(ldsb + vb + 4 * e);
+            va += 128u;
+            vb += b_step * 128u;
+        };
+        if (slot < nwin) {  // two operand sets: the next window's LDS reads are issued before this window's MFMAs
+            buf_f32x4 avA, avB;
+            float bvA[4], bvB[4];
+            read_window(avA, bvA);
+            int w = slot;
+#define ROWS_STAGE(ca, cb, na, nb)                                                                 \
+            {                                                                                      \
+                const bool more = (w + 4 < nwin); /* uniform */                                    \
+                if (more) read_window(na, nb);                                                     \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) acc = mfma32(ca[e], cb[e], acc);     \
+                /* two requests for the next row in the shadow of the last MFMA */                 \
+                if (k < kend) { request(k, nn, noh, buf ^ 1); ++k; }                               \
+                if (k < kend) { request(k, nn, noh, buf ^ 1); ++k; }                               \
+                if (!more) break;                                                                  \
+                w += 4;                                                                            \
+            }
+            for (;;) {
+                ROWS_STAGE(avA, bvA, avB, bvB)
+                ROWS_STAGE(avB, bvB, avA, bvA)
+            }
+#undef ROWS_STAGE
+        }
+        while (k < kend) { request(k, nn, noh, buf ^ 1); ++k; }  // narrow rows: fewer windows than requests
+        dma_wait();     // this wave's requests for row r + 1 have landed ...
+        lds_barrier();  // ... and so have everybody's; everybody is done reading stage `buf`
     }
 
-    // cross-wave reduction (waves 1..3 -> LDS -> wave 0), then one partial tile per workgroup
-    __syncthreads();
-    float(*red)[TM * 32][33] = reinterpret_cast<float(*)[TM * 32][33]>(smem);
-    if (wid > 0) {
+    // cross-wave reduction (slots 1..3 -> LDS -> slot 0), then this filter block's rows of the workgroup's partial tile
+    float(*red)[3][32][33] = reinterpret_cast<float(*)[3][32][33]>(lds);
+    if (slot > 0) {
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) red[wid - 1][tm * 32 + mfma_row(r, lane)][l31] = acc[tm][r];
+        for (int r = 0; r < 16; ++r) red[fh][slot - 1][mfma_row(r, lane)][l31] = acc[r];
     }
     __syncthreads();
-    if (wid == 0) {
-        float* out = a.partials + ((size_t)blockIdx.x * s.groups + g) * (TM * 32) * 32;
+    if (slot == 0) {
+        float* out = a.partials + ((size_t)blockIdx.x * s.groups + g) * a.mp * 32;
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int f = tm * 32 + mfma_row(r, lane);
-                out[f * 32 + l31] = ((acc[tm][r] + red[0][f][l31]) + red[1][f][l31]) + red[2][f][l31];
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int fr = mfma_row(r, lane);
+            out[(fb * 32 + fr) * 32 + l31] = ((acc[r] + red[fh][0][fr][l31]) + red[fh][1][fr][l31]) + red[fh][2][fr][l31];
+        }
     }
 }
 
@@ -403,21 +496,26 @@ void conv_dw_direct_finalize(const float* partials, int nparts, int groups, int 
 
 static bool dw_window_ok(const ConvShape& s) { return window_ok(s) && (s.OW % 8) == 0; }
 
-constexpr int kDwWinR = 7;
-
-static void dw_window_plan(const ConvShape& s, int* strips, int* spb, int* blocks) {
-    *strips = ceil_div(s.OH, kDwWinR);
-    const int total = s.N * *strips;
-    int b = kCUs * 4;
+static void dw_rows_plan(const ConvShape& s, int* rpb, int* blocks) {
+    const int total = s.N * s.OH;
+    const int fblocks = (s.Mg + 31) / 32;
+#if ROWS_TM == 2
+    int b = kCUs;  // one persistent workgroup of 8 waves per CU: both filter blocks, 133 KB of LDS
+    (void)fblocks;
+#else
+    // persistent workgroups, one per block of 32 filters: two per CU at the narrow pitch (75 KB of LDS each), one at the wide
+    int b = ((window_pitch(s) == 232 ? 2 : 1) * kCUs) / fblocks;
+#endif
+    if (b < 1) b = 1;
     if (b > total) b = total;
-    *spb = ceil_div(total, b);
-    *blocks = ceil_div(total, *spb);
+    *rpb = ceil_div(total, b);
+    *blocks = ceil_div(total, *rpb);
 }
 
 size_t conv_dw_window_workspace_floats(const ConvShape& s) {
     if (!dw_window_ok(s)) return 0;
-    int strips, spb, blocks;
-    dw_window_plan(s, &strips, &spb, &blocks);
+    int rpb, blocks;
+    dw_rows_plan(s, &rpb, &blocks);
     const int tm = (s.Mg <= 32) ? 1 : 2;
     return (size_t)blocks * s.groups * tm * 32 * 32;
 }
@@ -426,10 +524,11 @@ size_t conv_dw_window_workspace_floats(const ConvShape& s) {
 bool conv_backward_weights_window(const float* x, const float* dy, float* dw, float* dbias, const ConvShape& s,
                                   float* workspace, size_t workspace_floats) {
     if (!dw_window_ok(s)) return false;
-    int strips, spb, blocks;
-    dw_window_plan(s, &strips, &spb, &blocks);
+    ConvRowsDwArgs ra;
+    int rblocks;
+    dw_rows_plan(s, &ra.rows_per_block, &rblocks);
     const int tm = (s.Mg <= 32) ? 1 : 2;
-    const size_t need = (size_t)blocks * s.groups * tm * 32 * 32;
+    const size_t need = (size_t)rblocks * s.groups * tm * 32 * 32;
     if (workspace == nullptr || workspace_floats < need) {
         fprintf(stderr, "[bcnn_hip] conv backward: workspace too small (%zu floats given, %zu needed)\n", workspace_floats,
                 need);
@@ -437,23 +536,24 @@ bool conv_backward_weights_window(const float* x, const float* dy, float* dw, fl
     }
     KTimer kt(K_CONV_DW, 2.0 * (double)s.total_q * s.Mg * s.K * s.groups,
               4.0 * ((double)s.N * s.C * s.HW + (double)s.F * s.K + (double)s.N * s.F * s.OHOW));
-    ConvWindowDwArgs a;
-    a.x = x; a.dy = dy; a.partials = workspace; a.s = s;
-    a.strips = strips; a.total_strips = s.N * strips; a.strips_per_block = spb;
-    a.bias_col = dbias ? 1 : 0;
-    const dim3 grid((unsigned)blocks, (unsigned)s.groups);
-    const int pitch = window_pitch(s);
-#define LAUNCH3(CGv, Pv, TMv) conv_dw_window_kernel<CGv, kDwWinR, Pv, TMv><<<grid, 256, 0, current_stream()>>>(a)
-#define LAUNCH2(CGv, Pv) do { if (tm == 1) LAUNCH3(CGv, Pv, 1); else LAUNCH3(CGv, Pv, 2); } while (0)
-#define LAUNCH1(CGv) do { if (pitch == 232) LAUNCH2(CGv, 232); else LAUNCH2(CGv, 264); } while (0)
-    if (s.Cg == 1) LAUNCH1(1);
-    else if (s.Cg == 2) LAUNCH1(2);
-    else LAUNCH1(3);
-#undef LAUNCH1
-#undef LAUNCH2
-#undef LAUNCH3
+    ra.x = x; ra.dy = dy; ra.partials = workspace; ra.s = s;
+    ra.total_rows = s.N * s.OH;
+    ra.bias_col = dbias ? 1 : 0;
+    ra.mp = tm * 32;
+    const int pitch = window_pitch(s);  // dy pitch = 4 x odd floats >= OW
+    constexpr int RTM = ROWS_TM;        // blocks of 32 filters per workgroup
+    const int wtm = tm < RTM ? tm : RTM;
+    const dim3 rgrid((unsigned)rblocks, (unsigned)s.groups, (unsigned)(tm / wtm));
+#define RLAUNCH2(CGv, PDv, PXv) do { if (wtm == 1) conv_dw_rows_kernel<CGv, PDv, PXv, 1><<<rgrid, 256, 0, current_stream()>>>(ra); \
+                                     else conv_dw_rows_kernel<CGv, PDv, PXv, RTM><<<rgrid, 256 * RTM, 0, current_stream()>>>(ra); } while (0)
+#define RLAUNCH1(CGv) do { if (pitch == 232) RLAUNCH2(CGv, 228, 232); else RLAUNCH2(CGv, 260, 264); } while (0)
+    if (s.Cg == 1) RLAUNCH1(1);
+    else if (s.Cg == 2) RLAUNCH1(2);
+    else RLAUNCH1(3);
+#undef RLAUNCH1
+#undef RLAUNCH2
     KERNEL_CHECK();
-    conv_dw_direct_finalize(workspace, blocks, s.groups, s.Mg, s.K, tm * 32, a.bias_col, dw, dbias);
+    conv_dw_direct_finalize(workspace, rblocks, s.groups, s.Mg, s.K, tm * 32, ra.bias_col, dw, dbias);
     return true;
 }
 

@@ -52,6 +52,14 @@ __device__ __forceinline__ void dma_row_x4(rsrc_i4 rs, unsigned lds_base, unsign
                  : "s"(lds_base), "v"(voff), "s"(rs), "s"(soff)
                  : "memory", "m0");
 }
+// the same with the non-temporal hint: a stream that is read exactly once should not displace what other kernels keep in
+// L2 / Infinity Cache
+__device__ __forceinline__ void dma_row_x4_nt(rsrc_i4 rs, unsigned lds_base, unsigned voff, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds"
+                 :
+                 : "s"(lds_base), "v"(voff), "s"(rs), "s"(soff)
+                 : "memory", "m0");
+}
 // Workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. every global load the wave
 // has in flight -- fatal for a pipeline that keeps operand requests flying across the barrier.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }

@@ -7,6 +7,6 @@ SRC=$ROOT/bcnn_amd/csrc
 make -C $SRC exp -j8 > /dev/null
 TMP=/tmp/var_$NAME; rm -rf $TMP; mkdir -p $TMP
 cp $SRC/build_exp/*.o $TMP/
-(cd $SRC && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DBCNN_HIP_EXPERIMENT $DEFS -c $FILE.hip -o $TMP/$FILE.o)
+(cd $SRC && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-inline-asm -DBCNN_HIP_EXPERIMENT $DEFS -c $FILE.hip -o $TMP/$FILE.o)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/tools/exp/lib_$NAME.so $TMP/*.o -ldl
 echo built tools/exp/lib_$NAME.so
