@@ -282,7 +282,7 @@ void bcnn_end_net(bcnn_net **pnet) {
     bcnn_hip_free(hc->workspace_gpu);
     free(hc->param_ids);
     free(hc);
-    free(net->learner); free(net->data_aug); free(net->data_loader); free(net->inputs);
+    free(net->learner); free(net->data_aug); bcnn_destroy_data_loader(net); free(net->inputs);
     free(net);
     *pnet = NULL;
 }
@@ -459,7 +459,10 @@ bcnn_status bcnn_compile_net(bcnn_net *net) {
 }
 
 bcnn_status bcnn_set_mode(bcnn_net *net, bcnn_mode mode) {
+    if (net->mode == mode) return BCNN_SUCCESS;
     net->mode = mode;
+    /* TRAIN reads the train streams, VALID / PREDICT the (rewound) test streams: reference bcnn_net.c:490-504 */
+    if (net->data_loader) bcnn_switch_data_handles(net, net->data_loader);
     return BCNN_SUCCESS;
 }
 
@@ -706,19 +709,6 @@ static float current_loss(bcnn_net *net) {
             ++n;
         }
     return n ? loss / n : 0.f;
-}
-
-/* data: only the host->device hook of the reference loader is on the path (bcnn_data.c:413-425) */
-bcnn_status bcnn_loader_next(bcnn_net *net) {
-    for (int i = 0; i < net->num_inputs; ++i) {
-        bcnn_tensor *t = &net->tensors[net->inputs[i]];
-        if (t->data && t->data_gpu)
-            bcnn_hip_memcpy_h2d(t->data_gpu, t->data, (size_t)bcnn_tensor_size(t) * sizeof(float));
-    }
-    bcnn_tensor *lab = &net->tensors[1];
-    if (net->mode != BCNN_MODE_PREDICT && lab->data && lab->data_gpu)
-        bcnn_hip_memcpy_h2d(lab->data_gpu, lab->data, (size_t)bcnn_tensor_size(lab) * sizeof(float));
-    return BCNN_SUCCESS;
 }
 
 float bcnn_train_on_batch(bcnn_net *net) {

@@ -89,7 +89,7 @@ typedef struct {
     bcnn_lr_decay decay_type;
 } bcnn_learner;
 
-/* ---- data loader / augmenter (host only; out of scope beyond the H2D hook) ---------------------- */
+/* ---- data loader / augmenter (host only: bcnn_data.c; reference src/bcnn_data.h:34-131) ---------- */
 typedef struct {
     int input_width;
     int input_height;
@@ -113,6 +113,18 @@ typedef struct {
     int use_precomputed, brightness, apply_fliph, shift_x, shift_y;
     float rotation, scale, contrast, distortion, distortion_kx, distortion_ky;
 } bcnn_data_augmenter;
+
+struct bcnn_net;
+bcnn_status bcnn_loader_next(struct bcnn_net *net);
+void bcnn_convert_img_to_float(const uint8_t *src, int w, int h, int c, float norm_coeff, int swap_to_bgr, float mean_r,
+                               float mean_g, float mean_b, float *dst);
+bcnn_status bcnn_apply_data_augmentation(unsigned char *img, int width, int height, int depth, bcnn_data_augmenter *param,
+                                         unsigned char *buffer);
+bcnn_status bcnn_open_dataset(bcnn_loader *iter, struct bcnn_net *net, const char *train_path, const char *train_path_extra,
+                              const char *test_path, const char *test_path_extra, bool has_extra);
+bcnn_status bcnn_switch_data_handles(struct bcnn_net *net, bcnn_loader *iter);
+void bcnn_fill_input_tensor(struct bcnn_net *net, bcnn_loader *iter, char *path_img, int idx);
+void bcnn_destroy_data_loader(struct bcnn_net *net);
 
 /* ---- device context of a net (reference analogue: bcnn_cuda_context, src/bcnn_net.h:37-42) ------ */
 typedef struct bcnn_hip_context {

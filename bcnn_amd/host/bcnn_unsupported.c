@@ -1,6 +1,6 @@
 /*
  * bcnn_unsupported.c -- entry points of the public API that lie outside the hot path (SURVEY.md
- * section 8: control plane, storage, data loaders, detection head, rarely used layers). They exist so
+ * section 8: control plane, detection head, rarely used layers; the dataset readers are in bcnn_data.c). They exist so
  * that every consumer of the reference links; each returns BCNN_INVALID_PARAMETER (or does nothing)
  * and says so in the log. INTEGRATION.md lists them.
  */
@@ -19,21 +19,6 @@ bcnn_status bcnn_resize_net(bcnn_net *net, int w, int h, int c, int need_realloc
     (void)w; (void)h; (void)c; (void)need_realloc;
     NOT_BUILT(net, "bcnn_resize_net");
 }
-bcnn_status bcnn_set_data_loader(bcnn_net *net, bcnn_loader_type type, const char *a, const char *b, const char *c,
-                                 const char *d) {
-    (void)type; (void)a; (void)b; (void)c; (void)d;
-    NOT_BUILT(net, "bcnn_set_data_loader (dataset readers; feed tensors with bcnn_upload_tensor)");
-}
-void bcnn_augment_data_with_shift(bcnn_net *net, int x, int y) { (void)net; (void)x; (void)y; }
-void bcnn_augment_data_with_scale(bcnn_net *net, float a, float b) { (void)net; (void)a; (void)b; }
-void bcnn_augment_data_with_rotation(bcnn_net *net, float r) { (void)net; (void)r; }
-void bcnn_augment_data_with_flip(bcnn_net *net, int h, int v) { (void)net; (void)h; (void)v; }
-void bcnn_augment_data_with_color_adjustment(bcnn_net *net, int a, int b, float c, float d) {
-    (void)net; (void)a; (void)b; (void)c; (void)d;
-}
-void bcnn_augment_data_with_blobs(bcnn_net *net, int m) { (void)net; (void)m; }
-void bcnn_augment_data_with_distortion(bcnn_net *net, float d) { (void)net; (void)d; }
-
 /* uint8 HWC image -> float CHW, reference bcnn_data.c:70-100 */
 void bcnn_convert_img_to_float(const uint8_t *src, int w, int h, int c, float norm_coeff, int swap_to_bgr,
                                float mean_r, float mean_g, float mean_b, float *dst) {
