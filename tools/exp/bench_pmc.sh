@@ -5,7 +5,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/bpmc; rm -rf $O; mkdir -p $O
 WL=${1:-resnet18}
-ROUND=${ROUND:-r02}
+ROUND=${ROUND:-r03}
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/$C -- python3 $R/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline --no-side-workloads > $O/$C.log 2>&1
   tail -1 $O/$C.log | cut -c1-160
@@ -47,7 +47,7 @@ out = {
    # keys = bench.py's kernel classes. The fused Winograd kernel serves forward AND dX; the LDS-DMA GEMMs serve the
    # direct forward / dX layers and (as a 16-group GEMM) the three-kernel Winograd dW of the 14x14 / 7x7 stages.
    "conv_dw": cls(lambda k: ("conv_dw" in k) and "wino" not in k),
-   "conv_fwd": cls(lambda k: "conv_fwd_direct" in k or "cache_prefetch" in k or "conv_igemm" in k or "conv_pack_weights" in k),
+   "conv_fwd": cls(lambda k: "conv_fwd_direct" in k or "conv_fwd_window" in k or "cache_prefetch" in k or "conv_igemm" in k or "conv_pack_weights" in k),
    "conv_dx": cls(lambda k: "conv_igemm" in k or "conv_pack_weights" in k),
    "conv_fwd_winograd": cls(lambda k: "wino_fused_kernel" in k or "wino_pack_weights" in k),
    "conv_dx_winograd": cls(lambda k: "wino_fused_kernel" in k or "wino_pack_weights" in k),
