@@ -30,7 +30,12 @@ bool conv_backward_weights_direct(const float* x, const float* dy, float* dw, fl
 // conv_window.hip: window-in-LDS kernels for 3x3 / s1 layers with K <= 27 (configs[1])
 bool conv_forward_window(const float* x, const float* w, const float* bias, const float* slopes, float* y, const ConvShape& s,
                          int act, int raw);
+bool conv_forward_stem(const float* x, const float* w, const float* bias, const float* slopes, float* y, const ConvShape& s,
+                       int act, int raw, ConvStats* stats);
 size_t conv_dw_window_workspace_floats(const ConvShape& s);
+size_t conv_dw_stem_workspace_floats(const ConvShape& s);
+bool conv_backward_weights_stem(const float* x, const float* dy, float* dw, float* dbias, const ConvShape& s, float* workspace,
+                                size_t workspace_floats);
 bool conv_backward_weights_window(const float* x, const float* dy, float* dw, float* dbias, const ConvShape& s,
                                   float* workspace, size_t workspace_floats);
 // conv_winograd.hip: F(2x2, 3x3) for the deep 3x3 / s1 layers (false: the layer stays on the direct kernels)
@@ -84,6 +89,7 @@ static void conv_fwd_any(const float* x, const float* w, const float* bias, cons
     if (stats) stats->splits = 0;
     static const int window_on = BCNN_EXP_ENV("BCNN_HIP_NO_WINDOW") ? 0 : 1;  // A/B switch: the LDS-free kernels instead
     if (window_on && conv_forward_window(x, w, bias, slopes, y, s, act, raw)) return;
+    if (window_on && conv_forward_stem(x, w, bias, slopes, y, s, act, raw, stats)) return;
     if (conv_forward_direct(x, w, bias, slopes, y, s, act, raw)) return;
     if (conv_forward_winograd_fused(x, w, bias, slopes, y, s, act, raw, stats)) return;
     if (conv_forward_winograd(x, w, bias, slopes, y, s, act, raw, stats)) return;
@@ -100,7 +106,9 @@ size_t bcnn_hip_conv_workspace_size(int n, int c, int h, int w, int f, int k, in
     size_t m = conv_dw_workspace_floats(s);
     size_t b = conv_dw_direct_workspace_floats(s);
     const size_t d = conv_dw_dma_workspace_floats(s), bw = conv_dw_window_workspace_floats(s);
+    const size_t bs = conv_dw_stem_workspace_floats(s);
     if (bw > b) b = bw;
+    if (bs > b) b = bs;
     size_t wg = conv_dw_winograd_workspace_floats(s);
     const size_t wgf = conv_dw_winograd_fused_workspace_floats(s);
     if (wgf > wg) wg = wgf;
@@ -189,6 +197,8 @@ void bcnn_hip_conv_backward(const float* x, const float* w, const float* bias, c
     static const int dma_on = BCNN_EXP_ENV("BCNN_HIP_NO_DMA") ? 0 : 1;  // A/B switch for profiling
     static const int window_on = BCNN_EXP_ENV("BCNN_HIP_NO_WINDOW") ? 0 : 1;
     if (window_on && conv_backward_weights_window(x, dy, dw, batch_norm ? nullptr : dbias, s, workspace, workspace_elems))
+        bias_done = true;
+    else if (window_on && conv_backward_weights_stem(x, dy, dw, batch_norm ? nullptr : dbias, s, workspace, workspace_elems))
         bias_done = true;
     else if (conv_backward_weights_direct(x, dy, dw, batch_norm ? nullptr : dbias, s, workspace, workspace_elems))
         bias_done = true;

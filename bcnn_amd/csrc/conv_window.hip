@@ -32,6 +32,15 @@
 // independent 4-wave workgroups (one filter block each) 0.345; requests issued in one burst at the top of a row beat
 // requests spread behind the windows' MFMAs (0.345 / 0.415); non-temporal dy requests leave the dW time alone and keep
 // the layer input in the Infinity Cache for the next forward pass (0.37 -> 0.34 ms).
+// stem forward, measured (tools/exp/stem_variants.sh, N = 128): 4-row strips, 3 workgroups per CU 0.303 ms; 8-row strips, 2
+// per CU 0.291; 2 rows 0.36; batches of 4 / 8 / 16 operand reads ahead of the MFMAs 0.292 / 0.291 / 0.296, the compiler's
+// own read-wait-multiply schedule 0.30
+#ifndef STEM_R
+#define STEM_R 8
+#endif
+#ifndef STEM_WAVES
+#define STEM_WAVES 2
+#endif
 #ifndef ROWS_TM
 #define ROWS_TM 1
 #endif
@@ -320,6 +329,283 @@ bool conv_forward_window(const float* x, const float* w, const float* bias, cons
 }
 
 // ================================================================================================
+// forward, 7x7 / stride 2 (the RGB stem of ResNet-18: 3 -> 64 channels, 224^2 -> 112^2)
+// ================================================================================================
+// The same idea for the other few-channel layer of the benchmark. On the LDS-DMA GEMM (conv_igemm_dma.hip, "rowmode") the
+// stem runs at 0.51 of the fp32-MFMA peak: a 64 x 64 tile re-stages its 160 x 64 weight rows by DMA for every 64 pixels
+// and gathers 160 B rows. Here the weights live in registers (a wave owns 32 filters: 74 A operands) and a workgroup stages
+// the 13 input rows of 4 output rows once (36 KB); the 147 taps + the bias fill 74 MFMA steps exactly, ordered as above
+// -- (kc, kc+1) pairs, then the (kr, kr+1) pairs of column 6, then (c, c+1) of tap (6, 6) -- so that four address
+// registers + immediates serve all of them. Tiles are 32 CONSECUTIVE output pixels of the strip (output rows are
+// contiguous in a plane), so OW = 112 leaves no ragged tile; a lane's window origin follows from its (row, column).
+// With a fused batch-norm behind it (raw output) the kernel also emits the per-channel sum / sum of squares of what it
+// stores: per-lane partial sums over the wave's tiles, one half-wave DPP reduction per workgroup.
+template <int CG>
+struct StemSteps {  // taps of 7x7 filters; see WinSteps
+    static constexpr int N = (CG * 49 + 1) / 2;
+    WinStep st[N];
+    constexpr StemSteps() : st{} {
+        int n = 0;
+        for (int c = 0; c < CG; ++c)
+            for (int kr = 0; kr < 7; ++kr)
+                for (int kc = 0; kc < 6; kc += 2) st[n++] = WinStep{c, kr, kc, WD_ELEM, 1};
+        for (int c = 0; c < CG; ++c)
+            for (int kr = 0; kr < 6; kr += 2) st[n++] = WinStep{c, kr, 6, WD_ROW, 1};
+        for (int c = 0; c + 1 < CG; c += 2) st[n++] = WinStep{c, 6, 6, WD_PLANE, 1};
+        if (CG & 1) st[n++] = WinStep{CG - 1, 6, 6, WD_NONE, 0};
+    }
+};
+
+struct ConvStemFwdArgs {
+    const float* x;
+    const float* w;
+    const float* bias;
+    const float* slopes;
+    float* y;
+    float* stats;  // optional [F][splits][2]
+    ConvShape s;
+    int act, add_bias;
+    int strips;    // ceil(OH / R)
+    int splits;    // N * strips * 2
+};
+
+// half-wave sums on the DPP path: lanes 31 and 63 end up with the totals of lanes 0-31 / 32-63
+__device__ __forceinline__ float half_wave_sum_dpp(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));  // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));  // row_mirror: 16-lane sums
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false));  // row_bcast:15 into rows 1, 3
+    return v;
+}
+
+template <int CG, int R, int PITCH, int ACTM, bool STATS>
+__global__ __launch_bounds__(256, STEM_WAVES) void conv_fwd_stem_kernel(const ConvStemFwdArgs a) {
+    constexpr int KSZ = 7, S = 2;
+    constexpr int ROWS = S * (R - 1) + KSZ, PLANE = ROWS * PITCH;
+    constexpr StemSteps<CG> steps{};
+    constexpr int NT = StemSteps<CG>::N;
+    constexpr bool SPARE = (CG & 1) != 0;
+    constexpr int KS = SPARE ? NT : NT + 1;
+    __shared__ __attribute__((aligned(16))) float win[CG * PLANE];
+    const ConvShape& s = a.s;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int fh = wid & 1, tpar = wid >> 1;  // this wave's block of 32 filters, its parity of tiles
+    const int g = blockIdx.y;
+    const int n = (int)blockIdx.x / a.strips, strip = (int)blockIdx.x - n * a.strips;
+    const int oh0 = strip * R;
+    const int rows_here = (s.OH - oh0 < R) ? s.OH - oh0 : R;
+    const rsrc_i4 rx = make_rsrc(a.x, (unsigned)((long long)s.N * s.C * s.HW * 4));
+    const rsrc_i4 ry = make_rsrc(a.y, (unsigned)((long long)s.N * s.F * s.OHOW * 4));
+
+    // window: input rows S*oh0 - pad .. + ROWS, columns -kWinOrg .. ; out-of-image floats arrive as zeros
+    {
+        constexpr int P4 = PITCH / 4;
+        const unsigned chan0 = (unsigned)(n * s.C + g * s.Cg);
+        for (int i = tid; i < CG * ROWS * P4; i += 256) {
+            const int c = i / (ROWS * P4), rem = i - c * (ROWS * P4);
+            const int rr = rem / P4, j = rem - rr * P4;
+            const int ih = S * oh0 - s.pad + rr, iw0 = 4 * j - kWinOrg;
+            const bool ok = (unsigned)ih < (unsigned)s.H && (unsigned)iw0 < (unsigned)s.W;
+            const unsigned off = ok ? ((chan0 + (unsigned)c) * (unsigned)s.HW + (unsigned)(ih * s.W + iw0)) * 4u : kOOB;
+            *reinterpret_cast<buf_f32x4*>(win + (c * ROWS + rr) * PITCH + 4 * j) = buffer_load_f32x4(rx, (int)off, 0, 0);
+        }
+    }
+    // A operand of this wave's 32 filters
+    const float* wg = a.w + (long long)g * s.Mg * s.K;
+    float areg[KS];
+    {
+        const int f = fh * 32 + l31;
+        float bv = 0.f;
+        if (a.add_bias && f < s.Mg) {
+            bv = a.bias[g * s.Mg + f];
+            if (bv == 1.0f) bv = 0.f;  // quirk 2 (bcnn_mat.c:381-383)
+        }
+#pragma unroll
+        for (int st = 0; st < NT; ++st) {
+            const WinStep p = steps.st[st];
+            int c = p.c, kr = p.kr, kc = p.kc;
+            if (hi) {
+                if (p.kind == WD_ELEM) kc += 1;
+                else if (p.kind == WD_ROW) kr += 1;
+                else if (p.kind == WD_PLANE) c += 1;
+            }
+            const int k = c * 49 + kr * 7 + kc;
+            const bool ok = (!hi || p.second) && f < s.Mg;
+            const float v = wg[ok ? (long long)f * s.K + k : 0];
+            areg[st] = ok ? v : ((hi && !p.second) ? bv : 0.f);
+        }
+        if (!SPARE) areg[KS - 1] = hi ? 0.f : bv;
+    }
+    __syncthreads();
+
+    const char* winb = reinterpret_cast<const char*>(win);
+    const int base_col = kWinOrg - s.pad;
+    const unsigned fstride = (unsigned)s.OHOW * 4u;
+    const unsigned y_lane = 4u * (unsigned)hi * fstride + (unsigned)(fh * 32) * fstride;
+    const unsigned y_img = ((unsigned)(n * s.F + g * s.Mg) * (unsigned)s.OHOW + (unsigned)(oh0 * s.OW)) * 4u;
+    const int npix = rows_here * s.OW;           // output pixels of the strip, contiguous in every plane
+    const int ntile = (npix + 31) >> 5;
+    const bool full_m = (s.Mg - fh * 32 >= 32);
+    const bool wave_on = fh * 32 < s.Mg;
+
+    float ssum[16], ssq[16];
+    if (STATS) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ssum[r] = ssq[r] = 0.f;
+    }
+    if (wave_on) {
+        for (int t = tpar; t < ntile; t += 2) {
+            const int q = t * 32 + l31;
+            const bool valid = q < npix;
+            int row = 0, ow = valid ? q : 0;  // R is small: the row by comparison, no division
+#pragma unroll
+            for (int r = 1; r < R; ++r) {
+                const bool past = ow >= s.OW;
+                row += past ? 1 : 0;
+                ow -= past ? s.OW : 0;
+            }
+            const int origin = 4 * (S * row * PITCH + S * ow + base_col);
+            int vb[4];
+            vb[WD_ELEM] = origin + 4 * hi;
+            vb[WD_ROW] = origin + 4 * hi * PITCH;
+            vb[WD_PLANE] = origin + 4 * hi * PLANE;
+            vb[WD_NONE] = origin;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            // B operands in batches of SB steps, one batch ahead of the MFMAs that consume them (left to itself the
+            // compiler reads two values, waits for them, multiplies twice: the LDS latency shows after every pair)
+#ifndef STEM_SB
+#define STEM_SB 8
+#endif
+            constexpr int SB = STEM_SB, NB = (NT + SB - 1) / SB;
+            float bq[2][SB];
+            auto read_batch = [&](int bi, float (&dst)[SB]) {
+#pragma unroll
+                for (int j = 0; j < SB; ++j) {
+                    const int st = bi * SB + j;
+                    if (st < NT) {
+                        const WinStep p = steps.st[st];
+                        dst[j] = *reinterpret_cast<const float*>(winb + vb[p.kind] + 4 * (p.c * PLANE + p.kr * PITCH + p.kc));
+                    }
+                }
+            };
+            read_batch(0, bq[0]);
+#pragma unroll
+            for (int bi = 0; bi < NB; ++bi) {
+                if (bi + 1 < NB) read_batch(bi + 1, bq[(bi + 1) & 1]);
+#ifndef STEM_FREE_SCHED
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+                for (int j = 0; j < SB; ++j) {
+                    const int st = bi * SB + j;
+                    if (st < NT) {
+                        float b = bq[bi & 1][j];
+                        if (SPARE && st == NT - 1) b = hi ? 1.0f : b;
+                        acc = mfma32(areg[st], b, acc);
+                    }
+                }
+#ifndef STEM_FREE_SCHED
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+            }
+            if (!SPARE) acc = mfma32(areg[KS - 1], 1.0f, acc);
+
+            const unsigned ycur = valid ? y_img + (unsigned)q * 4u + y_lane : kOOB;
+            unsigned fs = fstride;
+            asm volatile("" : "+s"(fs));
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = acc[r];
+            if (ACTM == 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = v[r] * (float)(v[r] > 0);
+            } else if (ACTM == 2) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int f = fh * 32 + mfma_row(r, lane);
+                    const float sl = (a.act == BCNN_HIP_ACT_PRELU && f < s.Mg) ? a.slopes[g * s.Mg + f] : 0.f;
+                    v[r] = act_fwd_cheap(v[r], a.act, sl);
+                }
+            }
+            if (STATS) {
+                const float m = valid ? 1.f : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float t0 = v[r] * m;
+                    ssum[r] += t0;
+                    ssq[r] += t0 * t0;
+                }
+            }
+            if (full_m) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    buffer_store_f32(v[r], ry, (int)ycur, (int)((unsigned)((r & 3) + 8 * (r >> 2)) * fs), 0);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int fr = (r & 3) + 8 * (r >> 2);
+                    const unsigned off = (fh * 32 + fr + 4 * hi < s.Mg) ? ycur : kOOB;
+                    buffer_store_f32(v[r], ry, (int)off, (int)((unsigned)fr * fs), 0);
+                }
+            }
+        }
+    }
+    if (STATS && wave_on) {  // slot of this wave: (image, strip, tile parity)
+        const int slot = ((int)blockIdx.x) * 2 + tpar;
+        const rsrc_i4 rst = make_rsrc(a.stats, (unsigned)((size_t)s.F * a.splits * 2 * sizeof(float)));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float sv = half_wave_sum_dpp(ssum[r]), sq = half_wave_sum_dpp(ssq[r]);
+            const int f = fh * 32 + mfma_row(r, lane);  // lanes 31 / 63 hold the sums of their half's filter
+            const unsigned off = (l31 == 31 && f < s.Mg) ? (unsigned)(((g * s.Mg + f) * a.splits + slot) * 8) : kOOB;
+            buffer_store_f32x2(buf_f32x2{sv, sq}, rst, (int)off, 0, 0);
+        }
+    }
+}
+
+static bool stem_ok(const ConvShape& s) {
+    return !s.pointwise && s.ksz == 7 && s.stride == 2 && s.pad <= 4 && s.Cg >= 1 && s.Cg <= 3 && s.Mg <= 64 &&
+           (s.W % 4) == 0 && s.W + kWinOrg <= 232 && 2 * (s.OW - 1) + 7 + (kWinOrg - s.pad) <= 232 && s.total_q > 0 &&
+           (long long)s.N * s.F * s.OHOW < (1LL << 29) && (long long)s.N * s.C * s.HW < (1LL << 29);
+}
+
+// stats (optional, raw mode only): room for F * splits * 2 floats is checked against stats->capacity
+bool conv_forward_stem(const float* x, const float* w, const float* bias, const float* slopes, float* y, const ConvShape& s,
+                       int act, int raw, ConvStats* stats) {
+    if (stats) stats->splits = 0;
+    if (!stem_ok(s)) return false;
+    constexpr int R = STEM_R;
+    ConvStemFwdArgs a;
+    a.x = x; a.w = w; a.bias = bias; a.slopes = slopes; a.y = y; a.s = s;
+    a.act = raw ? BCNN_HIP_ACT_NONE : act;
+    a.add_bias = raw ? 0 : 1;
+    a.strips = ceil_div(s.OH, R);
+    a.splits = s.N * a.strips * 2;
+    const bool want_stats = stats && raw && stats->partials && (size_t)s.F * a.splits * 2 <= stats->capacity;
+    a.stats = want_stats ? stats->partials : nullptr;
+    const dim3 grid((unsigned)(s.N * a.strips), (unsigned)s.groups);
+    const int actm = (a.act == BCNN_HIP_ACT_NONE) ? 0 : (a.act == BCNN_HIP_ACT_RELU ? 1 : 2);
+    KTimer kt(K_CONV_FWD, 2.0 * (double)s.total_q * s.Mg * s.K * s.groups,
+              4.0 * ((double)s.N * s.C * s.HW + (double)s.F * s.K + (double)s.N * s.F * s.OHOW));
+#define SLAUNCH3(CGv, Av, STv) conv_fwd_stem_kernel<CGv, R, 232, Av, STv><<<grid, 256, 0, current_stream()>>>(a)
+#define SLAUNCH2(CGv) do { if (want_stats) SLAUNCH3(CGv, 0, true); else if (actm == 0) SLAUNCH3(CGv, 0, false); \
+                           else if (actm == 1) SLAUNCH3(CGv, 1, false); else SLAUNCH3(CGv, 2, false); } while (0)
+    if (s.Cg == 1) SLAUNCH2(1);
+    else if (s.Cg == 2) SLAUNCH2(2);
+    else SLAUNCH2(3);
+#undef SLAUNCH2
+#undef SLAUNCH3
+    KERNEL_CHECK();
+    if (want_stats) stats->splits = a.splits;
+    return true;
+}
+
+// ================================================================================================
 // dW (+ bias gradient), row-streamed: dy through LDS by LDS-DMA
 // ================================================================================================
 // A first version kept the LDS-free kernel's dy path (conv_direct.hip: 16-byte loads in MFMA fragment order) next to the
@@ -488,6 +774,220 @@ __global__ __launch_bounds__(256 * TM, 1) void conv_dw_rows_kernel(const ConvRow
             out[(fb * 32 + fr) * 32 + l31] = ((acc[r] + red[fh][0][fr][l31]) + red[fh][1][fr][l31]) + red[fh][2][fr][l31];
         }
     }
+}
+
+// ================================================================================================
+// dW (+ bias gradient) of the 7x7 / stride-2 stem, row-streamed
+// ================================================================================================
+// dW[f][tap] = sum over output pixels of dy[f][q] * x[tap's input pixel of q]: 64 x 147 (+ 1 bias column) outputs, reduction
+// over N*OH*OW = 1.6 M pixels. On the LDS-DMA weight-gradient GEMM ("rowmode") the layer runs at 0.40 of the fp32-MFMA
+// peak. Here a persistent workgroup of 8 waves per CU walks its share of the N*OH output rows through the two-stage LDS
+// ring of conv_dw_rows_kernel (one `buffer_load_dwordx4 ... lds` per dy row of a filter plane and per input row, all
+// requested in one burst a row ahead) and multiplies with v_mfma_f32_16x16x4_f32: wave (fb, th) owns filters
+// 16 fb .. 16 fb + 15 and taps 80 th .. 80 th + 79 -- five 16 x 16 accumulators, 20 registers -- so the 64 x 160 result
+// needs no cross-wave reduction and every wave does the same work on every row (7 windows of 16 pixels x 20 MFMAs).
+// The reduction index of a window is permuted so that a lane's four dy values are 16 contiguous bytes (ds_read_b128,
+// conflict-free at a row pitch of 120 floats); its four im2col values per tap block are four ds_read_b32 at stride 2.
+struct ConvStemDwArgs {
+    const float* x;
+    const float* dy;
+    float* partials;  // [nblocks][groups][64][160]
+    ConvShape s;
+    int total_rows;      // N * OH
+    int rows_per_block;
+    int bias_col;
+};
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+constexpr int kStemTapCols = 160;  // 10 blocks of 16: 147 taps, the ones column, zeros
+
+template <int CG, int PD, int PX>
+__global__ __launch_bounds__(512, 1) void conv_dw_stem_kernel(const ConvStemDwArgs a) {
+    constexpr int XR = CG * 7;                          // input rows per stage
+    constexpr int DYS = 64 * PD, XS = XR * PX;          // floats per stage
+    constexpr int XREQ = (XR + 7) / 8, NREQ = 8 + XREQ; // LDS-DMA instructions per wave and row
+    __shared__ __attribute__((aligned(16))) float lds[2 * DYS + 2 * XS + 16];
+    float* cst = lds + 2 * DYS + 2 * XS;  // eight ones, eight zeros
+    const ConvShape& s = a.s;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int fb = wid & 3, th = wid >> 2;
+    const int g = blockIdx.y;
+    const rsrc_i4 rx = make_rsrc(a.x, (unsigned)((long long)s.N * s.C * s.HW * 4));
+    const rsrc_i4 rdy = make_rsrc(a.dy, (unsigned)((long long)s.N * s.F * s.OHOW * 4));
+
+    // padding columns of both kinds of stage are never written again (dy beyond OW, x outside the image): zero everything once
+    for (int i = tid; i < 2 * DYS + 2 * XS; i += 512) lds[i] = 0.f;
+    if (tid < 16) cst[tid] = tid < 8 ? 1.0f : 0.0f;
+    __syncthreads();
+
+    const int K = CG * 49;
+    const unsigned a_lane = (unsigned)(((fb * 16 + l15) * PD + 4 * kq) * 4);
+    unsigned b_lane[5], b_step[5];
+#pragma unroll
+    for (int b = 0; b < 5; ++b) {
+        const int tap = (th * 5 + b) * 16 + l15;
+        const int c = tap / 49, r49 = tap - c * 49, kr = r49 / 7, kc = r49 - kr * 7;
+        const bool is_tap = tap < K;
+        // x[c][2 oh - pad + kr][2 px - pad + kc] with px = 16 w + 4 kq + e  ->  row (c, kr) of the stage, column 2 px + kc + org - pad
+        b_lane[b] = is_tap ? (unsigned)((2 * DYS + (c * 7 + kr) * PX + kc + (kWinOrg - s.pad) + 8 * kq) * 4)
+                           : (unsigned)((2 * DYS + 2 * XS + ((tap == K && a.bias_col) ? 0 : 8)) * 4);
+        b_step[b] = is_tap ? 1u : 0u;
+    }
+    const char* ldsb = reinterpret_cast<const char*>(lds);
+    const unsigned lds0 = lds_offset(lds);
+    const unsigned dma_lane = (unsigned)lane * 16u;
+    const bool dy_lane_on = lane * 4 < s.OW, x_lane_on = lane * 4 < s.W;
+
+    auto request = [&](int k, int n, int oh, int buf) {
+        if (k < 8) {
+            const int f = wid * 8 + k;
+            const bool fok = f < s.Mg;
+            const unsigned soff = __builtin_amdgcn_readfirstlane(
+                fok ? ((unsigned)(n * s.F + g * s.Mg + f) * (unsigned)s.OHOW + (unsigned)(oh * s.OW)) * 4u : 0u);
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((buf * DYS + f * PD) * 4));
+            const unsigned voff = fok ? dma_lane : kOOB;
+            if (dy_lane_on) dma_row_x4_nt(rdy, dst, voff, soff);
+        } else {
+            const int i0 = wid + 8 * (k - 8), i = i0 < XR ? i0 : XR - 1;
+            const int c = i / 7, kr = i - c * 7;
+            const int ih = 2 * oh - s.pad + kr;
+            const bool ok = (unsigned)ih < (unsigned)s.H;
+            const unsigned soff = __builtin_amdgcn_readfirstlane(
+                ((unsigned)(n * s.C + g * s.Cg + c) * (unsigned)s.HW + (unsigned)((ok ? ih : 0) * s.W)) * 4u);
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((2 * DYS + buf * XS + i * PX + kWinOrg) * 4));
+            const unsigned voff = ok ? dma_lane : kOOB;
+            if (x_lane_on) dma_row_x4(rx, dst, voff, soff);
+        }
+    };
+
+    f32x4_t acc[5];
+#pragma unroll
+    for (int b = 0; b < 5; ++b) acc[b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int nwin = (s.OW + 15) >> 4;
+    const int r0 = blockIdx.x * a.rows_per_block;
+    int r1 = r0 + a.rows_per_block;
+    if (r1 > a.total_rows) r1 = a.total_rows;
+
+    if (r0 < r1) {
+        const int n = r0 / s.OH, oh = r0 - n * s.OH;
+        for (int k = 0; k < NREQ; ++k) request(k, n, oh, 0);
+    }
+    dma_wait();
+    lds_barrier();
+    for (int r = r0; r < r1; ++r) {
+        const int buf = (r - r0) & 1;
+        if (r + 1 < r1) {
+            const int nn = (r + 1) / s.OH, noh = (r + 1) - nn * s.OH;
+            for (int k = 0; k < NREQ; ++k) request(k, nn, noh, buf ^ 1);
+        }
+        unsigned va = a_lane + (unsigned)(buf * DYS * 4);
+        unsigned vb[5];
+#pragma unroll
+        for (int b = 0; b < 5; ++b) vb[b] = b_lane[b] + b_step[b] * (unsigned)(buf * XS * 4);
+        // (a hand-made two-stage pipeline of these reads against the MFMAs measured slower: 0.324 against 0.307 ms)
+        for (int w = 0; w < nwin; ++w) {
+            const f32x4_t av = *reinterpret_cast<const f32x4_t*>(ldsb + va);
+            float bv[5][4];
+#pragma unroll
+            for (int b = 0; b < 5; ++b)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bv[b][e] = *reinterpret_cast<const float*>(ldsb + vb[b] + 8 * e);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int b = 0; b < 5; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[b][e], acc[b], 0, 0, 0);
+            va += 64u;
+#pragma unroll
+            for (int b = 0; b < 5; ++b) vb[b] += b_step[b] * 128u;
+        }
+        dma_wait();
+        lds_barrier();
+    }
+    // D: column = lane & 15 (tap of the block), row = 4 * (lane >> 4) + register (filter of the block)
+    float* out = a.partials + ((size_t)blockIdx.x * s.groups + g) * 64 * kStemTapCols;
+#pragma unroll
+    for (int b = 0; b < 5; ++b)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+            out[(fb * 16 + 4 * kq + rr) * kStemTapCols + (th * 5 + b) * 16 + l15] = acc[b][rr];
+}
+
+// dW[g][f][k] += sum_p partials[p][g][f][k] (k < K), dbias[g*Mg + f] += column K; fixed summation order
+__global__ __launch_bounds__(256) void conv_dw_stem_finalize_kernel(const float* __restrict__ partials, int nparts, int groups,
+                                                                   int Mg, int K, int bias_col, float* __restrict__ dw,
+                                                                   float* __restrict__ dbias) {
+    __shared__ float red[16][17];
+    const int kcols = K + (bias_col ? 1 : 0);
+    const int total = groups * Mg * kcols;
+    const int e = blockIdx.x * 16 + (threadIdx.x & 15), pl = threadIdx.x >> 4;
+    float sum = 0.f;
+    int g = 0, f = 0, k = 0;
+    if (e < total) {
+        k = e % kcols;
+        const int t = e / kcols;
+        f = t % Mg; g = t / Mg;
+        for (int p = pl; p < nparts; p += 16) sum += partials[(((size_t)p * groups + g) * 64 + f) * kStemTapCols + k];
+    }
+    red[pl][threadIdx.x & 15] = sum;
+    __syncthreads();
+    if (pl == 0 && e < total) {
+        float tot = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tot += red[i][threadIdx.x & 15];
+        if (k < K) dw[((size_t)g * Mg + f) * K + k] += tot;
+        else dbias[g * Mg + f] += tot;
+    }
+}
+
+static bool dw_stem_ok(const ConvShape& s) {
+    return stem_ok(s) && (s.OW % 4) == 0 && ((s.OW + 15) & ~15) <= 120 && 2 * (((s.OW + 15) & ~15) - 1) + 7 + (kWinOrg - s.pad) <= 232;
+}
+
+static void dw_stem_plan(const ConvShape& s, int* rpb, int* blocks) {
+    const int total = s.N * s.OH;
+    int b = kCUs;  // one persistent workgroup of 8 waves per CU (98 KB of LDS)
+    if (b > total) b = total;
+    *rpb = ceil_div(total, b);
+    *blocks = ceil_div(total, *rpb);
+}
+
+size_t conv_dw_stem_workspace_floats(const ConvShape& s) {
+    if (!dw_stem_ok(s)) return 0;
+    int rpb, blocks;
+    dw_stem_plan(s, &rpb, &blocks);
+    return (size_t)blocks * s.groups * 64 * kStemTapCols;
+}
+
+// false: shape not covered. true: dW accumulated, and the bias gradient too when dbias != NULL.
+bool conv_backward_weights_stem(const float* x, const float* dy, float* dw, float* dbias, const ConvShape& s, float* workspace,
+                                size_t workspace_floats) {
+    if (!dw_stem_ok(s)) return false;
+    ConvStemDwArgs a;
+    int blocks;
+    dw_stem_plan(s, &a.rows_per_block, &blocks);
+    const size_t need = (size_t)blocks * s.groups * 64 * kStemTapCols;
+    if (workspace == nullptr || workspace_floats < need) {
+        fprintf(stderr, "[bcnn_hip] conv backward: workspace too small (%zu floats given, %zu needed)\n", workspace_floats,
+                need);
+        exit(1);
+    }
+    KTimer kt(K_CONV_DW, 2.0 * (double)s.total_q * s.Mg * s.K * s.groups,
+              4.0 * ((double)s.N * s.C * s.HW + (double)s.F * s.K + (double)s.N * s.F * s.OHOW));
+    a.x = x; a.dy = dy; a.partials = workspace; a.s = s;
+    a.total_rows = s.N * s.OH;
+    a.bias_col = dbias ? 1 : 0;
+    const dim3 grid((unsigned)blocks, (unsigned)s.groups);
+    if (s.Cg == 1) conv_dw_stem_kernel<1, 120, 232><<<grid, 512, 0, current_stream()>>>(a);
+    else if (s.Cg == 2) conv_dw_stem_kernel<2, 120, 232><<<grid, 512, 0, current_stream()>>>(a);
+    else conv_dw_stem_kernel<3, 120, 232><<<grid, 512, 0, current_stream()>>>(a);
+    KERNEL_CHECK();
+    const int total = s.groups * s.Mg * (s.K + a.bias_col);
+    conv_dw_stem_finalize_kernel<<<ceil_div(total, 16), 256, 0, current_stream()>>>(workspace, blocks, s.groups, s.Mg, s.K,
+                                                                                    a.bias_col, dw, dbias);
+    KERNEL_CHECK();
+    return true;
 }
 
 // conv_direct.hip

@@ -79,3 +79,51 @@ def test_window_forward_is_deterministic_and_exactly_linear():
     assert bad[1, :, 16:19, 29:32].all()
     bad[1, :, 16:19, 29:32] = False
     assert not bad.any()
+
+
+# ---- 7x7 / stride-2 stem kernel (conv_fwd_stem_kernel) -----------------------------------------------------------------
+STEM_SHAPES = [  # n, c, h, w, f, p, g, act, bn
+    (2, 3, 32, 32, 64, 3, 1, 2, 0),     # OW = 16: a tile spans two output rows
+    (2, 3, 32, 32, 64, 3, 1, 2, 1),     # fused batch-norm: raw output + statistics from the kernel's epilogue
+    (3, 3, 30, 36, 40, 3, 1, 5, 0),     # OH = 15: strips of 4, 4, 4, 3; 40 filters: the second block of 32 is ragged
+    (2, 3, 22, 28, 20, 2, 1, 0, 1),     # padding 2, one ragged block of filters, statistics
+    (2, 1, 20, 24, 8, 3, 1, 2, 0),      # one input channel: 25 steps, bias in the free half-step
+    (2, 2, 20, 24, 33, 3, 1, 0, 0),     # two input channels: 49 tap steps + a step for the bias alone
+    (2, 6, 18, 20, 64, 3, 2, 2, 1),     # two groups of three channels
+    (1, 3, 16, 16, 64, 0, 1, 0, 0),     # VALID
+    (1, 3, 224, 224, 64, 3, 1, 2, 1),   # the ResNet-18 stem, one image
+    # OW % 4 == 0: the weight gradient runs on conv_dw_stem_kernel too (the shapes above fall back to the LDS-DMA GEMM for it)
+    (3, 3, 26, 40, 40, 3, 1, 5, 0),     # OW = 20 (two 16-pixel windows, the second ragged), OH = 13, ragged filters
+    (2, 6, 18, 24, 64, 3, 2, 2, 1),     # OW = 12, two groups, fused batch-norm (no bias gradient from the conv)
+    (5, 1, 14, 32, 16, 3, 1, 0, 0),     # one input channel: 49 taps, ones column 49; 5 images x 7 rows over 35 workgroups
+    (2, 2, 12, 16, 64, 2, 1, 2, 0),     # two input channels, padding 2
+]
+
+
+@pytest.mark.parametrize("shape", STEM_SHAPES)
+def test_stem_kernel_matches_oracle(shape):
+    from oracle import orc_bind as ob
+    from tests import _golden as G
+    from tests import _hip_cases as HC
+    n, c, h, w, f, p, g, act, bn = shape
+    rs = np.random.RandomState(sum(shape))
+    oh, ow = (h + 2 * p - 7) // 2 + 1, (w + 2 * p - 7) // 2 + 1
+    cg = c // g
+    cs = dict(op="conv", n=n, c=c, h=h, w=w, f=f, k=7, s=2, p=p, g=g, bn=bn, act=act, mode=ob.MODE_TRAIN, input_grad=0,
+              x=rs.uniform(-1, 1, (n, c, h, w)).astype(np.float32),
+              wt=(rs.uniform(-1, 1, (f, cg, 7, 7)) * (3.0 / (cg * 49)) ** 0.5).astype(np.float32),
+              bias=rs.uniform(-0.3, 0.3, f).astype(np.float32),
+              dy=(rs.uniform(-1, 1, (n, f, oh, ow)) * 1e-2).astype(np.float32))
+    cs["bias"][1] = 1.0
+    if n != 2:   # beta = 1: gradients are added onto the carry
+        cs["dw0"] = rs.uniform(-1, 1, cs["wt"].shape).astype(np.float32)
+        cs["db0"] = rs.uniform(-1, 1, f).astype(np.float32)
+    if bn:
+        cs.update(run_mean0=rs.uniform(-0.1, 0.1, f).astype(np.float32), run_var0=rs.uniform(0.5, 1.5, f).astype(np.float32),
+                  scales=rs.uniform(0.5, 1.5, f).astype(np.float32))
+    got = HC.run_hip(cs)
+    want = ob.run_oracle(cs)
+    for key in sorted(want):
+        if key in got:
+            err = G.rel_err(got[key], want[key])
+            assert err <= 1e-4, (shape, key, err)
