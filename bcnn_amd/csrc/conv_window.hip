@@ -1046,7 +1046,10 @@ bool conv_backward_weights_window(const float* x, const float* dy, float* dw, fl
     const dim3 rgrid((unsigned)rblocks, (unsigned)s.groups, (unsigned)(tm / wtm));
 #define RLAUNCH2(CGv, PDv, PXv) do { if (wtm == 1) conv_dw_rows_kernel<CGv, PDv, PXv, 1><<<rgrid, 256, 0, current_stream()>>>(ra); \
                                      else conv_dw_rows_kernel<CGv, PDv, PXv, RTM><<<rgrid, 256 * RTM, 0, current_stream()>>>(ra); } while (0)
-#define RLAUNCH1(CGv) do { if (pitch == 232) RLAUNCH2(CGv, 228, 232); else RLAUNCH2(CGv, 260, 264); } while (0)
+#ifndef ROWS_PX
+#define ROWS_PX 232
+#endif
+#define RLAUNCH1(CGv) do { if (pitch == 232) RLAUNCH2(CGv, 228, ROWS_PX); else RLAUNCH2(CGv, 260, 264); } while (0)
     if (s.Cg == 1) RLAUNCH1(1);
     else if (s.Cg == 2) RLAUNCH1(2);
     else RLAUNCH1(3);
