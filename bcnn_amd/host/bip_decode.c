@@ -7,7 +7,8 @@
  *   PNG  8-bit grey / grey+alpha / RGB / RGBA / palette, non-interlaced, any deflate block type (RFC 1950/1951/2083)
  *   PNM  P5 / P6 (binary), P2 / P3 (ASCII), maxval <= 255
  *   BMP  uncompressed 24 / 32 bit (bottom-up or top-down)
- * Anything else (JPEG, interlaced / 16-bit PNG, ...) fails with BIP_UNKNOWN_ERROR and a message on stderr, the
+ *   JPEG baseline / extended / progressive Huffman, 8-bit, 1 or 3 components (bip_jpeg.c: the reference's pixels exactly)
+ * Anything else (interlaced / 16-bit PNG, palette BMP, GIF, ...) fails with BIP_UNKNOWN_ERROR and a message on stderr, the
  * reference's error convention for an undecodable file. */
 #include <stdio.h>
 #include <stdlib.h>
@@ -365,6 +366,8 @@ static bip_status decode_bmp(const uint8_t *buf, size_t len, uint8_t **out, int3
     return BIP_SUCCESS;
 }
 
+uint8_t *bip_decode_jpeg(const uint8_t *buf, size_t len, int32_t *w, int32_t *h, int32_t *depth); /* bip_jpeg.c */
+
 /* ---------------------------------------------------------------------------------------------- entry points */
 bip_status bip_load_image_from_memory(unsigned char *buffer, int buffer_size, uint8_t **src, int32_t *src_width,
                                       int32_t *src_height, int32_t *src_depth) {
@@ -375,7 +378,13 @@ bip_status bip_load_image_from_memory(unsigned char *buffer, int buffer_size, ui
     if (len >= 3 && buffer[0] == 'P' && ((buffer[1] >= '2' && buffer[1] <= '3') || (buffer[1] >= '5' && buffer[1] <= '6')))
         return decode_pnm(buffer, len, src, src_width, src_height, src_depth);
     if (len >= 2 && buffer[0] == 'B' && buffer[1] == 'M') return decode_bmp(buffer, len, src, src_width, src_height, src_depth);
-    fprintf(stderr, "[ERROR] Cannot load image from buffer: format not supported by this build (PNG, PNM and BMP are)\n");
+    if (len >= 4 && buffer[0] == 0xff && buffer[1] == 0xd8) {
+        uint8_t *img = bip_decode_jpeg(buffer, len, src_width, src_height, src_depth);
+        if (img) { *src = img; return BIP_SUCCESS; }
+        fprintf(stderr, "[ERROR] bip_load_image: corrupt or unsupported JPEG stream (8-bit Huffman, 1 or 3 components are supported)\n");
+        return BIP_UNKNOWN_ERROR;
+    }
+    fprintf(stderr, "[ERROR] Cannot load image from buffer: format not supported by this build (PNG, JPEG, PNM and BMP are)\n");
     return BIP_UNKNOWN_ERROR;
 }
 

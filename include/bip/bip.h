@@ -2,7 +2,8 @@
  * the public API call: src/cli/bcnn_cl.c dumps detection overlays with bip_write_image (:1872);
  * examples/inference_benchmark loads its test image with bip_load_image (:530) and fits it to the net input
  * with bip_resize_bilinear (:338). Own dependency-free implementations in bcnn_amd/host/bip_min.c and
- * bip_decode.c (libbip.so): PNG writer (stored deflate blocks), PNG / PNM / BMP reader with a full inflate,
+ * bip_decode.c / bip_jpeg.c (libbip.so): PNG writer (stored deflate blocks), JPEG / PNG / PNM / BMP reader (JPEG with the
+ * reference's -- stb_image's -- exact pixels, PNG with a full inflate),
  * and the reference's fixed-point bilinear resize (bit-identical, tests/test_bip.py); bip_augment.c holds the operations
  * of the online data augmenter (crop / shift, horizontal flip, rotation, contrast, brightness: bcnn_data.c:211-334),
  * byte for byte like the reference (tests/test_data_loader.py). Perlin distortion and random spotlights are not built. */

@@ -161,8 +161,86 @@ def test_pnm_and_bmp_and_unsupported(ours, tmp_path):
     (tmp_path / "a.bmp").write_bytes(hdr + rows)
     st, got = _load(ours, tmp_path / "a.bmp")
     assert st == 0 and np.array_equal(got, img)
-    (tmp_path / "a.jpg").write_bytes(b"\xff\xd8\xff\xe0" + b"\0" * 64)
+    (tmp_path / "a.jpg").write_bytes(b"\xff\xd8\xff\xe0" + b"\0" * 64)                  # a JPEG signature with nothing behind it
     st, _ = _load(ours, tmp_path / "a.jpg")
     assert st == 4                                           # BIP_UNKNOWN_ERROR, like the reference on an undecodable file
     st, _ = _load(ours, tmp_path / "missing.png")
+    assert st == 4
+
+
+# ---- JPEG: byte-identical to the reference's decoder (stb_image 2.08 behind bip_load_image) ----------------------------
+def _jpeg_cases():
+    """(name, kwargs for PIL's encoder, mode, size, kind of content)"""
+    cases = []
+    for size in ((64, 48), (33, 17), (8, 8), (1, 1), (17, 33), (250, 121)):
+        for kind in ("photo", "noise"):
+            for q in (5, 50, 90, 100):
+                for prog in (False, True):
+                    cases.append(("grey", dict(quality=q, progressive=prog), "L", size, kind))
+                    for sub in (0, 1, 2):   # 4:4:4, 4:2:2, 4:2:0
+                        cases.append(("ycc%d" % sub, dict(quality=q, progressive=prog, subsampling=sub), "RGB", size, kind))
+    for size in ((48, 40), (37, 29)):       # 4:1:1 (chroma at a quarter of the width: the nearest-neighbour upsampler)
+        for prog in (False, True):
+            cases.append(("ycc411", dict(quality=80, progressive=prog, subsampling="4:1:1"), "RGB", size, "photo"))
+    for size in ((40, 24), (37, 29)):       # restart intervals: the predictors and the bit reservoir are reset at RSTn
+        for prog in (False, True):
+            for rst in (1, 3):
+                cases.append(("restart", dict(quality=75, progressive=prog, subsampling=2, restart_marker_blocks=rst), "RGB",
+                              size, "photo"))
+    return cases
+
+
+def test_jpeg_pixels_are_byte_identical_to_the_reference(ours, ref, tmp_path):
+    """The lossy stages of JPEG (inverse DCT, chroma upsampling, colour conversion) are implementation-defined; a drop-in
+    loader has to reproduce the reference's. ~400 files from PIL's encoder: baseline and progressive, three subsamplings,
+    grey, qualities 5..100, sizes that are not multiples of the MCU, restart intervals; plus two photographs written by
+    other encoders (sklearn's sample images)."""
+    PIL = pytest.importorskip("PIL")
+    from PIL import Image, ImageFile
+    ImageFile.MAXBLOCK = 1 << 24
+    rs = np.random.RandomState(0)
+    photo = None
+    for cand in ("sklearn/datasets/images/china.jpg", "sklearn/datasets/images/flower.jpg"):
+        for base in __import__("sys").path:
+            p = os.path.join(base, cand)
+            if os.path.exists(p):
+                photo = photo or Image.open(p).convert("RGB")
+                st, a = _load(ours, p)
+                st2, b = _load(ref, p)
+                assert st == 0 and st2 == 0 and a.shape == b.shape and np.array_equal(a, b), cand
+                break
+    n = 0
+    for name, kw, mode, size, kind in _jpeg_cases():
+        w, h = size
+        if kind == "photo" and photo is not None:
+            img = photo.resize(size)
+        else:
+            img = Image.fromarray(rs.randint(0, 256, (h, w, 3)).astype(np.uint8))
+        path = tmp_path / "t.jpg"
+        try:
+            img.convert(mode).save(str(path), "JPEG", **kw)
+        except (TypeError, ValueError, OSError):       # an encoder option this PIL does not have
+            continue
+        st, a = _load(ours, path)
+        st2, b = _load(ref, path)
+        assert st == 0 and st2 == 0, (name, kw, size)
+        assert a.shape == b.shape == (h, w, 1 if mode == "L" else 3), (name, kw, size, a.shape, b.shape)
+        assert np.array_equal(a, b), (name, kw, size, int(np.abs(a.astype(int) - b.astype(int)).max()))
+        n += 1
+    assert n >= 390
+
+
+def test_jpeg_unsupported_and_truncated_streams_fail_cleanly(ours, tmp_path):
+    PIL = pytest.importorskip("PIL")
+    from PIL import Image
+    rs = np.random.RandomState(3)
+    img = Image.fromarray(rs.randint(0, 256, (24, 40, 3)).astype(np.uint8))
+    img.save(str(tmp_path / "ok.jpg"), "JPEG", quality=80)
+    data = (tmp_path / "ok.jpg").read_bytes()
+    for cut in (2, 20, len(data) // 2, len(data) - 2):     # truncated at the header, in the tables, mid-scan, before EOI
+        (tmp_path / "cut.jpg").write_bytes(data[:cut])
+        st, _ = _load(ours, tmp_path / "cut.jpg")
+        assert st == 4, cut
+    img.convert("CMYK").save(str(tmp_path / "cmyk.jpg"), "JPEG")   # four components: refused, like stb_image 2.08
+    st, _ = _load(ours, tmp_path / "cmyk.jpg")
     assert st == 4

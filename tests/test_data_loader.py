@@ -259,6 +259,16 @@ def test_list_loaders_match_reference(tmp_path):
         assert bip.bip_write_image(p.encode(), _u8(img), w, h, 3, w * 3) == 0
         lines_c.append("%s %d" % (p, k % 4))
         lines_r.append("%s %.3f %.3f %.3f" % (p, *rs.uniform(-1, 1, 3)))
+    try:      # the usual case in practice: JPEG files (decoded to the same pixels as the reference's stb_image, tests/test_bip.py)
+        from PIL import Image
+        for k in range(3):
+            p = str(tmp_path / ("photo%d.jpg" % k))
+            Image.fromarray(rs.randint(0, 256, (18 + 2 * k, 22, 3)).astype(np.uint8)).save(p, "JPEG", quality=70 + 10 * k,
+                                                                                          subsampling=k, progressive=bool(k & 1))
+            lines_c.append("%s %d" % (p, k))
+            lines_r.append("%s %.3f %.3f %.3f" % (p, *rs.uniform(-1, 1, 3)))
+    except ImportError:
+        pass
     lines_c.insert(3, str(tmp_path / "missing.png") + " 1")   # unreadable sample: skipped, the next one takes its slot
     (tmp_path / "c.txt").write_text("\n".join(lines_c) + "\n")
     (tmp_path / "r.txt").write_text("\n".join(lines_r) + "\n")
