@@ -97,7 +97,8 @@ def test_bip_augmentation_primitives_are_byte_identical_to_the_reference():
     dict(range_shift_x=3, range_shift_y=3, use_precomputed=1, shift_x=-2, shift_y=1),
 ], ids=["mnist_example", "cifar10_example_with_ini_flip", "everything", "flip_flag_alone", "precomputed"])
 def test_apply_data_augmentation_draws_and_bytes_match_the_reference(cfg):
-    mine = C.CDLL(os.path.join(LIB, "libbcnn.so"))
+    from bcnn_amd import capi
+    mine = capi.lib()     # (imports torch before the HIP back-end: one HIP runtime per process, bcnn_amd/_lib.py)
     ref = rb.lib()
     rs = np.random.RandomState(7)
     for (w, h, d) in ((28, 28, 1), (32, 32, 3)):
