@@ -106,11 +106,11 @@ static int huff_build(jhuff *h, const int counts[16], const uint8_t *symbols, in
         h->first_index[len] = k;
         h->first_code[len] = code << (16 - len);
         for (int i = 0; i < counts[len - 1]; ++i, ++k, ++code) {
+            if (code >= (1 << len) || k >= nsym) return 0; /* more codes than the length can hold / than symbols given */
             if (len <= 9)
                 for (int fill = 0; fill < (1 << (9 - len)); ++fill)
                     h->quick[(code << (9 - len)) + fill] = (uint16_t)((len << 8) | symbols[k]);
         }
-        if (code > (1 << len)) return 0; /* more codes than the length can hold */
         h->end_code[len] = code << (16 - len);
         code <<= 1;
     }
@@ -142,44 +142,53 @@ static int huff_symbol(jdec *d, const jhuff *h) {
 #define FIX(x) ((int)((x) * 4096 + 0.5))
 static uint8_t clamp255(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
 
-/* one 8-point pass: even part in e0..e3, odd part in o0..o3 (both scaled by 4096); the caller combines e[i] +- o[3-i] */
-static void idct8(int s0, int s1, int s2, int s3, int s4, int s5, int s6, int s7, int e[4], int o[4]) {
-    const int z = (s2 + s6) * FIX(0.5411961f);
-    const int a = z + s6 * FIX(-1.847759065f), b = z + s2 * FIX(0.765366865f);
-    const int c = (s0 + s4) << 12, dd = (s0 - s4) << 12;
+/* one 8-point pass: even part in e[0..3], odd part in o[0..3] (both scaled by 4096); the caller combines e[i] +- o[3-i].
+ * All arithmetic is modulo 2^32 (unsigned), which is what the reference's int arithmetic amounts to on every target it
+ * runs on and keeps a corrupt stream's oversized coefficients from being undefined behaviour here. */
+typedef uint32_t u32;
+#define UMUL(a, k) ((u32)(a) * (u32)(int32_t)(k))
+static void idct8(int32_t s0, int32_t s1, int32_t s2, int32_t s3, int32_t s4, int32_t s5, int32_t s6, int32_t s7, u32 e[4],
+                  u32 o[4]) {
+    const u32 z = UMUL((u32)s2 + (u32)s6, FIX(0.5411961f));
+    const u32 a = z + UMUL(s6, FIX(-1.847759065f)), b = z + UMUL(s2, FIX(0.765366865f));
+    const u32 c = ((u32)s0 + (u32)s4) * 4096u, dd = ((u32)s0 - (u32)s4) * 4096u;
     e[0] = c + b; e[3] = c - b; e[1] = dd + a; e[2] = dd - a;
-    const int p3 = s7 + s3, p4 = s5 + s1, p1 = s7 + s1, p2 = s5 + s3;
-    const int p5 = (p3 + p4) * FIX(1.175875602f);
-    const int q1 = p5 + p1 * FIX(-0.899976223f), q2 = p5 + p2 * FIX(-2.562915447f);
-    const int q3 = p3 * FIX(-1.961570560f), q4 = p4 * FIX(-0.390180644f);
-    o[3] = s1 * FIX(1.501321110f) + q1 + q4;
-    o[2] = s3 * FIX(3.072711026f) + q2 + q3;
-    o[1] = s5 * FIX(2.053119869f) + q2 + q4;
-    o[0] = s7 * FIX(0.298631336f) + q1 + q3;
+    const u32 p3 = (u32)s7 + (u32)s3, p4 = (u32)s5 + (u32)s1, p1 = (u32)s7 + (u32)s1, p2 = (u32)s5 + (u32)s3;
+    const u32 p5 = UMUL(p3 + p4, FIX(1.175875602f));
+    const u32 q1 = p5 + UMUL(p1, FIX(-0.899976223f)), q2 = p5 + UMUL(p2, FIX(-2.562915447f));
+    const u32 q3 = UMUL(p3, FIX(-1.961570560f)), q4 = UMUL(p4, FIX(-0.390180644f));
+    o[3] = UMUL(s1, FIX(1.501321110f)) + q1 + q4;
+    o[2] = UMUL(s3, FIX(3.072711026f)) + q2 + q3;
+    o[1] = UMUL(s5, FIX(2.053119869f)) + q2 + q4;
+    o[0] = UMUL(s7, FIX(0.298631336f)) + q1 + q3;
+}
+static int32_t sar(u32 v, int n) { /* arithmetic shift right of the two's-complement value */
+    return (int32_t)(v >> n) | ((v & 0x80000000u) ? (int32_t)(~0u << (32 - n)) : 0);
 }
 
 static void idct_block(uint8_t *out, int pitch, const int16_t c[64]) {
-    int mid[64], e[4], o[4];
+    int32_t mid[64];
+    u32 e[4], o[4];
     for (int x = 0; x < 8; ++x) { /* columns; 2 extra bits of precision are kept */
         if (!(c[x + 8] | c[x + 16] | c[x + 24] | c[x + 32] | c[x + 40] | c[x + 48] | c[x + 56])) {
-            const int dc = c[x] << 2;
+            const int32_t dc = c[x] * 4;
             for (int y = 0; y < 8; ++y) mid[8 * y + x] = dc;
             continue;
         }
         idct8(c[x], c[x + 8], c[x + 16], c[x + 24], c[x + 32], c[x + 40], c[x + 48], c[x + 56], e, o);
         for (int i = 0; i < 4; ++i) {
-            mid[8 * i + x] = (e[i] + 512 + o[3 - i]) >> 10;
-            mid[8 * (7 - i) + x] = (e[i] + 512 - o[3 - i]) >> 10;
+            mid[8 * i + x] = sar(e[i] + 512u + o[3 - i], 10);
+            mid[8 * (7 - i) + x] = sar(e[i] + 512u - o[3 - i], 10);
         }
     }
     for (int y = 0; y < 8; ++y) { /* rows: remove 12 + 2 + 3 bits, re-centre on 128 */
-        const int *m = mid + 8 * y;
+        const int32_t *m = mid + 8 * y;
         idct8(m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7], e, o);
         uint8_t *row = out + (size_t)y * pitch;
         for (int i = 0; i < 4; ++i) {
-            const int base = e[i] + 65536 + (128 << 17);
-            row[i] = clamp255((base + o[3 - i]) >> 17);
-            row[7 - i] = clamp255((base - o[3 - i]) >> 17);
+            const u32 base = e[i] + 65536u + (128u << 17);
+            row[i] = clamp255(sar(base + o[3 - i], 17));
+            row[7 - i] = clamp255(sar(base - o[3 - i], 17));
         }
     }
 }
@@ -217,7 +226,7 @@ static int block_prog_dc(jdec *d, jcomp *c, int16_t blk[64]) {
         const int t = huff_symbol(d, &d->dc[c->dc_table]);
         if (t < 0 || t > 15) return 0;
         c->dc_pred += t ? take_signed(d, t) : 0;
-        blk[0] = (int16_t)(c->dc_pred << d->al);
+        blk[0] = (int16_t)(c->dc_pred * (1 << d->al));
     } else if (take_bit(d)) { /* refinement: one more bit */
         blk[0] += (int16_t)(1 << d->al);
     }
@@ -248,7 +257,7 @@ static int block_prog_ac(jdec *d, jcomp *c, int16_t blk[64]) {
             }
             k += run;
             if (k > 63) return 0;
-            blk[k_unzig[k++]] = (int16_t)(take_signed(d, size) << d->al);
+            blk[k_unzig[k++]] = (int16_t)(take_signed(d, size) * (1 << d->al));
         }
         return 1;
     }
