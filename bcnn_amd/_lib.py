@@ -64,6 +64,13 @@ SIGNATURES = {
     "bcnn_hip_avgpool_backward": (None, [vp, vp, i, i, i, i]),
     "bcnn_hip_depthwise_forward": (None, [vp, vp, vp, vp] + [i] * 8),
     "bcnn_hip_depthwise_backward": (None, [vp] * 7 + [i] * 9),
+    "bcnn_hip_depthwise_stats_size": (sz, [i] * 7),
+    "bcnn_hip_depthwise_forward_stats": (i, [vp, vp, vp, vp] + [i] * 8 + [vp, sz]),
+    "bcnn_hip_batchnorm_forward_stats": (None, [vp] * 10 + [i, i, i, i, i, vp, i]),
+    "bcnn_hip_depthwise_bn_fusable": (i, [i] * 8),
+    "bcnn_hip_batchnorm_backward_sums": (None, [vp] * 9 + [i, i, i]),
+    "bcnn_hip_depthwise_backward_bn": (None, [vp] * 7 + [i] * 9 + [vp] * 5),
+    "bcnn_hip_batchnorm_backward_apply": (None, [vp] * 8 + [i, i, i]),
     "bcnn_hip_sgd_update": (None, [vp, vp, vp, vp, sz, sz, i, f, f, f]),
     "bcnn_hip_sgd_update_chunks": (None, [vp, i, i, f, f, f]),
     "bcnn_hip_zero_chunks": (None, [vp, i]),

@@ -9,6 +9,7 @@
 // reference CPU path makes ~10 forward sweeps (two copies, x_norm, scale and bias passes).
 #include "chan_reduce.h"
 #include "conv_common.h"
+#include "bn_math.h"
 
 namespace bcnn_hip {
 
@@ -95,21 +96,6 @@ struct BnApplyArgs {
     int C, HW, predict, act;
     long long total;
 };
-
-__device__ __forceinline__ float bn_one(float x, float mean, float rs, float sc, float b, int predict,
-                                        int act, float* xn_out) {
-    float v;
-    if (predict) {
-        v = __fadd_rn(__fmul_rn(x, sc), b);  // scale_and_add_bias, bcnn_batchnorm_layer.c:183-194
-    } else {
-        v = __fdiv_rn(__fsub_rn(x, mean), rs);
-        *xn_out = v;
-        if (sc == 0.0f) v = 0.f;             // bcnn_scal: a == 0 -> memset
-        else if (sc != 1.0f) v = __fmul_rn(v, sc);
-        if (b != 0.0f && b != 1.0f) v = __fadd_rn(v, b);  // bcnn_add_scalar quirk
-    }
-    return act_fwd_cheap(v, act, 0.f);
-}
 
 struct BnApplyBody {
     BnApplyArgs a;
@@ -227,17 +213,6 @@ struct BnBwdApplyArgs {
     long long total;
 };
 
-__device__ __forceinline__ float bn_bwd_one(float g, float yv, float xv, float mean, float rs, float sc,
-                                            float dm_m, float dv, float fM, int act) {
-    if (act != BCNN_HIP_ACT_NONE) g *= act_bwd_cheap(yv, act, 0.f);
-    if (sc == 0.0f) g = 0.f;
-    else if (sc != 1.0f) g = __fmul_rn(g, sc);
-    // grad*1.0f/sqrtf(var+1e-5) + dvar*2*(x-mean)/M + dmean/M     (bcnn_batchnorm_layer.c:292-296)
-    const float t1 = __fdiv_rn(g, rs);
-    const float t2 = __fdiv_rn(__fmul_rn(__fmul_rn(dv, 2.0f), __fsub_rn(xv, mean)), fM);
-    return __fadd_rn(__fadd_rn(t1, t2), dm_m);
-}
-
 struct BnBwdApplyBody {
     BnBwdApplyArgs a;
     bool al;
@@ -328,9 +303,49 @@ void bcnn_hip_batchnorm_forward(const float* x, float* y, float* run_mean, float
                            mode, act, nullptr);
 }
 
+void bcnn_hip_batchnorm_forward_stats(const float* x, float* y, float* run_mean, float* run_var, const float* scales,
+                                      const float* bias, float* saved_mean, float* saved_var, float* x_norm,
+                                      float* workspace, int n, int c, int hw, int mode, int act, const float* stats,
+                                      int splits) {
+    ConvStats st;
+    st.partials = const_cast<float*>(stats); st.splits = stats ? splits : 0; st.capacity = 0;
+    batchnorm_forward_impl(x, y, run_mean, run_var, scales, bias, saved_mean, saved_var, x_norm, workspace, n, c, hw,
+                           mode, act, &st);
+}
+
 }  // extern "C"
 
 namespace bcnn_hip {
+// S1 = sum g', S2 = sum g' (x - mean) per channel -> dbias, dscales, dmean, dvar (the first sweep of the backward pass)
+static void batchnorm_backward_sums(const float* dy, const float* y, int act, const float* scales, float* dscales,
+                                    float* dbias, const float* saved_mean, const float* saved_var, float* dmean,
+                                    float* dvar, const float* workspace, int n, int c, int hw, const float* fwd_bias) {
+    const long long M = (long long)n * hw;
+    const int splits = chan_splits(c, M);
+    float* part = reduce_scratch((size_t)c * splits * 2);
+    BwdSumsF f;
+    f.dy = dy; f.y = y; f.x = workspace; f.mean = saved_mean; f.act = act; f.C = c; f.HW = hw;
+    f.fwd_bias = fwd_bias; f.var = saved_var; f.scale = scales;
+    launch_chan_reduce<2>(f, c, hw, M, splits, part);
+    bn_bwd_finalize_kernel<<<ceil_div(c, 256), 256, 0, current_stream()>>>(part, c, splits, scales, saved_var,
+                                                                          dbias, dscales, dmean, dvar);
+    KERNEL_CHECK();
+}
+
+// dy <- scale * g' / sqrt(var + 1e-5) + dvar * 2 (x - mean) / M + dmean / M, copied to dx (the second sweep)
+static void batchnorm_backward_apply(float* dy, float* dx, const float* y, int act, const float* scales,
+                                     const float* saved_mean, const float* saved_var, const float* dmean,
+                                     const float* dvar, const float* workspace, int n, int c, int hw,
+                                     const float* fwd_bias) {
+    const long long M = (long long)n * hw, total = M * c;
+    BnBwdApplyArgs a;
+    a.dy = dy; a.dx = (dx && dx != dy) ? dx : nullptr; a.y = y; a.x = workspace;
+    a.mean = saved_mean; a.var = saved_var; a.scale = scales; a.dmean = dmean; a.dvar = dvar;
+    a.C = c; a.HW = hw; a.act = act; a.M = (int)M; a.total = total; a.fwd_bias = fwd_bias;
+    auto al16 = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    launch_chan_map(BnBwdApplyBody{a, al16(dy) && al16(a.dx) && al16(workspace) && al16(y)}, n, c, hw);
+}
+
 // fwd_bias (optional): the bias the forward pass added; with it the forward output is recomputed from the
 // workspace copy of the input instead of read from y (fused activation backward only).
 void batchnorm_backward_impl(float* dy, float* dx, const float* y, int act, const float* scales, float* dscales,
@@ -345,25 +360,31 @@ void batchnorm_backward_impl(float* dy, float* dx, const float* y, int act, cons
         bcnn_hip_activation_backward(y, dy, (size_t)total, act, nullptr, nullptr, hw, c);
         act = BCNN_HIP_ACT_NONE;
     }
-    const int splits = chan_splits(c, M);
-    float* part = reduce_scratch((size_t)c * splits * 2);
-    BwdSumsF f;
-    f.dy = dy; f.y = y; f.x = workspace; f.mean = saved_mean; f.act = act; f.C = c; f.HW = hw;
-    f.fwd_bias = fwd_bias; f.var = saved_var; f.scale = scales;
-    launch_chan_reduce<2>(f, c, hw, M, splits, part);
-    bn_bwd_finalize_kernel<<<ceil_div(c, 256), 256, 0, current_stream()>>>(part, c, splits, scales, saved_var,
-                                                                          dbias, dscales, dmean, dvar);
-    KERNEL_CHECK();
-    BnBwdApplyArgs a;
-    a.dy = dy; a.dx = (dx && dx != dy) ? dx : nullptr; a.y = y; a.x = workspace;
-    a.mean = saved_mean; a.var = saved_var; a.scale = scales; a.dmean = dmean; a.dvar = dvar;
-    a.C = c; a.HW = hw; a.act = act; a.M = (int)M; a.total = total; a.fwd_bias = fwd_bias;
-    auto al16 = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    launch_chan_map(BnBwdApplyBody{a, al16(dy) && al16(a.dx) && al16(workspace) && al16(y)}, n, c, hw);
+    batchnorm_backward_sums(dy, y, act, scales, dscales, dbias, saved_mean, saved_var, dmean, dvar, workspace, n, c, hw,
+                            fwd_bias);
+    batchnorm_backward_apply(dy, dx, y, act, scales, saved_mean, saved_var, dmean, dvar, workspace, n, c, hw, fwd_bias);
 }
 }  // namespace bcnn_hip
 
 extern "C" {
+
+void bcnn_hip_batchnorm_backward_sums(const float* dy, const float* scales, float* dscales, float* dbias,
+                                      const float* saved_mean, const float* saved_var, float* dmean, float* dvar,
+                                      const float* x, int n, int c, int hw) {
+    const long long total = (long long)n * hw * c;
+    if (!total) return;
+    KTimer kt(K_BN_BWD, 0.0, 4.0 * 2.0 * (double)total);  // one pass over (dy, x)
+    batchnorm_backward_sums(dy, nullptr, BCNN_HIP_ACT_NONE, scales, dscales, dbias, saved_mean, saved_var, dmean, dvar, x,
+                            n, c, hw, nullptr);
+}
+
+void bcnn_hip_batchnorm_backward_apply(float* dy, float* dx, const float* scales, const float* saved_mean,
+                                       const float* saved_var, const float* dmean, const float* dvar, const float* x,
+                                       int n, int c, int hw) {
+    if (!(long long)n * hw * c) return;
+    batchnorm_backward_apply(dy, dx, nullptr, BCNN_HIP_ACT_NONE, scales, saved_mean, saved_var, dmean, dvar, x, n, c, hw,
+                             nullptr);
+}
 
 void bcnn_hip_batchnorm_backward(float* dy, float* dx, const float* y, int act, const float* scales,
                                  float* dscales, float* dbias, const float* saved_mean,

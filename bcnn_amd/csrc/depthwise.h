@@ -1,0 +1,35 @@
+// depthwise.h -- shapes and entry points shared by the depthwise-convolution kernels (depthwise.hip: register-window
+// kernels for any shape; depthwise_lds.hip: the LDS-staged 3x3 kernels).
+#pragma once
+#include "conv_common.h"
+
+namespace bcnn_hip {
+
+struct DwShape {
+    int N, C, H, W, OH, OW, ksz, stride, pad;
+};
+
+// Batch-norm coefficients of the stand-alone batch-norm node that consumes a depthwise layer's output, for the backward
+// kernel that applies bcnn_batchnorm_layer.c:292-296 to the incoming gradient on the fly (device pointers, [C] each).
+struct DwBnBwd {
+    const float* dz;      // gradient with respect to the batch-norm OUTPUT
+    const float* mean;    // saved batch mean
+    const float* var;     // saved batch variance
+    const float* scale;
+    const float* dmean;   // written by bn_bwd_finalize_kernel
+    const float* dvar;
+};
+
+// depthwise_lds.hip. All return false (and launch nothing) when the shape is not theirs.
+bool depthwise_lds_ok(const DwShape& s);
+size_t depthwise_lds_stats_floats(const DwShape& s);    // capacity a ConvStats needs for depthwise_forward_lds
+size_t depthwise_lds_partial_floats(const DwShape& s);  // scratch of depthwise_backward_lds
+// y = act(dwconv(x) + bias); with `stats` also the per-channel sum / sum of squares partials of y
+bool depthwise_forward_lds(const float* x, const float* w, const float* bias, float* y, const DwShape& s, int act,
+                           ConvStats* stats);
+// g = dy * act'(y) (written back over dy when `write_back`), or with `bn` g = BNbackward(bn->dz) * act'(y) and dy is not
+// touched; dbias += sum g; dw += sum x * g; dx = (overwrite ? 0 : dx) + w * g
+bool depthwise_backward_lds(const float* x, const float* w, const float* y, float* dy, float* dx, float* dw, float* dbias,
+                            const DwShape& s, int act, int overwrite, int write_back, const DwBnBwd* bn);
+
+}  // namespace bcnn_hip

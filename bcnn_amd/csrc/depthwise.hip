@@ -7,14 +7,12 @@
 // All reductions are two-level and deterministic (the reference CUDA kernel races at
 // bcnn_depthwise_conv_layer.cu:113).
 #include "chan_reduce.h"
+#include "depthwise.h"
 
 namespace bcnn_hip {
 
 void activation_backward_grad_bias(const float* y, float* dy, float* dbias, int n, int c, int hw, int act);  // blas1.hip
 
-struct DwShape {
-    int N, C, H, W, OH, OW, ksz, stride, pad;
-};
 
 __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ bias, float* __restrict__ y,
@@ -527,6 +525,10 @@ void bcnn_hip_depthwise_forward(const float* x, const float* w, const float* bia
     if (total <= 0) return;
     KTimer kt(K_DEPTHWISE_FWD, 2.0 * (double)total * k * k, 4.0 * ((double)n * c * h * wd + (double)total));
     const int fused = act_is_cheap(act) ? act : BCNN_HIP_ACT_NONE;
+    if (depthwise_forward_lds(x, w, bias, y, s, fused, nullptr)) {
+        if (fused != act) bcnn_hip_activation_forward(y, (size_t)total, act, nullptr, s.OH * s.OW, c);
+        return;
+    }
     const unsigned gpr = (unsigned)ceil_div(s.OW, 4);
     constexpr int VR = DW_VR;
     const unsigned rgs = (unsigned)ceil_div(s.OH, VR);
@@ -549,6 +551,50 @@ void bcnn_hip_depthwise_forward(const float* x, const float* w, const float* bia
     if (fused != act) bcnn_hip_activation_forward(y, (size_t)total, act, nullptr, s.OH * s.OW, c);
 }
 
+size_t bcnn_hip_depthwise_stats_size(int n, int c, int h, int wd, int k, int stride, int pad) {
+    if (stride < 1 || k < 1) return 0;
+    DwShape s{n, c, h, wd, (h + 2 * pad - k) / stride + 1, (wd + 2 * pad - k) / stride + 1, k, stride, pad};
+    return depthwise_lds_stats_floats(s);
+}
+
+int bcnn_hip_depthwise_forward_stats(const float* x, const float* w, const float* bias, float* y, int n, int c, int h,
+                                     int wd, int k, int stride, int pad, int act, float* stats, size_t stats_floats) {
+    DwShape s{n, c, h, wd, (h + 2 * pad - k) / stride + 1, (wd + 2 * pad - k) / stride + 1, k, stride, pad};
+    const long long total = (long long)n * c * s.OH * s.OW;
+    if (total > 0 && stats && act_is_cheap(act)) {
+        // the statistics are those of the STORED output, so the activation has to be fused in the kernel
+        KTimer kt(K_DEPTHWISE_FWD, 2.0 * (double)total * k * k, 4.0 * ((double)n * c * h * wd + (double)total));
+        ConvStats st;
+        st.partials = stats; st.capacity = stats_floats; st.splits = 0;
+        if (depthwise_forward_lds(x, w, bias, y, s, act, &st)) return st.splits;
+    }
+    bcnn_hip_depthwise_forward(x, w, bias, y, n, c, h, wd, k, stride, pad, act);
+    return 0;
+}
+
+int bcnn_hip_depthwise_bn_fusable(int n, int c, int h, int wd, int k, int stride, int pad, int act) {
+    if (stride < 1 || k < 1) return 0;
+    DwShape s{n, c, h, wd, (h + 2 * pad - k) / stride + 1, (wd + 2 * pad - k) / stride + 1, k, stride, pad};
+    return depthwise_lds_ok(s) && act_bwd_is_cheap(act) && act != BCNN_HIP_ACT_PRELU;
+}
+
+void bcnn_hip_depthwise_backward_bn(const float* x, const float* w, const float* y, const float* dz, float* dx, float* dw,
+                                    float* dbias, int n, int c, int h, int wd, int k, int stride, int pad, int act,
+                                    int overwrite, const float* bn_mean, const float* bn_var, const float* bn_scales,
+                                    const float* bn_dmean, const float* bn_dvar) {
+    DwShape s{n, c, h, wd, (h + 2 * pad - k) / stride + 1, (wd + 2 * pad - k) / stride + 1, k, stride, pad};
+    const long long total_o = (long long)n * c * s.OH * s.OW;
+    if (total_o <= 0) return;
+    // algorithmic bytes: dz, y, x read; dx written (read too when it accumulates)
+    KTimer kt(K_DEPTHWISE_BWD, 4.0 * (double)total_o * k * k,
+              4.0 * (2.0 * (double)total_o + (overwrite ? 2.0 : 3.0) * (double)n * c * h * wd));
+    DwBnBwd bn{dz, bn_mean, bn_var, bn_scales, bn_dmean, bn_dvar};
+    if (!dx || !depthwise_backward_lds(x, w, y, nullptr, dx, dw, dbias, s, act, overwrite, 0, &bn)) {
+        fprintf(stderr, "[bcnn_hip] bcnn_hip_depthwise_backward_bn: shape not fusable (ask bcnn_hip_depthwise_bn_fusable)\n");
+        exit(1);
+    }
+}
+
 void bcnn_hip_depthwise_backward(const float* x, const float* w, const float* y, float* dy, float* dx,
                                  float* dw, float* dbias, int n, int c, int h, int wd, int k, int stride,
                                  int pad, int act, int overwrite) {
@@ -561,6 +607,19 @@ void bcnn_hip_depthwise_backward(const float* x, const float* w, const float* y,
               4.0 * (((act != BCNN_HIP_ACT_NONE) ? 3.0 : 0.0) * (double)total_o + (double)total_o +
                      (dx ? ((double)n * c * h * wd + (double)total_o) + ((double)total_o + (overwrite ? 1.0 : 2.0) * (double)n * c * h * wd)
                          : 0.0)));
+    if (dx && depthwise_lds_ok(s) && act != BCNN_HIP_ACT_PRELU) {
+        // one pass: dy *= act'(y) written back, dbias, dW, dX (softplus: its derivative needs exp() -> own pass first)
+        int a = act;
+        if (!act_bwd_is_cheap(act)) {
+            bcnn_hip_activation_backward(y, dy, (size_t)total_o, act, nullptr, nullptr, ohow, c);
+            a = BCNN_HIP_ACT_NONE;
+        }
+        if (depthwise_backward_lds(x, w, y, dy, dx, dw, dbias, s, a, overwrite, /*write_back=*/1, nullptr)) return;
+        if (a != act) {  // not reached: depthwise_lds_ok() is the kernel's only shape condition
+            fprintf(stderr, "[bcnn_hip] depthwise_backward_lds refused a shape depthwise_lds_ok accepted\n");
+            exit(1);
+        }
+    }
     activation_backward_grad_bias(y, dy, dbias, n, c, ohow, act);  // one sweep: dy *= act'(y), dbias += sum
     if (!dx) return;  // reference: dW and dX are both skipped when the source has no gradient (:318, :432)
     const int NT = k * k;

@@ -448,6 +448,7 @@ bcnn_status bcnn_compile_net(bcnn_net *net) {
         comm_sync_parameters(net); /* communicator installed before the arena existed / new parameters appeared */
     }
     mark_dead_grad_fills(net);
+    bcnn_link_depthwise_batchnorm(net);
     if (hc->fill_chunks_gpu) { /* the table of live fills follows the dead-fill marks */
         bcnn_hip_sync();
         bcnn_hip_free(hc->fill_chunks_gpu);
@@ -511,7 +512,10 @@ void bcnn_forward(bcnn_net *net) {
         if (hc->num_fill_chunks < 0) build_fill_table(net);
         bcnn_hip_zero_chunks((const bcnn_hip_fill_chunk *)hc->fill_chunks_gpu, hc->num_fill_chunks);
     }
+    bcnn_drop_pending_gradients(net);
+    hc->in_pass = 1;
     for (int i = 0; i < net->num_nodes; ++i) net->nodes[i].forward(net, &net->nodes[i]);
+    hc->in_pass = 0;
 }
 
 /* in-library data parallelism: the gradient-ready callback of bcnn_set_data_parallel_comm */
@@ -533,6 +537,7 @@ void bcnn_backward(bcnn_net *net) {
     bcnn_hip_context *hc = hctx(net);
     size_t ready_from = hc->arena_size;
     if (hc->comm_active) hc->comm_lo = hc->comm_hi = hc->arena_size;
+    hc->in_pass = 2;
     for (int i = net->num_nodes - 1; i >= 0; --i) {
         net->nodes[i].backward(net, &net->nodes[i]);
         if (hc->grad_ready_fn && hc->node_grad_first && hc->node_grad_first[i] < ready_from) {
@@ -540,6 +545,7 @@ void bcnn_backward(bcnn_net *net) {
             ready_from = hc->node_grad_first[i];
         }
     }
+    hc->in_pass = 0;
     if (hc->grad_ready_fn && ready_from > 0 && hc->arena_size > 0)  /* members no node claims (none today) */
         hc->grad_ready_fn(0, ready_from, hc->grad_ready_user);
     if (hc->comm_active) {
@@ -750,6 +756,7 @@ bcnn_status bcnn_upload_tensor(bcnn_net *net, int index, int with_grad) {
     bcnn_tensor *t = &net->tensors[index];
     const size_t bytes = (size_t)bcnn_tensor_size(t) * sizeof(float);
     if (t->data && t->data_gpu) bcnn_hip_memcpy_h2d(t->data_gpu, t->data, bytes);
+    if (with_grad) bcnn_materialize_gradients(net, -1); /* before a caller's values can mix with pending ones */
     if (with_grad && t->grad_data && t->grad_data_gpu) bcnn_hip_memcpy_h2d(t->grad_data_gpu, t->grad_data, bytes);
     return BCNN_SUCCESS;
 }
@@ -759,6 +766,7 @@ bcnn_status bcnn_download_tensor(bcnn_net *net, int index, int with_grad) {
     bcnn_tensor *t = &net->tensors[index];
     const size_t bytes = (size_t)bcnn_tensor_size(t) * sizeof(float);
     if (t->data && t->data_gpu) bcnn_hip_memcpy_d2h(t->data, t->data_gpu, bytes);
+    if (with_grad) bcnn_materialize_gradients(net, index); /* gradients a fused backward pass did not need to write */
     if (with_grad && t->grad_data && t->grad_data_gpu) bcnn_hip_memcpy_d2h(t->grad_data, t->grad_data_gpu, bytes);
     return BCNN_SUCCESS;
 }
@@ -807,6 +815,7 @@ bcnn_status bcnn_forward_node(bcnn_net *net, int node) {
 bcnn_status bcnn_backward_node(bcnn_net *net, int node) {
     if (node < 0 || node >= net->num_nodes || !net->nodes[node].backward) return BCNN_INVALID_PARAMETER;
     bcnn_hip_context *hc = hctx(net);
+    bcnn_materialize_gradients(net, -1); /* a single worker reads and rewrites gradient tensors in place */
     /* outside the executor nobody promised that the gradients were left unfilled: accumulate like the reference */
     unsigned char *saved = hc->grad_fill_dead;
     hc->grad_fill_dead = NULL;

@@ -162,6 +162,9 @@ typedef struct bcnn_hip_context {
      * into buckets of comm_bucket floats and all-reduced on the communicator's stream while backward continues */
     int comm_active;
     size_t comm_bucket, comm_lo, comm_hi;
+    /* 1 inside bcnn_forward / 2 inside bcnn_backward: node workers may rely on their neighbours having run in this pass
+     * (bcnn_forward_node / bcnn_backward_node run one worker alone: 0) */
+    int in_pass;
 } bcnn_hip_context;
 
 /* ---- net ------------------------------------------------------------------------------------------ */
@@ -259,6 +262,16 @@ typedef struct bcnn_depthwise_conv_param {
     float *adam_m, *adam_v;
 #ifdef BCNN_USE_HIP
     float *adam_m_gpu, *adam_v_gpu;
+    /* set by bcnn_compile_net when this node's output feeds a stand-alone batch-norm node (bcnn_link_depthwise_batchnorm):
+     * inside a whole forward / backward pass the two workers share work */
+    int bn_node;         /* index of that batch-norm node, -1: none */
+    int bn_fused_bwd;    /* the batch-norm node leaves its apply sweep to this node's backward kernel */
+    float *stats_gpu;    /* per-channel statistics partials of the last forward (TRAIN) */
+    size_t stats_floats;
+    int stats_splits;    /* > 0: stats_gpu holds the statistics of the output written by the last forward of this pass */
+    int grads_pending;   /* the last backward pass did not write the gradient of this node's output nor rewrite the
+                          * batch-norm node's output gradient (nothing inside a pass reads them): they are produced on
+                          * demand by bcnn_materialize_gradients, as the reference's two workers leave them */
 #endif
 } bcnn_depthwise_conv_param;
 
@@ -270,6 +283,10 @@ typedef struct bcnn_batchnorm_param {
 #ifdef BCNN_USE_HIP
     float *workspace_gpu;
     float *x_norm_gpu;
+    int dw_node;         /* the depthwise node that produces this node's input (see bcnn_depthwise_conv_param), -1: none */
+    int dw_fused_bwd;    /* that node applies this node's backward to the gradient it consumes */
+    int input_kept;      /* the input tensor is not this node's output and has no other consumer: it IS the copy of the
+                          * input the reference keeps in `workspace` (bcnn_batchnorm_layer.c:208) */
 #endif
 } bcnn_batchnorm_param;
 
@@ -346,6 +363,9 @@ void bcnn_forward_cost_layer(bcnn_net *net, bcnn_node *node);
 void bcnn_backward_cost_layer(bcnn_net *net, bcnn_node *node);
 
 /* SGD step on one node's parameters (bcnn_learner.c:67-104 in the reference) */
+void bcnn_link_depthwise_batchnorm(bcnn_net *net); /* bcnn_layers_hot.c; called by bcnn_compile_net */
+void bcnn_materialize_gradients(bcnn_net *net, int tensor); /* tensor < 0: every pending one */
+void bcnn_drop_pending_gradients(bcnn_net *net);
 int bcnn_grad_sole_writer(bcnn_net *net, int tensor); /* 1: this gradient's zero fill was skipped, assign instead of += */
 void bcnn_node_sgd_step(bcnn_net *net, bcnn_tensor *weights, bcnn_tensor *biases);
 void bcnn_node_optim_step(bcnn_net *net, bcnn_tensor *weights, bcnn_tensor *biases, float **adam_m_gpu,

@@ -220,6 +220,7 @@ bcnn_status bcnn_add_depthwise_conv_layer(bcnn_net *net, int size, int stride, i
     bcnn_depthwise_conv_param *param = (bcnn_depthwise_conv_param *)calloc(1, node.param_size);
     node.param = param;
     param->activation = activation; param->size = size; param->stride = stride; param->pad = pad;
+    param->bn_node = -1;
     node.forward = bcnn_forward_depthwise_conv_layer;
     node.backward = bcnn_backward_depthwise_conv_layer;
     node.update = bcnn_update_depthwise_conv_layer;
@@ -236,6 +237,14 @@ void bcnn_forward_depthwise_conv_layer(bcnn_net *net, bcnn_node *node) {
     bcnn_depthwise_conv_param *p = (bcnn_depthwise_conv_param *)node->param;
     bcnn_tensor *x = &net->tensors[node->src[0]], *w = &net->tensors[node->src[1]];
     bcnn_tensor *b = &net->tensors[node->src[2]], *y = &net->tensors[node->dst[0]];
+    p->stats_splits = 0;
+    if (hctx(net)->in_pass == 1 && net->mode == BCNN_MODE_TRAIN && p->bn_node >= 0 && p->stats_gpu) {
+        /* the batch-norm node that runs next in this pass takes its statistics from this kernel's epilogue */
+        p->stats_splits = bcnn_hip_depthwise_forward_stats(x->data_gpu, w->data_gpu, b->data_gpu, y->data_gpu, x->n, x->c,
+                                                           x->h, x->w, p->size, p->stride, p->pad, (int)p->activation,
+                                                           p->stats_gpu, p->stats_floats);
+        return;
+    }
     bcnn_hip_depthwise_forward(x->data_gpu, w->data_gpu, b->data_gpu, y->data_gpu, x->n, x->c, x->h, x->w, p->size,
                                p->stride, p->pad, (int)p->activation);
 }
@@ -244,6 +253,20 @@ void bcnn_backward_depthwise_conv_layer(bcnn_net *net, bcnn_node *node) {
     bcnn_depthwise_conv_param *p = (bcnn_depthwise_conv_param *)node->param;
     bcnn_tensor *x = &net->tensors[node->src[0]], *w = &net->tensors[node->src[1]];
     bcnn_tensor *b = &net->tensors[node->src[2]], *y = &net->tensors[node->dst[0]];
+    if (hctx(net)->in_pass == 2 && p->bn_fused_bwd && x->grad_data_gpu) {
+        /* the batch-norm node (which ran just before in this pass) only produced its sums: its apply sweep
+         * (bcnn_batchnorm_layer.c:292-296) happens inside this node's kernel, on the gradient of ITS output */
+        const bcnn_node *bn = &net->nodes[p->bn_node];
+        const bcnn_batchnorm_param *bp = (const bcnn_batchnorm_param *)bn->param;
+        bcnn_hip_depthwise_backward_bn(x->data_gpu, w->data_gpu, y->data_gpu, net->tensors[bn->dst[0]].grad_data_gpu,
+                                       x->grad_data_gpu, w->grad_data_gpu, b->grad_data_gpu, x->n, x->c, x->h, x->w,
+                                       p->size, p->stride, p->pad, (int)p->activation,
+                                       bcnn_grad_sole_writer(net, node->src[0]), bp->saved_mean.data_gpu,
+                                       bp->saved_variance.data_gpu, net->tensors[bn->src[3]].data_gpu,
+                                       bp->saved_mean.grad_data_gpu, bp->saved_variance.grad_data_gpu);
+        p->grads_pending = 1;
+        return;
+    }
     bcnn_hip_depthwise_backward(x->data_gpu, w->data_gpu, y->data_gpu, y->grad_data_gpu, x->grad_data_gpu,
                                 w->grad_data_gpu, b->grad_data_gpu, x->n, x->c, x->h, x->w, p->size, p->stride,
                                 p->pad, (int)p->activation, bcnn_grad_sole_writer(net, node->src[0]));
@@ -258,6 +281,7 @@ void bcnn_release_param_depthwise_conv_layer(bcnn_node *node) {
     bcnn_depthwise_conv_param *p = (bcnn_depthwise_conv_param *)node->param;
     bcnn_hip_free(p->adam_m_gpu);
     bcnn_hip_free(p->adam_v_gpu);
+    bcnn_hip_free(p->stats_gpu);
 }
 
 /* ================================================================================================
@@ -274,6 +298,7 @@ bcnn_status bcnn_add_batchnorm_layer(bcnn_net *net, const char *src_id, const ch
     node.param_size = sizeof(bcnn_batchnorm_param);
     bcnn_batchnorm_param *param = (bcnn_batchnorm_param *)calloc(1, node.param_size);
     node.param = param;
+    param->dw_node = -1;
     node.forward = bcnn_forward_batchnorm_layer;
     node.backward = bcnn_backward_batchnorm_layer;
     node.release_param = bcnn_release_param_batchnorm_layer;
@@ -292,26 +317,153 @@ bcnn_status bcnn_add_batchnorm_layer(bcnn_net *net, const char *src_id, const ch
     return BCNN_SUCCESS;
 }
 
+/* the copy of the input the reference keeps for the backward pass (bcnn_batchnorm_layer.c:208): the input tensor itself
+ * when nothing can overwrite it before then (input_kept, decided by bcnn_link_depthwise_batchnorm) */
+static float *batchnorm_kept_input(const bcnn_batchnorm_param *p, const bcnn_tensor *x) {
+    return (p->input_kept || !p->workspace_gpu) ? x->data_gpu : p->workspace_gpu;
+}
+
 void bcnn_forward_batchnorm_layer(bcnn_net *net, bcnn_node *node) {
     bcnn_batchnorm_param *p = (bcnn_batchnorm_param *)node->param;
     bcnn_tensor *x = &net->tensors[node->src[0]], *y = &net->tensors[node->dst[0]];
-    bcnn_hip_batchnorm_forward(x->data_gpu, y->data_gpu, net->tensors[node->src[1]].data_gpu,
-                               net->tensors[node->src[2]].data_gpu, net->tensors[node->src[3]].data_gpu,
-                               net->tensors[node->src[4]].data_gpu, p->saved_mean.data_gpu,
-                               p->saved_variance.data_gpu, p->x_norm_gpu, p->workspace_gpu, x->n, x->c, x->h * x->w,
-                               (int)net->mode, BCNN_HIP_ACT_NONE);
+    const float *stats = NULL;
+    int splits = 0;
+    if (hctx(net)->in_pass == 1 && net->mode == BCNN_MODE_TRAIN && p->dw_node >= 0) {
+        /* the depthwise node that ran just before in this pass left the statistics of the tensor it wrote */
+        bcnn_depthwise_conv_param *dp = (bcnn_depthwise_conv_param *)net->nodes[p->dw_node].param;
+        stats = dp->stats_gpu;
+        splits = dp->stats_splits;
+        dp->stats_splits = 0;
+    }
+    bcnn_hip_batchnorm_forward_stats(x->data_gpu, y->data_gpu, net->tensors[node->src[1]].data_gpu,
+                                     net->tensors[node->src[2]].data_gpu, net->tensors[node->src[3]].data_gpu,
+                                     net->tensors[node->src[4]].data_gpu, p->saved_mean.data_gpu,
+                                     p->saved_variance.data_gpu, p->x_norm_gpu,
+                                     net->mode == BCNN_MODE_PREDICT ? NULL : batchnorm_kept_input(p, x), x->n, x->c,
+                                     x->h * x->w, (int)net->mode, BCNN_HIP_ACT_NONE, stats, splits);
 }
 
 void bcnn_backward_batchnorm_layer(bcnn_net *net, bcnn_node *node) {
     bcnn_batchnorm_param *p = (bcnn_batchnorm_param *)node->param;
     bcnn_tensor *x = &net->tensors[node->src[0]], *y = &net->tensors[node->dst[0]];
     bcnn_tensor *scales = &net->tensors[node->src[3]], *biases = &net->tensors[node->src[4]];
+    if (hctx(net)->in_pass == 2 && p->dw_fused_bwd && net->tensors[net->nodes[p->dw_node].src[0]].grad_data_gpu) {
+        /* sums only: the depthwise node that runs next in this pass applies :292-296 inside its own kernel */
+        bcnn_hip_batchnorm_backward_sums(y->grad_data_gpu, scales->data_gpu, scales->grad_data_gpu, biases->grad_data_gpu,
+                                         p->saved_mean.data_gpu, p->saved_variance.data_gpu,
+                                         p->saved_mean.grad_data_gpu, p->saved_variance.grad_data_gpu,
+                                         batchnorm_kept_input(p, x), x->n, x->c, x->h * x->w);
+        return;
+    }
     /* VALID-mode backward would use the running statistics (reference :306-309); only TRAIN is meaningful */
     bcnn_hip_batchnorm_backward(y->grad_data_gpu, x->grad_data_gpu, NULL, BCNN_HIP_ACT_NONE, scales->data_gpu,
                                 scales->grad_data_gpu, biases->grad_data_gpu, p->saved_mean.data_gpu,
                                 p->saved_variance.data_gpu, p->saved_mean.grad_data_gpu,
-                                p->saved_variance.grad_data_gpu, p->x_norm_gpu, p->workspace_gpu, x->n, x->c,
+                                p->saved_variance.grad_data_gpu, p->x_norm_gpu, batchnorm_kept_input(p, x), x->n, x->c,
                                 x->h * x->w);
+}
+
+/* The fused backward of a depthwise / batch-norm pair leaves two gradient tensors unwritten that the reference's workers
+ * rewrite in place: the batch-norm node's dst gradient (-> gradient w.r.t. its input, bcnn_batchnorm_layer.c:292-296)
+ * and the depthwise node's dst gradient (that, times act'(y), bcnn_depthwise_conv_layer.c:311-314). Every input of those
+ * two sweeps is still in place after the pass, so a caller that asks for either tensor (bcnn_get_tensor_by_*,
+ * bcnn_download_tensor) gets them produced here, once, with the unfused kernels. */
+void bcnn_materialize_gradients(bcnn_net *net, int tensor) {
+    for (int i = 0; i < net->num_nodes; ++i) {
+        bcnn_node *dw = &net->nodes[i];
+        if (dw->type != BCNN_LAYER_DEPTHWISE_CONV2D) continue;
+        bcnn_depthwise_conv_param *dp = (bcnn_depthwise_conv_param *)dw->param;
+        if (!dp->grads_pending || dp->bn_node < 0 || dp->bn_node >= net->num_nodes) continue;
+        bcnn_node *bn = &net->nodes[dp->bn_node];
+        if (tensor >= 0 && tensor != dw->dst[0] && tensor != bn->dst[0]) continue;
+        dp->grads_pending = 0;
+        const bcnn_batchnorm_param *bp = (const bcnn_batchnorm_param *)bn->param;
+        bcnn_tensor *y = &net->tensors[dw->dst[0]], *z = &net->tensors[bn->dst[0]];
+        if (!y->grad_data_gpu || !z->grad_data_gpu) continue;
+        bcnn_hip_batchnorm_backward_apply(z->grad_data_gpu, y->grad_data_gpu, net->tensors[bn->src[3]].data_gpu,
+                                          bp->saved_mean.data_gpu, bp->saved_variance.data_gpu,
+                                          bp->saved_mean.grad_data_gpu, bp->saved_variance.grad_data_gpu, y->data_gpu,
+                                          y->n, y->c, y->h * y->w);
+        bcnn_hip_activation_backward(y->data_gpu, y->grad_data_gpu, (size_t)bcnn_tensor_size(y), (int)dp->activation, NULL,
+                                     NULL, y->h * y->w, y->c);
+    }
+}
+
+void bcnn_drop_pending_gradients(bcnn_net *net) { /* a new forward pass: the reference zero-fills them (bcnn_net.c:361-375) */
+    for (int i = 0; i < net->num_nodes; ++i)
+        if (net->nodes[i].type == BCNN_LAYER_DEPTHWISE_CONV2D)
+            ((bcnn_depthwise_conv_param *)net->nodes[i].param)->grads_pending = 0;
+}
+
+/* Pairs every depthwise node with the stand-alone batch-norm node that consumes its output (bcnn_compile_net; the
+ * MobileNet block of the reference's configs: [depthwise-conv] -> [batchnorm]). Recomputed from scratch at every compile:
+ * node indices, not pointers (the node array moves when nodes are added). */
+void bcnn_link_depthwise_batchnorm(bcnn_net *net) {
+    for (int i = 0; i < net->num_nodes; ++i) {
+        bcnn_node *nd = &net->nodes[i];
+        if (nd->type == BCNN_LAYER_DEPTHWISE_CONV2D) {
+            bcnn_depthwise_conv_param *dp = (bcnn_depthwise_conv_param *)nd->param;
+            dp->bn_node = -1;
+            dp->bn_fused_bwd = 0;
+            dp->stats_splits = 0;
+            dp->grads_pending = 0;
+        } else if (nd->type == BCNN_LAYER_BATCHNORM) {
+            bcnn_batchnorm_param *bp = (bcnn_batchnorm_param *)nd->param;
+            bp->dw_node = -1;
+            bp->dw_fused_bwd = 0;
+            bp->input_kept = 0;
+        }
+    }
+    if (BCNN_EXP_ENV("BCNN_NO_NODE_FUSION")) return; /* A/B switch of the experiment build */
+    for (int j = 0; j < net->num_nodes; ++j) {
+        bcnn_node *bn = &net->nodes[j];
+        if (bn->type != BCNN_LAYER_BATCHNORM) continue;
+        bcnn_batchnorm_param *bp = (bcnn_batchnorm_param *)bn->param;
+        const int t = bn->src[0];
+        int producer = -1, writers = 0, consumers = 0;
+        for (int i = 0; i < net->num_nodes; ++i) {
+            for (int k = 0; k < net->nodes[i].num_dst; ++k)
+                if (net->nodes[i].dst[k] == t) {
+                    producer = i;
+                    ++writers;
+                }
+            for (int k = 0; k < net->nodes[i].num_src; ++k)
+                if (net->nodes[i].src[k] == t) ++consumers;
+        }
+        /* nobody else reads or rewrites the input between this node's forward and its backward */
+        const int private_input = writers == 1 && consumers == 1 && bn->dst[0] != t;
+        bp->input_kept = private_input;
+        if (private_input && bp->workspace_gpu) { /* the copy is not needed */
+            bcnn_hip_sync();
+            bcnn_hip_free(bp->workspace_gpu);
+            bp->workspace_gpu = NULL;
+        } else if (!private_input && !bp->workspace_gpu && net->mode != BCNN_MODE_PREDICT) {
+            bp->workspace_gpu = bcnn_hip_malloc_f32((size_t)bcnn_tensor_size(&net->tensors[t]));
+        }
+        if (producer != j - 1 || writers != 1 || net->nodes[producer].type != BCNN_LAYER_DEPTHWISE_CONV2D) continue;
+        bcnn_node *dw = &net->nodes[producer];
+        bcnn_depthwise_conv_param *dp = (bcnn_depthwise_conv_param *)dw->param;
+        const bcnn_tensor *x = &net->tensors[dw->src[0]];
+        /* forward: the statistics of the depthwise output are the same whoever else reads it */
+        const size_t need = bcnn_hip_depthwise_stats_size(x->n, x->c, x->h, x->w, dp->size, dp->stride, dp->pad);
+        if (need > 0) {
+            if (need > dp->stats_floats) {
+                bcnn_hip_sync();
+                bcnn_hip_free(dp->stats_gpu);
+                dp->stats_gpu = bcnn_hip_malloc_f32(need);
+                dp->stats_floats = need;
+            }
+            dp->bn_node = j;
+            bp->dw_node = producer;
+        }
+        /* backward: the gradient of the depthwise output has this node as its only writer and that node as its only
+         * reader, so it does not have to exist */
+        if (dp->bn_node == j && private_input &&
+            bcnn_hip_depthwise_bn_fusable(x->n, x->c, x->h, x->w, dp->size, dp->stride, dp->pad, (int)dp->activation)) {
+            dp->bn_fused_bwd = 1;
+            bp->dw_fused_bwd = 1;
+        }
+    }
 }
 
 void bcnn_release_param_batchnorm_layer(bcnn_node *node) {

@@ -134,6 +134,45 @@ def depthwise_backward(x, wt, y, dy, dx, dw, dbias, k, stride, pad, act=0, overw
                                             _f32(dbias), n, c, h, w, k, stride, pad, act, 1 if overwrite else 0)
 
 
+def depthwise_forward_stats(x, wt, bias, y, k, stride, pad, act, stats):
+    """bcnn_hip_depthwise_forward that also leaves per-channel (sum, sum of squares) partials of y in `stats`;
+    returns the number of partials per channel (0: none, run the plain batch-norm forward)"""
+    n, c, h, w = x.shape
+    return _lib.load().bcnn_hip_depthwise_forward_stats(_f32(x), _f32(wt), _f32(bias), _f32(y), n, c, h, w, k, stride,
+                                                        pad, act, _f32(stats), stats.numel())
+
+
+def depthwise_stats_size(n, c, h, w, k, stride, pad):
+    return _lib.load().bcnn_hip_depthwise_stats_size(n, c, h, w, k, stride, pad)
+
+
+def batchnorm_forward_stats(x, y, run_mean, run_var, scales, bias, saved_mean, saved_var, workspace, mode, stats, splits):
+    """bcnn_forward_batchnorm_cpu (bcnn_batchnorm_layer.c:196-242) with the statistics partials of the producer"""
+    n, c, h, w = x.shape
+    _lib.load().bcnn_hip_batchnorm_forward_stats(_f32(x), _f32(y), _f32(run_mean), _f32(run_var), _f32(scales), _f32(bias),
+                                                 _f32(saved_mean), _f32(saved_var), None, _f32(workspace), n, c, h * w,
+                                                 mode, 0, _f32(stats), splits)
+
+
+def depthwise_bn_fusable(n, c, h, w, k, stride, pad, act):
+    return bool(_lib.load().bcnn_hip_depthwise_bn_fusable(n, c, h, w, k, stride, pad, act))
+
+
+def batchnorm_backward_sums(dy, scales, dscales, dbias, saved_mean, saved_var, dmean, dvar, x):
+    """first sweep of bcnn_backward_batchnorm_cpu (bcnn_batchnorm_layer.c:301-332): the per-channel sums only"""
+    n, c, h, w = x.shape
+    _lib.load().bcnn_hip_batchnorm_backward_sums(_f32(dy), _f32(scales), _f32(dscales), _f32(dbias), _f32(saved_mean),
+                                                 _f32(saved_var), _f32(dmean), _f32(dvar), _f32(x), n, c, h * w)
+
+
+def depthwise_backward_bn(x, wt, y, dz, dx, dw, dbias, k, stride, pad, act, overwrite, mean, var, scales, dmean, dvar):
+    """depthwise backward on the gradient a following stand-alone batch-norm node would hand down, applied on the fly"""
+    n, c, h, w = x.shape
+    _lib.load().bcnn_hip_depthwise_backward_bn(_f32(x), _f32(wt), _f32(y), _f32(dz), _f32(dx), _f32(dw), _f32(dbias), n, c,
+                                               h, w, k, stride, pad, act, 1 if overwrite else 0, _f32(mean), _f32(var),
+                                               _f32(scales), _f32(dmean), _f32(dvar))
+
+
 def gemm(ta, tb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc):
     """bcnn_gemm (bcnn_mat.c:2627-2650)"""
     _lib.load().bcnn_hip_gemm(ta, tb, m, n, k, alpha, _f32(a), lda, _f32(b), ldb, beta, _f32(c), ldc)

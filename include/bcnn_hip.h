@@ -209,6 +209,51 @@ void bcnn_hip_depthwise_backward(const float *x_d, const float *w_d, const float
                                  int k, int stride, int pad, int act, int overwrite);
 
 /* ---------------------------------------------------------------------------------------------
+ * A depthwise layer whose output feeds a stand-alone batch-norm node (the MobileNet block, reference
+ * examples/... mobilenet configs: [depthwise-conv] -> [batchnorm] -> [conv 1x1]). The reference runs the two nodes'
+ * workers back to back (bcnn_depthwise_conv_layer.c:165-293 then bcnn_batchnorm_layer.c:196-242; backward
+ * bcnn_batchnorm_layer.c:301-332 then bcnn_depthwise_conv_layer.c:295-547); these entry points let an executor that
+ * runs whole passes share work between the two workers. Results are those of the separate calls (forward, dx: the
+ * same operations in the same order; statistics and gradient sums: fixed-order two-level sums).
+ *   bcnn_hip_depthwise_stats_size      floats the statistics scratch of this layer shape needs; 0 = this shape's
+ *                                      forward kernel emits no statistics
+ *   bcnn_hip_depthwise_forward_stats   bcnn_hip_depthwise_forward that also leaves per-channel partial sums
+ *                                      (sum, sum of squares of y) in stats_d; returns the number of partials per
+ *                                      channel, 0 when none were written
+ *   bcnn_hip_batchnorm_forward_stats   bcnn_hip_batchnorm_forward (TRAIN mode) that takes those partials instead of
+ *                                      reading x_d for its statistics (splits == 0: plain bcnn_hip_batchnorm_forward)
+ *   bcnn_hip_depthwise_bn_fusable      non-zero when bcnn_hip_depthwise_backward_bn handles this layer
+ *   bcnn_hip_batchnorm_backward_sums   first half of bcnn_hip_batchnorm_backward: dbias / dscales accumulate, dmean /
+ *                                      dvar are written; dy_d is NOT rewritten (x_d: the batch-norm input)
+ *   bcnn_hip_batchnorm_backward_apply  second half of bcnn_hip_batchnorm_backward alone (dmean / dvar from the first):
+ *                                      dy_d rewritten in place and copied to dx_d -- what the executor runs when a
+ *                                      caller asks for a gradient tensor the fused pass did not have to write
+ *   bcnn_hip_depthwise_backward_bn     bcnn_hip_depthwise_backward on g = BNbackward(dz_d) (second half of
+ *                                      bcnn_hip_batchnorm_backward, bcnn_batchnorm_layer.c:292-296, applied on the fly);
+ *                                      neither dz_d nor the depthwise output gradient is written
+ * ------------------------------------------------------------------------------------------- */
+size_t bcnn_hip_depthwise_stats_size(int n, int c, int h, int w, int k, int stride, int pad);
+int bcnn_hip_depthwise_forward_stats(const float *x_d, const float *w_d, const float *bias_d, float *y_d, int n, int c,
+                                     int h, int w, int k, int stride, int pad, int act, float *stats_d,
+                                     size_t stats_floats);
+void bcnn_hip_batchnorm_forward_stats(const float *x_d, float *y_d, float *run_mean_d, float *run_var_d,
+                                      const float *scales_d, const float *bias_d, float *saved_mean_d,
+                                      float *saved_var_d, float *x_norm_d, float *workspace_d, int n, int c, int hw,
+                                      int mode, int act, const float *stats_d, int splits);
+int bcnn_hip_depthwise_bn_fusable(int n, int c, int h, int w, int k, int stride, int pad, int act);
+void bcnn_hip_batchnorm_backward_sums(const float *dy_d, const float *scales_d, float *dscales_d, float *dbias_d,
+                                      const float *saved_mean_d, const float *saved_var_d, float *dmean_d,
+                                      float *dvar_d, const float *x_d, int n, int c, int hw);
+void bcnn_hip_batchnorm_backward_apply(float *dy_d, float *dx_d, const float *scales_d, const float *saved_mean_d,
+                                       const float *saved_var_d, const float *dmean_d, const float *dvar_d,
+                                       const float *x_d, int n, int c, int hw);
+void bcnn_hip_depthwise_backward_bn(const float *x_d, const float *w_d, const float *y_d, const float *dz_d,
+                                    float *dx_d, float *dw_d, float *dbias_d, int n, int c, int h, int w, int k,
+                                    int stride, int pad, int act, int overwrite, const float *bn_mean_d,
+                                    const float *bn_var_d, const float *bn_scales_d, const float *bn_dmean_d,
+                                    const float *bn_dvar_d);
+
+/* ---------------------------------------------------------------------------------------------
  * SGD step on a parameter arena.  Replaces bcnn_sgd_update_gpu (bcnn_learner.c:86-104); semantics
  * of bcnn_sgd_update_cpu (:67-83) fused into one pass per buffer:
  *   b -= (lr/batch)*db; db *= momentum; dw += (decay*batch)*w; w -= (lr/batch)*dw; dw *= momentum.
