@@ -50,17 +50,25 @@ __global__ void bn_stats_finalize_kernel(const float* __restrict__ partials, int
 // Same result for MANY partials per channel (the convolution epilogue emits one per column tile, up to a
 // few thousand): one workgroup per channel, threads stride over the partials in double, fixed-shape
 // butterfly + a fixed-order cross-wave step.
-__global__ __launch_bounds__(256) void bn_stats_finalize_wide_kernel(const float* __restrict__ partials, int C, int splits,
-                                                                    int M, float* __restrict__ saved_mean,
-                                                                    float* __restrict__ saved_var,
-                                                                    float* __restrict__ run_mean,
-                                                                    float* __restrict__ run_var) {
-    __shared__ double red[4][2];
+constexpr int kFinalizeThreads = 1024;
+__global__ __launch_bounds__(kFinalizeThreads) void bn_stats_finalize_wide_kernel(
+    const float* __restrict__ partials, int C, int splits, int M, float* __restrict__ saved_mean,
+    float* __restrict__ saved_var, float* __restrict__ run_mean, float* __restrict__ run_var) {
+    constexpr int NW = kFinalizeThreads / 64;
+    __shared__ double red[NW][2];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int c = blockIdx.x;
     const float2* p = reinterpret_cast<const float2*>(partials) + (long long)c * splits;
     double s = 0.0, ss = 0.0;
-    for (int i = threadIdx.x; i < splits; i += 256) {
+    // four independent loads per round: with one, a channel of 50 176 partials (the first pointwise layer of
+    // MobileNet) was a chain of 196 dependent round trips per thread = 80 us
+    int i = threadIdx.x;
+    for (; i + 3 * kFinalizeThreads < splits; i += 4 * kFinalizeThreads) {
+        const float2 v0 = p[i], v1 = p[i + kFinalizeThreads], v2 = p[i + 2 * kFinalizeThreads], v3 = p[i + 3 * kFinalizeThreads];
+        s += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
+        ss += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+    }
+    for (; i < splits; i += kFinalizeThreads) {
         const float2 v = p[i];
         s += (double)v.x;
         ss += (double)v.y;
@@ -70,8 +78,9 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_wide_kernel(const float
     if (lane == 0) { red[wid][0] = s; red[wid][1] = ss; }
     __syncthreads();
     if (threadIdx.x != 0) return;
-    s = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
-    ss = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+    s = 0.0;
+    ss = 0.0;
+    for (int w = 0; w < NW; ++w) { s += red[w][0]; ss += red[w][1]; }
     const float inv = 1.0f / (float)M;
     const float mean = __fmul_rn((float)s, inv);
     const float var = __fsub_rn(__fmul_rn((float)ss, inv), __fmul_rn(mean, mean));
@@ -271,7 +280,7 @@ void batchnorm_forward_impl(const float* x, float* y, float* run_mean, float* ru
     if (mode == BCNN_HIP_MODE_PREDICT) a.ws = nullptr;  // the reference keeps no copy in PREDICT mode
     if (mode == BCNN_HIP_MODE_VALID) a.xn = nullptr;    // x_norm is only written in TRAIN mode (:230)
     if (have_pre) {
-        bn_stats_finalize_wide_kernel<<<c, 256, 0, current_stream()>>>(
+        bn_stats_finalize_wide_kernel<<<c, kFinalizeThreads, 0, current_stream()>>>(
             pre->partials, c, pre->splits, (int)M, saved_mean, saved_var, run_mean, run_var);
         KERNEL_CHECK();
         a.mean = saved_mean; a.var = saved_var;

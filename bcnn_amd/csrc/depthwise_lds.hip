@@ -27,9 +27,18 @@ namespace bcnn_hip {
 
 namespace {
 
-constexpr int kTileFloats = 4096;  // most a tile reads per stream: 4 x 16 bytes per thread in flight
+#ifndef DWL_ABL
+#define DWL_ABL 0  // ablation bits for tools/exp (wrong results): 1 no weight gradient, 2 no data gradient, 4 no batch-norm math
+#endif
+#ifndef DWL_TILE
+#define DWL_TILE 4096
+#endif
+#ifndef DWL_IMAGE
+#define DWL_IMAGE 3600
+#endif
+constexpr int kTileFloats = DWL_TILE;  // most a tile reads per stream: 4 x 16 bytes per thread in flight
 constexpr int kMaxQ = kTileFloats / 4 / 256;
-constexpr int kImageFloats = 3600;  // padded LDS image of a multi-plane tile (x and g each)
+constexpr int kImageFloats = DWL_IMAGE;  // padded LDS image of a multi-plane tile (x and g each)
 constexpr int kSlack = 4;          // LDS rows behind an image that ragged row groups may read (values discarded)
 constexpr int kConst = 16;         // floats per plane in the constants table: 9 taps, bias | mean, rs, scale, dmean/M, dvar
 
@@ -42,7 +51,20 @@ struct DwlGeom {
     int stage_floats;      // forward: outputs of a tile; backward: the dx rows a tile owns
 };
 
-inline unsigned dwl_magic(unsigned d) { return d > 1 ? (unsigned)((0x100000000ULL + d - 1) / d) : 0u; }
+// n / d without a hardware division and without a branch: multiply-high by ceil(2^32 / d) (exact while n * d < 2^32);
+// d == 1 has no 32-bit magic, so it is encoded as magic 0 + an all-ones mask that passes n through
+struct DwlDiv {
+    unsigned magic, mask;
+};
+inline DwlDiv dwl_magic(unsigned d) {
+    DwlDiv v;
+    v.magic = d > 1 ? (unsigned)((0x100000000ULL + d - 1) / d) : 0u;
+    v.mask = d > 1 ? 0u : 0xffffffffu;
+    return v;
+}
+#ifdef __HIPCC__
+__device__ __forceinline__ unsigned dwl_div(unsigned n, const DwlDiv& d) { return __umulhi(n, d.magic) | (n & d.mask); }
+#endif
 
 inline DwlGeom dwl_plan(const DwShape& s) {
     DwlGeom g;
@@ -60,7 +82,7 @@ inline DwlGeom dwl_plan(const DwShape& s) {
         g.BR = s.OH;
         g.NB = 1;
         g.P = 1;
-        if (plane < 1024) {  // several whole planes per tile, sized by their PADDED image (small planes pad a lot)
+        if (plane < kTileFloats / 4) {  // several whole planes per tile, sized by their PADDED image (small planes pad a lot)
             g.P = (kImageFloats / ((s.H + 1) * (s.W + 4))) & ~3;
             if (g.P < 4) g.P = 4;
             while (g.P > 4 && g.P * plane > kTileFloats) g.P -= 4;
@@ -88,17 +110,41 @@ inline DwlGeom dwl_plan(const DwShape& s) {
 // plane) lands at LDS row j * RP + lr0 + row, column 4 + col
 struct DwlImg {
     int Wd, PW, RP, rpp, lr0;
-    unsigned wd_magic, rpp_magic;
+    DwlDiv wd_magic, rpp_magic;
 };
 __device__ __forceinline__ int dwl_slot(const DwlImg& m, int e, bool multi, int& j, int& row) {
-    const int gr = (int)magic_div((unsigned)e, m.wd_magic), col = e - gr * m.Wd;
+    const int gr = (int)dwl_div((unsigned)e, m.wd_magic), col = e - gr * m.Wd;
     j = 0;
     row = gr;
     if (multi) {
-        j = (int)magic_div((unsigned)gr, m.rpp_magic);
+        j = (int)dwl_div((unsigned)gr, m.rpp_magic);
         row = gr - j * m.rpp;
     }
     return (j * m.RP + m.lr0 + row) * m.PW + 4 + col;
+}
+
+// sum over the 16 lanes of a DPP row, valid in every lane of the row (the first four steps of wave_sum_dpp)
+__device__ __forceinline__ float row_sum_dpp(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));  // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));  // row_mirror
+    return v;
+}
+
+// the slot of the element after the one at (slot, j, row, col): rows that are not a multiple of 16 bytes are scattered
+// element by element, and walking beats dividing four times per 16 bytes
+__device__ __forceinline__ void dwl_next(const DwlImg& m, bool multi, int& slot, int& j, int& row, int& col) {
+    ++slot;
+    if (++col == m.Wd) {
+        col = 0;
+        slot += m.PW - m.Wd;
+        if (++row == m.rpp && multi) {
+            row = 0;
+            ++j;
+            slot += (m.RP - m.rpp) * m.PW;
+        }
+    }
 }
 
 __device__ __forceinline__ void dwl_zero(float* img, int floats) {  // floats % 4 == 0, img 16-byte aligned
@@ -129,10 +175,15 @@ __device__ __forceinline__ void dwl_scatter(const float* g, int count, bool vec,
             if (rowvec) {
                 *reinterpret_cast<float4*>(img + dwl_slot(m, e, multi, j, row)) = v[q];
             } else {
-                img[dwl_slot(m, e, multi, j, row)] = v[q].x;
-                img[dwl_slot(m, e + 1, multi, j, row)] = v[q].y;
-                img[dwl_slot(m, e + 2, multi, j, row)] = v[q].z;
-                img[dwl_slot(m, e + 3, multi, j, row)] = v[q].w;
+                int slot = dwl_slot(m, e, multi, j, row);
+                int col = slot - ((j * m.RP + m.lr0 + row) * m.PW + 4);
+                img[slot] = v[q].x;
+                dwl_next(m, multi, slot, j, row, col);
+                img[slot] = v[q].y;
+                dwl_next(m, multi, slot, j, row, col);
+                img[slot] = v[q].z;
+                dwl_next(m, multi, slot, j, row, col);
+                img[slot] = v[q].w;
             }
         }
     } else {
@@ -158,7 +209,7 @@ struct DwlFwdArgs {
     float* stats;  // NULL: none
     int C, H, W, OH, OW, planes, act, splits, RG;
     DwlGeom g;
-    unsigned w_magic, h_magic, ow_magic, rg_magic;
+    DwlDiv w_magic, h_magic, ow_magic, rg_magic;
     int x_floats;  // LDS floats of the x image (multiple of 4)
 };
 
@@ -199,8 +250,8 @@ __global__ __launch_bounds__(256) void dwl_fwd_kernel(const DwlFwdArgs a) {
     constexpr int NR = (VR - 1) * S + 3;
     const int items = Pe * a.RG * a.OW;
     for (int item = tid; item < items; item += 256) {
-        const int t = (int)magic_div((unsigned)item, a.ow_magic), ow = item - t * a.OW;
-        const int j = (int)magic_div((unsigned)t, a.rg_magic), rl0 = (t - j * a.RG) * VR;
+        const int t = (int)dwl_div((unsigned)item, a.ow_magic), ow = item - t * a.OW;
+        const int j = (int)dwl_div((unsigned)t, a.rg_magic), rl0 = (t - j * a.RG) * VR;
         const float* wp = wl + j * kConst;
         float wv[9];
 #pragma unroll
@@ -286,7 +337,7 @@ struct DwlBwdArgs {
     float fM;         // N * OH * OW as float (batch-norm)
     int C, H, W, OH, OW, planes, act, overwrite, write_back, splits, RG;
     DwlGeom g;
-    unsigned w_magic, h_magic, ow_magic, oh_magic, rg_magic, rgx_magic, hw2_magic;
+    DwlDiv w_magic, h_magic, ow_magic, oh_magic, rg_magic, rgx_magic, hw2_magic;
     int RGX;          // stride 1: ceil(own rows / 4) of a full band; stride 2: unused
     int x_floats, g_floats;
 };
@@ -297,10 +348,11 @@ template <int S, int VR, bool BN>
 __global__ __launch_bounds__(256) void dwl_bwd_kernel(const DwlBwdArgs a) {
     extern __shared__ float4 dwl_smem[];
     __shared__ float red[4][10];
+    // the dx rows are collected where the x image was: it is dead once the weight gradient is done
     float* xl = reinterpret_cast<float*>(dwl_smem);
-    float* gl = xl + a.x_floats;
-    float* dl = gl + a.g_floats;
-    float* wl = dl + a.g.stage_floats;
+    float* dl = xl;
+    float* gl = xl + a.x_floats;  // x_floats covers the larger of the two
+    float* wl = gl + a.g_floats;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int pb = tile / a.g.NB, band = tile - pb * a.g.NB;
@@ -355,20 +407,13 @@ __global__ __launch_bounds__(256) void dwl_bwd_kernel(const DwlBwdArgs a) {
         }
         wl[i] = v;
     }
-    if (!a.overwrite) {  // dx accumulates onto what is there: the sums start from the old values
-        if (((reinterpret_cast<uintptr_t>(gdx) & 15) == 0) && (dcount & 3) == 0) {
-            for (int i = tid; i < dcount / 4; i += 256) reinterpret_cast<float4*>(dl)[i] = reinterpret_cast<const float4*>(gdx)[i];
-        } else {
-            for (int i = tid; i < dcount; i += 256) dl[i] = gdx[i];
-        }
-    }
     __syncthreads();
     dwl_scatter<kMaxQ>(gx, xcount, xvec, xrowvec, multi, mx, xv, xl);
     {
         // g = [batch-norm backward of dz] * act'(y), into the image and (own rows, no batch-norm) back over dy
         auto one = [&](float gin, float yv, int j) -> float {
             float g = gin;
-            if (BN) {
+            if (BN && !(DWL_ABL & 4)) {
                 const float* k = wl + j * kConst;
                 g = bn_bwd_one(gin, 0.f, yv, k[9], k[10], k[11], k[12], k[13], a.fM, BCNN_HIP_ACT_NONE);
             }
@@ -395,12 +440,13 @@ __global__ __launch_bounds__(256) void dwl_bwd_kernel(const DwlBwdArgs a) {
                     if (wb && oh >= oh0 && oh < oh0 + BRt) reinterpret_cast<float4*>(gdy)[tid + q * 256] = o;
                 } else {  // whole planes: every row is the tile's own
                     int s0 = dwl_slot(mg, e, multi, j, row);
+                    int col = s0 - ((j * mg.RP + mg.lr0 + row) * mg.PW + 4);
                     o.x = one(gi.x, yv.x, j); gl[s0] = o.x;
-                    s0 = dwl_slot(mg, e + 1, multi, j, row);
+                    dwl_next(mg, multi, s0, j, row, col);
                     o.y = one(gi.y, yv.y, j); gl[s0] = o.y;
-                    s0 = dwl_slot(mg, e + 2, multi, j, row);
+                    dwl_next(mg, multi, s0, j, row, col);
                     o.z = one(gi.z, yv.z, j); gl[s0] = o.z;
-                    s0 = dwl_slot(mg, e + 3, multi, j, row);
+                    dwl_next(mg, multi, s0, j, row, col);
                     o.w = one(gi.w, yv.w, j); gl[s0] = o.w;
                     if (wb) reinterpret_cast<float4*>(gdy)[tid + q * 256] = o;
                 }
@@ -418,17 +464,21 @@ __global__ __launch_bounds__(256) void dwl_bwd_kernel(const DwlBwdArgs a) {
     __syncthreads();
 
     // ---- weight gradient + bias gradient over the tile's own output rows: one partial per plane ----
-    {
+    // One plane per workgroup: all 256 threads share it. Several planes: every 16-lane row of a wave takes a plane of its
+    // own (small planes have few items -- 14 on a 7 x 7 plane -- and a row sum costs four DPP steps instead of six).
+    if (!(DWL_ABL & 1)) {
         constexpr int NR = (VR - 1) * S + 3;
         const int items = a.RG * a.OW;
-        const int jstep = multi ? 4 : 1, jfirst = multi ? wid : 0;
-        const int ifirst = multi ? lane : tid, istep = multi ? 64 : 256;
-        for (int j = jfirst; j < Pe; j += jstep) {
+        const bool rows = a.g.P >= 8;  // fewer planes than that: a whole wave per plane keeps all four waves busy
+        const int jstep = multi ? (rows ? 16 : 4) : 1, jfirst = multi ? (rows ? wid * 4 + (lane >> 4) : wid) : 0;
+        const int ifirst = multi ? (rows ? (lane & 15) : lane) : tid, istep = multi ? (rows ? 16 : 64) : 256;
+        const int jend = (multi && rows) ? ((Pe + 15) & ~15) : Pe;  // whole waves walk together (DPP needs the lanes on)
+        for (int j = jfirst; j < jend; j += jstep) {
             float acc[10];
 #pragma unroll
             for (int i = 0; i < 10; ++i) acc[i] = 0.f;
-            for (int item = ifirst; item < items; item += istep) {
-                const int rg = (int)magic_div((unsigned)item, a.ow_magic), ow = item - rg * a.OW, rl0 = rg * VR;
+            for (int item = ifirst; item < items && j < Pe; item += istep) {
+                const int rg = (int)dwl_div((unsigned)item, a.ow_magic), ow = item - rg * a.OW, rl0 = rg * VR;
                 const float* ip = xl + (j * a.g.RPX + rl0 * S) * a.g.PWX + 3 + ow * S;
                 const float* gp = gl + (j * a.g.RPG + rl0 + 1) * a.g.PWG + 4 + ow;
                 float gvv[VR];
@@ -451,35 +501,51 @@ __global__ __launch_bounds__(256) void dwl_bwd_kernel(const DwlBwdArgs a) {
                     }
                 }
             }
-#pragma unroll
-            for (int i = 0; i < 10; ++i) acc[i] = wave_sum_dpp(acc[i]);
-            const int p = p0 + j, n = p / a.C, c = p - n * a.C;
-            float* dst = a.partials + ((size_t)c * a.splits + (size_t)n * a.g.NB + band) * kPart;
             if (multi) {
-                if (lane == 63) {
+#pragma unroll
+                for (int i = 0; i < 10; ++i) acc[i] = rows ? row_sum_dpp(acc[i]) : wave_sum_dpp(acc[i]);
+                if ((rows ? (lane & 15) == 0 : lane == 63) && j < Pe) {
+                    const int p = p0 + j, n = p / a.C, c = p - n * a.C;
+                    float* dst = a.partials + ((size_t)c * a.splits + n) * kPart;
 #pragma unroll
                     for (int i = 0; i < 10; ++i) dst[i] = acc[i];
                 }
             } else {
+#pragma unroll
+                for (int i = 0; i < 10; ++i) acc[i] = wave_sum_dpp(acc[i]);
                 if (lane == 63) {
 #pragma unroll
                     for (int i = 0; i < 10; ++i) red[wid][i] = acc[i];
                 }
                 __syncthreads();
-                if (tid < 10) dst[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+                if (tid < 10) {
+                    const int n = p0 / a.C, c = p0 - n * a.C;
+                    a.partials[((size_t)c * a.splits + (size_t)n * a.g.NB + band) * kPart + tid] =
+                        (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+                }
             }
         }
     }
 
+    __syncthreads();  // every wave is done with the x image: its space now collects dx
+    if (!a.overwrite) {  // dx accumulates onto what is there: the sums start from the old values
+        if (((reinterpret_cast<uintptr_t>(gdx) & 15) == 0) && (dcount & 3) == 0) {
+            for (int i = tid; i < dcount / 4; i += 256) reinterpret_cast<float4*>(dl)[i] = reinterpret_cast<const float4*>(gdx)[i];
+        } else {
+            for (int i = tid; i < dcount; i += 256) dl[i] = gdx[i];
+        }
+        __syncthreads();
+    }
     // ---- data gradient of the tile's own input rows, per pixel the taps in the reference's scatter order
     //      (descending kh, kw == ascending output position) ----
-    if (S == 1) {
+    if (DWL_ABL & 2) {
+    } else if (S == 1) {
         constexpr int VRX = 4;
         const int rgx_n = a.RGX;
         const int items = Pe * rgx_n * a.W;
         for (int item = tid; item < items; item += 256) {
-            const int t = (int)magic_div((unsigned)item, a.w_magic), iw = item - t * a.W;
-            const int j = (int)magic_div((unsigned)t, a.rgx_magic), il0 = (t - j * rgx_n) * VRX;
+            const int t = (int)dwl_div((unsigned)item, a.w_magic), iw = item - t * a.W;
+            const int j = (int)dwl_div((unsigned)t, a.rgx_magic), il0 = (t - j * rgx_n) * VRX;
             const float* wp = wl + j * kConst;
             float wv[9];
 #pragma unroll
@@ -510,10 +576,10 @@ __global__ __launch_bounds__(256) void dwl_bwd_kernel(const DwlBwdArgs a) {
         const int hw2 = (a.W + 1) >> 1;
         const int items = Pe * BRt * hw2;
         for (int item = tid; item < items; item += 256) {
-            const int t = (int)magic_div((unsigned)item, a.hw2_magic), b = item - t * hw2;
+            const int t = (int)dwl_div((unsigned)item, a.hw2_magic), b = item - t * hw2;
             int j = 0, ar = t;
             if (multi) {
-                j = (int)magic_div((unsigned)t, a.oh_magic);
+                j = (int)dwl_div((unsigned)t, a.oh_magic);
                 ar = t - j * a.OH;
             }
             const float* wp = wl + j * kConst;
@@ -592,7 +658,7 @@ bool depthwise_lds_ok(const DwShape& s) {
     if (!on) return false;
     if (s.ksz != 3 || s.pad != 1 || (s.stride != 1 && s.stride != 2)) return false;
     if (s.N < 1 || s.C < 1 || s.H < 1 || s.W < 1 || s.OH < 1 || s.OW < 1) return false;
-    if (s.W > 512) return false;  // a band needs at least 3 + stride input rows of <= 4096 floats
+    if (s.W > kTileFloats / 8) return false;  // a band needs at least 3 + stride input rows of <= kTileFloats floats
     const DwlGeom g = dwl_plan(s);
     const long long tiles = (long long)ceil_div((long long)s.N * s.C, g.P) * g.NB;
     return tiles < 0x7fffffffLL && (long long)s.N * s.C * s.H * s.W < 0x7fffffffLL * 2;
@@ -655,6 +721,7 @@ bool depthwise_backward_lds(const float* x, const float* w, const float* y, floa
     const int own_rows = a.g.BR * S < s.H ? a.g.BR * S : s.H;
     a.g.stage_floats = (a.g.P * own_rows * s.W + 3) & ~3;
     a.x_floats = (a.g.rows_x * a.g.PWX + 3) & ~3;
+    if (a.x_floats < a.g.stage_floats) a.x_floats = a.g.stage_floats;  // the dx rows reuse the x image's space
     a.g_floats = (a.g.rows_g * a.g.PWG + 3) & ~3;
     a.w_magic = dwl_magic((unsigned)s.W); a.h_magic = dwl_magic((unsigned)s.H);
     a.ow_magic = dwl_magic((unsigned)s.OW); a.oh_magic = dwl_magic((unsigned)s.OH);
@@ -663,7 +730,7 @@ bool depthwise_backward_lds(const float* x, const float* w, const float* y, floa
     a.fM = (float)((long long)s.N * s.OH * s.OW);
     if (bn) a.bn = *bn;
     else a.bn = DwBnBwd{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    const size_t lds = (size_t)(a.x_floats + a.g_floats + a.g.stage_floats + a.g.P * kConst) * sizeof(float);
+    const size_t lds = (size_t)(a.x_floats + a.g_floats + a.g.P * kConst) * sizeof(float);
     if (lds > 64 * 1024) return false;
     a.partials = reduce_scratch((size_t)s.C * a.splits * kPart);
     const unsigned tiles = (unsigned)ceil_div((long long)a.planes, a.g.P) * (unsigned)a.g.NB;

@@ -3,6 +3,7 @@
 // tiny next to the convolutions; they exist so a training step never leaves the device.
 #include <cfloat>
 
+#include "chan_reduce.h"
 #include "common.h"
 
 namespace bcnn_hip {
@@ -124,15 +125,18 @@ __global__ __launch_bounds__(256) void softmax_kernel(const float* __restrict__ 
 // ResNet-18 step here); one 1024-thread workgroup computes it in place and only the 4-byte result travels.
 // Sums are accumulated in double like the host loops; per-row work is done by one wave with the reference's
 // "first strict maximum above FLT_MIN wins" rule.
+// Grid of `gridDim.x` workgroups, each leaves one double in partials[blockIdx.x]; cost_metric_final_kernel adds them in
+// index order (a single workgroup over 256 x 1000 values took 97 us of the MobileNet step).
 __global__ __launch_bounds__(1024) void cost_metric_kernel(int metric, const float* __restrict__ pred,
                                                            const float* __restrict__ label,
                                                            const float* __restrict__ grad, int B, int per,
-                                                           float* __restrict__ out) {
+                                                           double* __restrict__ partials) {
     __shared__ double red[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nrow = 16 * gridDim.x, row0 = blockIdx.x * 16 + wave;
     double acc = 0.0;
     if (metric == 0) {  // BCNN_METRIC_ERROR_RATE
-        for (int i = wave; i < B; i += 16) {
+        for (int i = row0; i < B; i += nrow) {
             const float* row = pred + (size_t)i * per;
             float pm = FLT_MIN;
             int best = 0;
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(1024) void cost_metric_kernel(int metric, const flo
             if (lane == 0 && label[(size_t)i * per + best] == 0) acc += 1.0;
         }
     } else if (metric == 5) {  // BCNN_METRIC_DICE
-        for (int i = wave; i < B; i += 16) {
+        for (int i = row0; i < B; i += nrow) {
             int n = 0, d = 0;
             for (int j = lane; j < per; j += 64) {
                 const float l = label[(size_t)i * per + j];
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(1024) void cost_metric_kernel(int metric, const flo
         }
     } else {
         const size_t sz = (size_t)B * per;
-        for (size_t i = threadIdx.x; i < sz; i += 1024) {
+        for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < sz; i += (size_t)gridDim.x * 1024) {
             if (metric == 1) {  // BCNN_METRIC_LOGLOSS
                 if (label[i] > 0.0f) {
                     float q = pred[i];
@@ -180,8 +184,14 @@ __global__ __launch_bounds__(1024) void cost_metric_kernel(int metric, const flo
     if (threadIdx.x == 0) {
         double t = 0.0;
         for (int w = 0; w < 16; ++w) t += red[w];
-        out[0] = (float)(metric == 3 ? t / per : t);  // BCNN_METRIC_MSE divides by the per-sample size
+        partials[blockIdx.x] = t;
     }
+}
+__global__ void cost_metric_final_kernel(int metric, const double* __restrict__ partials, int n, int per,
+                                         float* __restrict__ out) {
+    double t = 0.0;
+    for (int i = 0; i < n; ++i) t += partials[i];
+    out[0] = (float)(metric == 3 ? t / per : t);  // BCNN_METRIC_MSE divides by the per-sample size
 }
 
 }  // namespace bcnn_hip
@@ -244,7 +254,14 @@ void bcnn_hip_eltwise_backward(const float* y, float* dy, float* da, float* db, 
 
 void bcnn_hip_cost_metric(int metric, const float* pred, const float* label, const float* grad, int batch, int per,
                           float* out) {
-    cost_metric_kernel<<<1, 1024, 0, current_stream()>>>(metric, pred, label, grad, batch, per, out);
+    const long long sz = (long long)batch * per;
+    int blocks = (int)((sz + 8191) / 8192);  // >= 8 values per thread before a second workgroup pays
+    if (blocks > 64) blocks = 64;
+    if (blocks < 1) blocks = 1;
+    double* partials = reinterpret_cast<double*>(reduce_scratch(2 * 64));
+    cost_metric_kernel<<<blocks, 1024, 0, current_stream()>>>(metric, pred, label, grad, batch, per, partials);
+    KERNEL_CHECK();
+    cost_metric_final_kernel<<<1, 1, 0, current_stream()>>>(metric, partials, blocks, per, out);
     KERNEL_CHECK();
 }
 
