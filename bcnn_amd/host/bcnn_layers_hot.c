@@ -445,20 +445,24 @@ void bcnn_link_depthwise_batchnorm(bcnn_net *net) {
         bcnn_depthwise_conv_param *dp = (bcnn_depthwise_conv_param *)dw->param;
         const bcnn_tensor *x = &net->tensors[dw->src[0]];
         /* forward: the statistics of the depthwise output are the same whoever else reads it */
-        const size_t need = bcnn_hip_depthwise_stats_size(x->n, x->c, x->h, x->w, dp->size, dp->stride, dp->pad);
-        if (need > 0) {
-            if (need > dp->stats_floats) {
-                bcnn_hip_sync();
-                bcnn_hip_free(dp->stats_gpu);
-                dp->stats_gpu = bcnn_hip_malloc_f32(need);
-                dp->stats_floats = need;
-            }
-            dp->bn_node = j;
-            bp->dw_node = producer;
+        size_t need = bcnn_hip_depthwise_stats_size(x->n, x->c, x->h, x->w, dp->size, dp->stride, dp->pad);
+        if (BCNN_EXP_ENV("BCNN_NO_DW_STATS")) need = 0; /* experiment build: forward hand-off off, backward fusion on */
+        if (need > dp->stats_floats) {
+            bcnn_hip_sync();
+            bcnn_hip_free(dp->stats_gpu);
+            dp->stats_gpu = bcnn_hip_malloc_f32(need);
+            dp->stats_floats = need;
+        } else if (need == 0 && dp->stats_gpu) { /* no scratch = no hand-off (bcnn_forward_depthwise_conv_layer) */
+            bcnn_hip_sync();
+            bcnn_hip_free(dp->stats_gpu);
+            dp->stats_gpu = NULL;
+            dp->stats_floats = 0;
         }
+        dp->bn_node = j;
+        bp->dw_node = producer;
         /* backward: the gradient of the depthwise output has this node as its only writer and that node as its only
          * reader, so it does not have to exist */
-        if (dp->bn_node == j && private_input &&
+        if (private_input &&
             bcnn_hip_depthwise_bn_fusable(x->n, x->c, x->h, x->w, dp->size, dp->stride, dp->pad, (int)dp->activation)) {
             dp->bn_fused_bwd = 1;
             bp->dw_fused_bwd = 1;

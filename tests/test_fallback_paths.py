@@ -15,8 +15,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"BCNN_HIP_NO_DMA": "1"}, {"BCNN_HIP_NO_FUSED_STATS": "1"},
-                                 {"BCNN_HIP_NO_SMALLC_DX": "1", "BCNN_HIP_NO_PREFETCH": "1"}],
-                         ids=["register_staged_kernels", "unfused_bn_statistics", "implicit_gemm_dx_for_small_c"])
+                                 {"BCNN_HIP_NO_SMALLC_DX": "1", "BCNN_HIP_NO_PREFETCH": "1"}, {"BCNN_HIP_NO_DW_LDS": "1"}],
+                         ids=["register_staged_kernels", "unfused_bn_statistics", "implicit_gemm_dx_for_small_c",
+                              "register_window_depthwise_kernels"])
 def test_golden_suite_on_the_other_code_path(env):
     e = dict(os.environ)
     e.update(env)
@@ -65,6 +66,52 @@ def test_experiment_host_runtime_with_every_gradient_fill_kept_trains_bit_identi
                      "BCNN_KEEP_ALL_GRAD_FILLS": "1"}):
         e = dict(os.environ); e.update(env)
         r = subprocess.run([sys.executable, "-c", _TRAIN], cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        shas.append([ln for ln in r.stdout.splitlines() if ln.startswith("SHA")][0])
+    assert shas[0] == shas[1]
+
+
+_TRAIN_MB = r"""
+import ctypes, hashlib, sys
+sys.path.insert(0, %r)
+import numpy as np, torch
+import bench
+from bcnn_amd import capi
+ctypes.CDLL(None).srand(12)
+net = capi.Net(mode=capi.MODE_TRAIN, w=64, h=64, c=3, n=4)
+bench.build_mobilenet_v1(net, capi, classes=10)
+net.compile(); net.set_sgd(0.01, 0.9, 5e-4)
+rs = np.random.RandomState(4)
+for _ in range(3):
+    net.data(0)[...] = rs.uniform(-1, 1, net.shape(0))
+    lab = np.zeros(net.shape(1), np.float32); lab[np.arange(4), rs.randint(0, 10, 4)] = 1
+    net.data(1)[...] = lab.reshape(net.shape(1))
+    net.upload(0); net.upload(1)
+    net.forward(); net.backward(); net.update()
+net.sync()
+p, n = net.parameter_arena()
+print("SHA", hashlib.sha256(torch.as_tensor(capi.DeviceArray(p, n), device="cuda:0").cpu().numpy().tobytes()).hexdigest())
+""" % ROOT
+
+
+@pytest.mark.gpu
+def test_depthwise_batchnorm_backward_fusion_trains_bit_identically():
+    """bcnn_link_depthwise_batchnorm (host/bcnn_layers_hot.c) lets a depthwise node and the batch-norm node behind it
+    share work inside bcnn_forward / bcnn_backward. The experiment host runtime can switch the sharing off:
+    BCNN_NO_NODE_FUSION=1 runs every worker on its own like the reference does, BCNN_NO_DW_STATS=1 only stops the
+    forward statistics hand-off. With the SAME batch statistics (hand-off off in both runs) the fused backward -- the
+    batch-norm backward applied on the fly inside the depthwise kernel, no copy of the batch-norm input, gradient tensors
+    not written -- performs the separate workers' operations in their order, so three SGD steps of MobileNet-v1 (64 x 64
+    input: planes from 32 x 32 down to 2 x 2) must leave bit-identical parameters. (With the hand-off on, the statistics
+    are the same sums in another fixed order: 1e-7 apart, which this randomly initialised 27-batch-norm net at batch 4
+    amplifies to 1e-2 in the gradients -- on both sides of any comparison; that path is pinned against the reference by
+    the mobilenet graph of tests/test_net_parity.py and by tests/test_depthwise_lds.py.)"""
+    lib = os.path.join(ROOT, "bcnn_amd", "lib")
+    exp = {"BCNN_LIB": os.path.join(lib, "libbcnn_exp.so"), "BCNN_HIP_LIB": os.path.join(lib, "libbcnn_hip_exp.so")}
+    shas = []
+    for extra in ({"BCNN_NO_DW_STATS": "1"}, {"BCNN_NO_NODE_FUSION": "1"}):
+        e = dict(os.environ); e.update(exp); e.update(extra)
+        r = subprocess.run([sys.executable, "-c", _TRAIN_MB], cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         shas.append([ln for ln in r.stdout.splitlines() if ln.startswith("SHA")][0])
     assert shas[0] == shas[1]
