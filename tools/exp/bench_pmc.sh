@@ -54,8 +54,8 @@ out = {
    "conv_dw_winograd": cls(lambda k: "wino_dw" in k or "wino_input_transform" in k or "wino_dy_transform" in k),
    "bn_fwd": cls(lambda k: "BnApplyBody" in k or "bn_stats" in k or "StatsF" in k),
    "bn_bwd": cls(lambda k: "BnBwd" in k or "bn_bwd" in k or "BwdSumsF" in k),
-   "depthwise_fwd": cls(lambda k: "dw3_fwd" in k or "dw_fwd" in k),
-   "depthwise_bwd": cls(lambda k: "dw3_bwd" in k or "dw_bwd" in k or "ActBwdSumF" in k or "dw_weight_accumulate" in k),
+   "depthwise_fwd": cls(lambda k: "dw3_fwd" in k or "dw_fwd" in k or "dwl_fwd" in k),
+   "depthwise_bwd": cls(lambda k: "dw3_bwd" in k or "dw_bwd" in k or "dwl_bwd" in k or "dwl_finalize" in k or "ActBwdSumF" in k or "dw_weight_accumulate" in k),
  },
  "kernels": {k[:120]: v for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["hbm_bytes_per_step"])[:24]},
  "total_hbm_bytes_per_step": sum(v["hbm_bytes_per_step"] for v in rows.values()),
