@@ -71,6 +71,10 @@ SIGNATURES = {
     "bcnn_hip_batchnorm_backward_sums": (None, [vp] * 9 + [i, i, i]),
     "bcnn_hip_depthwise_backward_bn": (None, [vp] * 7 + [i] * 9 + [vp] * 5),
     "bcnn_hip_batchnorm_backward_apply": (None, [vp] * 8 + [i, i, i]),
+    "bcnn_hip_conv_residual_fusable": (i, [i, i, i, i, vp, vp, vp]),
+    "bcnn_hip_conv_forward_residual": (None, [vp, vp, vp] + [i] * 9 + [vp] * 7 + [sz, i, vp]),
+    "bcnn_hip_conv_backward_residual": (None, [vp] * 7 + [i] * 9 + [vp] * 7 + [vp, sz, vp, vp, i, vp, vp, sz]),
+    "bcnn_hip_batchnorm_apply": (None, [vp] * 6 + [i, i, i, i]),
     "bcnn_hip_sgd_update": (None, [vp, vp, vp, vp, sz, sz, i, f, f, f]),
     "bcnn_hip_sgd_update_chunks": (None, [vp, i, i, f, f, f]),
     "bcnn_hip_zero_chunks": (None, [vp, i]),

@@ -104,6 +104,11 @@ struct BnApplyArgs {
     const float* bias;
     int C, HW, predict, act;
     long long total;
+    // a following eltwise node folded into this pass (bcnn_eltwise_layer.c:82-113): y = act2(act(bn(x)) + res[off]) for
+    // off < res_count (the reference adds its second operand to the first res_count elements only), act2(act(bn(x))) behind
+    const float* res;
+    unsigned res_count;
+    int act2;
 };
 
 struct BnApplyBody {
@@ -123,12 +128,25 @@ struct BnApplyBody {
             yv.w = bn_one(xv.w, mean, rs, sc, b, a.predict, a.act, &nv.w);
             if (side_ws) *reinterpret_cast<float4*>(a.ws + off) = xv;
             if (side_xn) *reinterpret_cast<float4*>(a.xn + off) = nv;
+            if (a.res) {
+                if (off + 4 <= a.res_count) {
+                    const float4 r = *reinterpret_cast<const float4*>(a.res + off);
+                    yv.x += r.x; yv.y += r.y; yv.z += r.z; yv.w += r.w;
+                } else if (off < a.res_count) {
+                    yv.x += a.res[off];
+                    if (off + 1 < a.res_count) yv.y += a.res[off + 1];
+                    if (off + 2 < a.res_count) yv.z += a.res[off + 2];
+                }
+                yv.x = act_fwd_cheap(yv.x, a.act2, 0.f); yv.y = act_fwd_cheap(yv.y, a.act2, 0.f);
+                yv.z = act_fwd_cheap(yv.z, a.act2, 0.f); yv.w = act_fwd_cheap(yv.w, a.act2, 0.f);
+            }
             *reinterpret_cast<float4*>(a.y + off) = yv;
         } else {
             for (int k = 0; k < cnt; ++k) {
                 const float xv = a.x[off + k];
                 float nv = 0.f;
-                const float yv = bn_one(xv, mean, rs, sc, b, a.predict, a.act, &nv);
+                float yv = bn_one(xv, mean, rs, sc, b, a.predict, a.act, &nv);
+                if (a.res) yv = act_fwd_cheap(yv + (off + k < a.res_count ? a.res[off + k] : 0.f), a.act2, 0.f);
                 if (side_ws) a.ws[off + k] = xv;
                 if (side_xn) a.xn[off + k] = nv;
                 a.y[off + k] = yv;
@@ -139,6 +157,18 @@ struct BnApplyBody {
 
 // ---- backward sums ---------------------------------------------------------------------------------
 // g' = dy * act'(y) (optional fused activation backward);  S1 = sum g',  S2 = sum g' * (x - mean)
+// The value the forward pass stored for pre-normalisation input x at flat offset `off`, recomputed with the forward's
+// operations (bit-identical): act(bn(x)), or with a folded eltwise node (res != NULL) act(bn(x) + res[off]) for
+// off < res_count.
+__device__ __forceinline__ float bn_recompute_y(float x, float m, float rs, float sc, float b, int act, const float* res,
+                                                unsigned res_count, unsigned long long off) {
+    float dummy;
+    if (!res) return bn_one(x, m, rs, sc, b, 0, act, &dummy);
+    float v = bn_one(x, m, rs, sc, b, 0, BCNN_HIP_ACT_NONE, &dummy);
+    if (off < res_count) v += res[off];
+    return act_fwd_cheap(v, act, 0.f);
+}
+
 struct BwdSumsF {
     const float* dy;
     const float* y;   // post-activation output, used only when act != NONE and fwd_bias == NULL
@@ -150,14 +180,16 @@ struct BwdSumsF {
     const float* var;
     const float* scale;
     int act, C, HW;
-    __device__ float fwd_y(float xv, int c) const {
-        float dummy;
-        return bn_one(xv, mean[c], sqrtf(var[c] + 0.000001f), scale[c], fwd_bias[c], 0, act, &dummy);
+    const float* res;     // folded eltwise node (with fwd_bias): its second operand and how much of it is added
+    unsigned res_count;
+    __device__ float fwd_y(float xv, int c, long long off) const {
+        return bn_recompute_y(xv, mean[c], sqrtf(var[c] + 0.000001f), scale[c], fwd_bias[c], act, res, res_count,
+                              (unsigned long long)off);
     }
     __device__ void operator()(long long off, int c, float (&acc)[2]) const {
         float g = dy[off];
         const float xv = x[off];
-        if (act != BCNN_HIP_ACT_NONE) g *= act_bwd_cheap(fwd_bias ? fwd_y(xv, c) : y[off], act, 0.f);
+        if (act != BCNN_HIP_ACT_NONE) g *= act_bwd_cheap(fwd_bias ? fwd_y(xv, c, off) : y[off], act, 0.f);
         acc[0] += g;
         acc[1] += g * (xv - mean[c]);
     }
@@ -168,10 +200,12 @@ struct BwdSumsF {
         if (act != BCNN_HIP_ACT_NONE) {
             float4 yv;
             if (fwd_bias) {
-                float dummy;
                 const float rs = sqrtf(var[c] + 0.000001f), sc = scale[c], b = fwd_bias[c];
-                yv.x = bn_one(xv.x, m, rs, sc, b, 0, act, &dummy); yv.y = bn_one(xv.y, m, rs, sc, b, 0, act, &dummy);
-                yv.z = bn_one(xv.z, m, rs, sc, b, 0, act, &dummy); yv.w = bn_one(xv.w, m, rs, sc, b, 0, act, &dummy);
+                const unsigned long long o = (unsigned long long)off;
+                yv.x = bn_recompute_y(xv.x, m, rs, sc, b, act, res, res_count, o);
+                yv.y = bn_recompute_y(xv.y, m, rs, sc, b, act, res, res_count, o + 1);
+                yv.z = bn_recompute_y(xv.z, m, rs, sc, b, act, res, res_count, o + 2);
+                yv.w = bn_recompute_y(xv.w, m, rs, sc, b, act, res, res_count, o + 3);
             } else {
                 yv = *reinterpret_cast<const float4*>(y + off);
             }
@@ -220,6 +254,9 @@ struct BnBwdApplyArgs {
     const float* fwd_bias;  // != NULL: recompute the forward output from x instead of reading y
     int C, HW, act, M;
     long long total;
+    int keep_dy;            // dy is only read; the result goes to dx alone
+    const float* res;       // folded eltwise node (with fwd_bias), see bn_recompute_y
+    unsigned res_count;
 };
 
 struct BnBwdApplyBody {
@@ -230,7 +267,6 @@ struct BnBwdApplyBody {
         const bool use_act = a.act != BCNN_HIP_ACT_NONE, use_y = use_act && a.fwd_bias == nullptr;
         const float mean = a.mean[c], rs = sqrtf(a.var[c] + 0.00001f), sc = a.scale[c];
         const float rs_fwd = sqrtf(a.var[c] + 0.000001f), fb = a.fwd_bias ? a.fwd_bias[c] : 0.f;
-        float dummy;
         const float dmm = __fdiv_rn(a.dmean[c], fM), dv = a.dvar[c];
         if (cnt == 4 && al && (off & 3u) == 0) {
             const float4 g = *reinterpret_cast<const float4*>(a.dy + off);
@@ -238,22 +274,25 @@ struct BnBwdApplyBody {
             float4 yv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (use_y) yv = *reinterpret_cast<const float4*>(a.y + off);
             else if (use_act) {
-                yv.x = bn_one(xv.x, mean, rs_fwd, sc, fb, 0, a.act, &dummy); yv.y = bn_one(xv.y, mean, rs_fwd, sc, fb, 0, a.act, &dummy);
-                yv.z = bn_one(xv.z, mean, rs_fwd, sc, fb, 0, a.act, &dummy); yv.w = bn_one(xv.w, mean, rs_fwd, sc, fb, 0, a.act, &dummy);
+                yv.x = bn_recompute_y(xv.x, mean, rs_fwd, sc, fb, a.act, a.res, a.res_count, off);
+                yv.y = bn_recompute_y(xv.y, mean, rs_fwd, sc, fb, a.act, a.res, a.res_count, off + 1ull);
+                yv.z = bn_recompute_y(xv.z, mean, rs_fwd, sc, fb, a.act, a.res, a.res_count, off + 2ull);
+                yv.w = bn_recompute_y(xv.w, mean, rs_fwd, sc, fb, a.act, a.res, a.res_count, off + 3ull);
             }
             float4 o;
             o.x = bn_bwd_one(g.x, yv.x, xv.x, mean, rs, sc, dmm, dv, fM, a.act);
             o.y = bn_bwd_one(g.y, yv.y, xv.y, mean, rs, sc, dmm, dv, fM, a.act);
             o.z = bn_bwd_one(g.z, yv.z, xv.z, mean, rs, sc, dmm, dv, fM, a.act);
             o.w = bn_bwd_one(g.w, yv.w, xv.w, mean, rs, sc, dmm, dv, fM, a.act);
-            *reinterpret_cast<float4*>(a.dy + off) = o;
+            if (!a.keep_dy) *reinterpret_cast<float4*>(a.dy + off) = o;
             if (a.dx) *reinterpret_cast<float4*>(a.dx + off) = o;
         } else {
             for (int k = 0; k < cnt; ++k) {
                 const float xk = a.x[off + k];
-                const float yk = use_y ? a.y[off + k] : (use_act ? bn_one(xk, mean, rs_fwd, sc, fb, 0, a.act, &dummy) : 0.f);
+                const float yk = use_y ? a.y[off + k]
+                                       : (use_act ? bn_recompute_y(xk, mean, rs_fwd, sc, fb, a.act, a.res, a.res_count, off + k) : 0.f);
                 const float o = bn_bwd_one(a.dy[off + k], yk, xk, mean, rs, sc, dmm, dv, fM, a.act);
-                a.dy[off + k] = o;
+                if (!a.keep_dy) a.dy[off + k] = o;
                 if (a.dx) a.dx[off + k] = o;
             }
         }
@@ -264,7 +303,7 @@ struct BnBwdApplyBody {
 // pre: statistics partials already produced by the convolution epilogue (pre->splits > 0), else NULL
 void batchnorm_forward_impl(const float* x, float* y, float* run_mean, float* run_var, const float* scales,
                             const float* bias, float* saved_mean, float* saved_var, float* x_norm, float* workspace,
-                            int n, int c, int hw, int mode, int act, const ConvStats* pre) {
+                            int n, int c, int hw, int mode, int act, const ConvStats* pre, const BnResidual* res) {
     const long long M = (long long)n * hw, total = M * c;
     if (!total) return;
     const bool have_pre = pre && pre->splits > 0 && mode == BCNN_HIP_MODE_TRAIN;
@@ -275,6 +314,12 @@ void batchnorm_forward_impl(const float* x, float* y, float* run_mean, float* ru
     BnApplyArgs a;
     a.x = x; a.y = y; a.ws = workspace; a.xn = x_norm; a.scale = scales; a.bias = bias;
     a.C = c; a.HW = hw; a.act = act; a.total = total;
+    a.res = nullptr; a.res_count = 0; a.act2 = BCNN_HIP_ACT_NONE;
+    if (res) {  // the caller checked: both activations cheap, 16-byte aligned operand
+        a.res = res->res;
+        a.res_count = (unsigned)(res->count < (size_t)total ? res->count : (size_t)total);
+        a.act2 = res->act;
+    }
     a.predict = (mode == BCNN_HIP_MODE_PREDICT);
     a.mean = run_mean; a.var = run_var;
     if (mode == BCNN_HIP_MODE_PREDICT) a.ws = nullptr;  // the reference keeps no copy in PREDICT mode
@@ -294,7 +339,7 @@ void batchnorm_forward_impl(const float* x, float* y, float* run_mean, float* ru
         a.mean = saved_mean; a.var = saved_var;
     }
     auto al16 = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    launch_chan_map(BnApplyBody{a, al16(x) && al16(y) && al16(a.ws) && al16(a.xn)}, n, c, hw);
+    launch_chan_map(BnApplyBody{a, al16(x) && al16(y) && al16(a.ws) && al16(a.xn) && al16(a.res)}, n, c, hw);
     if (want_act != act) bcnn_hip_activation_forward(y, (size_t)total, want_act, nullptr, hw, c);
 }
 
@@ -309,7 +354,7 @@ void bcnn_hip_batchnorm_forward(const float* x, float* y, float* run_mean, float
                                 float* saved_var, float* x_norm, float* workspace, int n, int c, int hw,
                                 int mode, int act) {
     batchnorm_forward_impl(x, y, run_mean, run_var, scales, bias, saved_mean, saved_var, x_norm, workspace, n, c, hw,
-                           mode, act, nullptr);
+                           mode, act, nullptr, nullptr);
 }
 
 void bcnn_hip_batchnorm_forward_stats(const float* x, float* y, float* run_mean, float* run_var, const float* scales,
@@ -319,7 +364,7 @@ void bcnn_hip_batchnorm_forward_stats(const float* x, float* y, float* run_mean,
     ConvStats st;
     st.partials = const_cast<float*>(stats); st.splits = stats ? splits : 0; st.capacity = 0;
     batchnorm_forward_impl(x, y, run_mean, run_var, scales, bias, saved_mean, saved_var, x_norm, workspace, n, c, hw,
-                           mode, act, &st);
+                           mode, act, &st, nullptr);
 }
 
 }  // extern "C"
@@ -328,13 +373,14 @@ namespace bcnn_hip {
 // S1 = sum g', S2 = sum g' (x - mean) per channel -> dbias, dscales, dmean, dvar (the first sweep of the backward pass)
 static void batchnorm_backward_sums(const float* dy, const float* y, int act, const float* scales, float* dscales,
                                     float* dbias, const float* saved_mean, const float* saved_var, float* dmean,
-                                    float* dvar, const float* workspace, int n, int c, int hw, const float* fwd_bias) {
+                                    float* dvar, const float* workspace, int n, int c, int hw, const float* fwd_bias,
+                                    const float* res = nullptr, unsigned res_count = 0) {
     const long long M = (long long)n * hw;
     const int splits = chan_splits(c, M);
     float* part = reduce_scratch((size_t)c * splits * 2);
     BwdSumsF f;
     f.dy = dy; f.y = y; f.x = workspace; f.mean = saved_mean; f.act = act; f.C = c; f.HW = hw;
-    f.fwd_bias = fwd_bias; f.var = saved_var; f.scale = scales;
+    f.fwd_bias = fwd_bias; f.var = saved_var; f.scale = scales; f.res = res; f.res_count = res_count;
     launch_chan_reduce<2>(f, c, hw, M, splits, part);
     bn_bwd_finalize_kernel<<<ceil_div(c, 256), 256, 0, current_stream()>>>(part, c, splits, scales, saved_var,
                                                                           dbias, dscales, dmean, dvar);
@@ -345,12 +391,14 @@ static void batchnorm_backward_sums(const float* dy, const float* y, int act, co
 static void batchnorm_backward_apply(float* dy, float* dx, const float* y, int act, const float* scales,
                                      const float* saved_mean, const float* saved_var, const float* dmean,
                                      const float* dvar, const float* workspace, int n, int c, int hw,
-                                     const float* fwd_bias) {
+                                     const float* fwd_bias, int keep_dy = 0, const float* res = nullptr,
+                                     unsigned res_count = 0) {
     const long long M = (long long)n * hw, total = M * c;
     BnBwdApplyArgs a;
     a.dy = dy; a.dx = (dx && dx != dy) ? dx : nullptr; a.y = y; a.x = workspace;
     a.mean = saved_mean; a.var = saved_var; a.scale = scales; a.dmean = dmean; a.dvar = dvar;
     a.C = c; a.HW = hw; a.act = act; a.M = (int)M; a.total = total; a.fwd_bias = fwd_bias;
+    a.keep_dy = keep_dy; a.res = res; a.res_count = res_count;
     auto al16 = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     launch_chan_map(BnBwdApplyBody{a, al16(dy) && al16(a.dx) && al16(workspace) && al16(y)}, n, c, hw);
 }
@@ -373,9 +421,52 @@ void batchnorm_backward_impl(float* dy, float* dx, const float* y, int act, cons
                             fwd_bias);
     batchnorm_backward_apply(dy, dx, y, act, scales, saved_mean, saved_var, dmean, dvar, workspace, n, c, hw, fwd_bias);
 }
+// d(res)[i] += dout[i] * act'(out[i]) for the first `count` elements (the partial operand of the folded eltwise node)
+__global__ __launch_bounds__(256) void bn_residual_grad_kernel(const float* __restrict__ out, const float* __restrict__ dout,
+                                                               float* __restrict__ dres, unsigned count, int act) {
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u)
+        dres[i] += dout[i] * act_bwd_cheap(out[i], act, 0.f);  // `out` is read here only: one image's worth
+}
+
+// Backward of a batch-norm (no activation of its own) whose output went through a folded eltwise node: the incoming
+// gradient is dout * act'(out) (bcnn_eltwise_layer.c:124-127), read from the eltwise node's tensors and NOT rewritten; the
+// gradient w.r.t. the batch-norm input goes to dx. dres (optional) accumulates the partial operand's gradient.
+// The eltwise output needed by act' is RECOMPUTED from x, the forward bias and res (bn_recompute_y: the forward's own
+// operations, bit-identical) instead of read: the two sweeps read (dout, x) like a plain batch-norm backward.
+void batchnorm_backward_residual(const float* dout, const float* out, int act_res, const float* res, float* dres,
+                                 size_t res_count, float* dx, const float* scales, float* dscales, float* dbias,
+                                 const float* fwd_bias, const float* saved_mean, const float* saved_var, float* dmean,
+                                 float* dvar, const float* workspace, int n, int c, int hw) {
+    const long long total = (long long)n * hw * c;
+    if (!total) return;
+    KTimer kt(K_BN_BWD, 0.0, 4.0 * 5.0 * (double)total);  // (dout, x) twice + dx
+    const unsigned cnt = (unsigned)(res_count < (size_t)total ? res_count : (size_t)total);
+    if (dres && cnt) {
+        bn_residual_grad_kernel<<<stream_grid(cnt, 256), 256, 0, current_stream()>>>(out, dout, dres, cnt, act_res);
+        KERNEL_CHECK();
+    }
+    batchnorm_backward_sums(dout, out, act_res, scales, dscales, dbias, saved_mean, saved_var, dmean, dvar, workspace, n, c,
+                            hw, fwd_bias, res, cnt);
+    batchnorm_backward_apply(const_cast<float*>(dout), dx, out, act_res, scales, saved_mean, saved_var, dmean, dvar,
+                             workspace, n, c, hw, fwd_bias, /*keep_dy=*/1, res, cnt);
+}
+
 }  // namespace bcnn_hip
 
 extern "C" {
+
+void bcnn_hip_batchnorm_apply(const float* x, float* y, const float* scales, const float* bias, const float* saved_mean,
+                              const float* saved_var, int n, int c, int hw, int act) {
+    const long long total = (long long)n * hw * c;
+    if (!total) return;
+    BnApplyArgs a;
+    a.x = x; a.y = y; a.ws = nullptr; a.xn = nullptr; a.scale = scales; a.bias = bias; a.mean = saved_mean; a.var = saved_var;
+    a.C = c; a.HW = hw; a.act = act_is_cheap(act) ? act : BCNN_HIP_ACT_NONE; a.total = total; a.predict = 0;
+    a.res = nullptr; a.res_count = 0; a.act2 = BCNN_HIP_ACT_NONE;
+    auto al16 = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    launch_chan_map(BnApplyBody{a, al16(x) && al16(y)}, n, c, hw);
+    if (a.act != act) bcnn_hip_activation_forward(y, (size_t)total, act, nullptr, hw, c);
+}
 
 void bcnn_hip_batchnorm_backward_sums(const float* dy, const float* scales, float* dscales, float* dbias,
                                       const float* saved_mean, const float* saved_var, float* dmean, float* dvar,

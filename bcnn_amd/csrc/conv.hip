@@ -8,7 +8,12 @@ void conv_forward_dispatch(const float* x, const float* w, const float* bias, co
                            const ConvShape& s, int act, int raw, ConvStats* stats);
 void batchnorm_forward_impl(const float* x, float* y, float* run_mean, float* run_var, const float* scales,
                             const float* bias, float* saved_mean, float* saved_var, float* x_norm, float* workspace,
-                            int n, int c, int hw, int mode, int act, const ConvStats* pre);  // batchnorm.hip
+                            int n, int c, int hw, int mode, int act, const ConvStats* pre,
+                            const BnResidual* res);  // batchnorm.hip
+void batchnorm_backward_residual(const float* dout, const float* out, int act_res, const float* res, float* dres,
+                                 size_t res_count, float* dx, const float* scales, float* dscales, float* dbias,
+                                 const float* fwd_bias, const float* saved_mean, const float* saved_var, float* dmean,
+                                 float* dvar, const float* workspace, int n, int c, int hw);  // batchnorm.hip
 void batchnorm_backward_impl(float* dy, float* dx, const float* y, int act, const float* scales, float* dscales,
                              float* dbias, const float* saved_mean, const float* saved_var, float* dmean,
                              float* dvar, const float* workspace, int n, int c, int hw, const float* fwd_bias);
@@ -120,10 +125,13 @@ size_t bcnn_hip_conv_workspace_size(int n, int c, int h, int w, int f, int k, in
     return m;
 }
 
-void bcnn_hip_conv_forward(const float* x, const float* w, const float* bias, float* y, int n, int c, int h,
-                           int wd, int f, int k, int stride, int pad, int groups, int act, const float* slopes,
-                           int batch_norm, float* run_mean, float* run_var, const float* scales,
-                           float* saved_mean, float* saved_var, float* x_norm, float* bn_workspace, int mode) {
+// res != NULL (batch_norm, TRAIN mode, cheap activations -- bcnn_hip_conv_residual_fusable): the following eltwise node
+// is folded into the batch-norm apply pass, whose result goes to res_out; y is not written
+static void conv_forward_impl(const float* x, const float* w, const float* bias, float* y, int n, int c, int h,
+                              int wd, int f, int k, int stride, int pad, int groups, int act, const float* slopes,
+                              int batch_norm, float* run_mean, float* run_var, const float* scales,
+                              float* saved_mean, float* saved_var, float* x_norm, float* bn_workspace, int mode,
+                              const BnResidual* res, float* res_out) {
     const ConvShape s = make_conv_shape(n, c, h, wd, f, k, stride, pad, groups);
     if (!batch_norm) {
         if (act_is_cheap(act)) {
@@ -153,21 +161,60 @@ void bcnn_hip_conv_forward(const float* x, const float* w, const float* bias, fl
     // x_norm is not materialised on this path: the backward pass recomputes it from the raw convolution
     // output kept in bn_workspace (a full-tensor write and read less per layer and step).
     (void)x_norm;
-    batchnorm_forward_impl(raw, y, run_mean, run_var, scales, bias, saved_mean, saved_var, nullptr, raw, n, f, s.OHOW,
-                           mode, fused_act, &st);
+    batchnorm_forward_impl(raw, res ? res_out : y, run_mean, run_var, scales, bias, saved_mean, saved_var, nullptr, raw, n, f,
+                           s.OHOW, mode, fused_act, &st, res);
     if (act == BCNN_HIP_ACT_PRELU)
         bcnn_hip_activation_forward(y, (size_t)n * f * s.OHOW, act, slopes, s.OHOW, f);
 }
 
-void bcnn_hip_conv_backward(const float* x, const float* w, const float* bias, const float* y, float* dy, float* dx,
-                            float* dw, float* dbias, int n, int c, int h, int wd, int f, int k, int stride, int pad,
-                            int groups, int act, const float* slopes, float* dslopes, int batch_norm,
-                            const float* scales, float* dscales, const float* saved_mean,
-                            const float* saved_var, float* dmean, float* dvar, const float* x_norm,
-                            const float* bn_workspace, float* workspace, size_t workspace_elems) {
+void bcnn_hip_conv_forward(const float* x, const float* w, const float* bias, float* y, int n, int c, int h,
+                           int wd, int f, int k, int stride, int pad, int groups, int act, const float* slopes,
+                           int batch_norm, float* run_mean, float* run_var, const float* scales,
+                           float* saved_mean, float* saved_var, float* x_norm, float* bn_workspace, int mode) {
+    conv_forward_impl(x, w, bias, y, n, c, h, wd, f, k, stride, pad, groups, act, slopes, batch_norm, run_mean, run_var,
+                      scales, saved_mean, saved_var, x_norm, bn_workspace, mode, nullptr, nullptr);
+}
+
+int bcnn_hip_conv_residual_fusable(int batch_norm, int act, int res_act, int mode, const float* bn_workspace,
+                                   const float* res, const float* res_out) {
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    return batch_norm && mode == BCNN_HIP_MODE_TRAIN && bn_workspace && act == BCNN_HIP_ACT_NONE && act_is_cheap(res_act) &&
+           act_bwd_is_cheap(res_act) && res_act != BCNN_HIP_ACT_PRELU && al16(res) && al16(res_out) && al16(bn_workspace);
+}
+
+void bcnn_hip_conv_forward_residual(const float* x, const float* w, const float* bias, int n, int c, int h, int wd, int f,
+                                    int k, int stride, int pad, int groups, float* run_mean, float* run_var,
+                                    const float* scales, float* saved_mean, float* saved_var, float* bn_workspace,
+                                    const float* res, size_t res_count, int res_act, float* res_out) {
+    BnResidual r{res, res_count, res_act};
+    conv_forward_impl(x, w, bias, /*y=*/nullptr, n, c, h, wd, f, k, stride, pad, groups, BCNN_HIP_ACT_NONE, nullptr, 1,
+                      run_mean, run_var, scales, saved_mean, saved_var, nullptr, bn_workspace, BCNN_HIP_MODE_TRAIN, &r,
+                      res_out);
+}
+
+struct ConvResidualBwd {
+    const float* out;   // the folded eltwise node's output
+    const float* dout;  // and its gradient (read only)
+    const float* res;   // the eltwise node's second operand
+    float* dres;        // and its gradient (accumulated), may be NULL
+    size_t res_count;
+    int act;
+};
+static void conv_backward_impl(const float* x, const float* w, const float* bias, const float* y, float* dy, float* dx,
+                               float* dw, float* dbias, int n, int c, int h, int wd, int f, int k, int stride, int pad,
+                               int groups, int act, const float* slopes, float* dslopes, int batch_norm,
+                               const float* scales, float* dscales, const float* saved_mean,
+                               const float* saved_var, float* dmean, float* dvar, const float* x_norm,
+                               const float* bn_workspace, float* workspace, size_t workspace_elems,
+                               const ConvResidualBwd* rb) {
     const ConvShape s = make_conv_shape(n, c, h, wd, f, k, stride, pad, groups);
     const size_t ysize = (size_t)n * f * s.OHOW;
-    if (batch_norm) {
+    if (rb) {
+        // dy <- batch-norm backward of dout * act'(out): the eltwise node's backward and this node's batch-norm backward
+        // in the two sweeps the latter takes alone
+        batchnorm_backward_residual(rb->dout, rb->out, rb->act, rb->res, rb->dres, rb->res_count, dy, scales, dscales, dbias,
+                                    bias, saved_mean, saved_var, dmean, dvar, bn_workspace, n, f, s.OHOW);
+    } else if (batch_norm) {
         int fused_act = act;
         if (act == BCNN_HIP_ACT_PRELU) {
             bcnn_hip_activation_backward(y, dy, ysize, act, slopes, dslopes, s.OHOW, f);
@@ -225,6 +272,29 @@ void bcnn_hip_conv_backward(const float* x, const float* w, const float* bias, c
     if (dx && !conv_backward_data_winograd_fused(w, dy, dx, s) && !conv_backward_data_winograd(w, dy, dx, s))
         conv_backward_data(w, dy, dx, s);
     if (side) HIP_CHECK(hipStreamWaitEvent(main_stream, side->done, 0));
+}
+
+void bcnn_hip_conv_backward(const float* x, const float* w, const float* bias, const float* y, float* dy, float* dx,
+                            float* dw, float* dbias, int n, int c, int h, int wd, int f, int k, int stride, int pad,
+                            int groups, int act, const float* slopes, float* dslopes, int batch_norm,
+                            const float* scales, float* dscales, const float* saved_mean,
+                            const float* saved_var, float* dmean, float* dvar, const float* x_norm,
+                            const float* bn_workspace, float* workspace, size_t workspace_elems) {
+    conv_backward_impl(x, w, bias, y, dy, dx, dw, dbias, n, c, h, wd, f, k, stride, pad, groups, act, slopes, dslopes,
+                       batch_norm, scales, dscales, saved_mean, saved_var, dmean, dvar, x_norm, bn_workspace, workspace,
+                       workspace_elems, nullptr);
+}
+
+void bcnn_hip_conv_backward_residual(const float* x, const float* w, const float* bias, float* dy, float* dx, float* dw,
+                                     float* dbias, int n, int c, int h, int wd, int f, int k, int stride, int pad,
+                                     int groups, const float* scales, float* dscales, const float* saved_mean,
+                                     const float* saved_var, float* dmean, float* dvar, const float* bn_workspace,
+                                     float* workspace, size_t workspace_elems, const float* res_out,
+                                     const float* dres_out, int res_act, const float* res, float* dres, size_t res_count) {
+    ConvResidualBwd rb{res_out, dres_out, res, dres, res_count, res_act};
+    conv_backward_impl(x, w, bias, nullptr, dy, dx, dw, dbias, n, c, h, wd, f, k, stride, pad, groups, BCNN_HIP_ACT_NONE,
+                       nullptr, nullptr, 1, scales, dscales, saved_mean, saved_var, dmean, dvar, nullptr, bn_workspace,
+                       workspace, workspace_elems, &rb);
 }
 
 }  // extern "C"

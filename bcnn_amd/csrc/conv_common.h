@@ -36,6 +36,13 @@ struct ConvStats {
     size_t capacity;  // floats behind `partials`; every forward path checks its own slot count against it
 };
 
+// A following eltwise node folded into a convolution node's batch-norm apply pass (bcnn_eltwise_layer.c:82-113)
+struct BnResidual {
+    const float* res;  // the eltwise node's second operand
+    size_t count;      // elements of it that are added (the reference adds min_c * H * W of them: image 0)
+    int act;           // the eltwise node's activation
+};
+
 #ifdef __HIPCC__
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

@@ -449,6 +449,7 @@ bcnn_status bcnn_compile_net(bcnn_net *net) {
     }
     mark_dead_grad_fills(net);
     bcnn_link_depthwise_batchnorm(net);
+    bcnn_link_conv_eltwise(net);
     if (hc->fill_chunks_gpu) { /* the table of live fills follows the dead-fill marks */
         bcnn_hip_sync();
         bcnn_hip_free(hc->fill_chunks_gpu);
@@ -755,6 +756,7 @@ bcnn_status bcnn_upload_tensor(bcnn_net *net, int index, int with_grad) {
     if (index < 0 || index >= net->num_tensors) return BCNN_INVALID_PARAMETER;
     bcnn_tensor *t = &net->tensors[index];
     const size_t bytes = (size_t)bcnn_tensor_size(t) * sizeof(float);
+    bcnn_materialize_data(net, index); /* the pending values would otherwise land on top of the caller's later */
     if (t->data && t->data_gpu) bcnn_hip_memcpy_h2d(t->data_gpu, t->data, bytes);
     if (with_grad) bcnn_materialize_gradients(net, -1); /* before a caller's values can mix with pending ones */
     if (with_grad && t->grad_data && t->grad_data_gpu) bcnn_hip_memcpy_h2d(t->grad_data_gpu, t->grad_data, bytes);
@@ -765,6 +767,7 @@ bcnn_status bcnn_download_tensor(bcnn_net *net, int index, int with_grad) {
     if (index < 0 || index >= net->num_tensors) return BCNN_INVALID_PARAMETER;
     bcnn_tensor *t = &net->tensors[index];
     const size_t bytes = (size_t)bcnn_tensor_size(t) * sizeof(float);
+    bcnn_materialize_data(net, index); /* an output tensor a fused forward pass did not need to write */
     if (t->data && t->data_gpu) bcnn_hip_memcpy_d2h(t->data, t->data_gpu, bytes);
     if (with_grad) bcnn_materialize_gradients(net, index); /* gradients a fused backward pass did not need to write */
     if (with_grad && t->grad_data && t->grad_data_gpu) bcnn_hip_memcpy_d2h(t->grad_data, t->grad_data_gpu, bytes);
@@ -808,6 +811,7 @@ void *bcnn_get_node_state(bcnn_net *net, int node, int which) {
 
 bcnn_status bcnn_forward_node(bcnn_net *net, int node) {
     if (node < 0 || node >= net->num_nodes || !net->nodes[node].forward) return BCNN_INVALID_PARAMETER;
+    bcnn_materialize_data(net, -1); /* a single worker reads its inputs from the tensors themselves */
     net->nodes[node].forward(net, &net->nodes[node]);
     return BCNN_SUCCESS;
 }
@@ -815,6 +819,7 @@ bcnn_status bcnn_forward_node(bcnn_net *net, int node) {
 bcnn_status bcnn_backward_node(bcnn_net *net, int node) {
     if (node < 0 || node >= net->num_nodes || !net->nodes[node].backward) return BCNN_INVALID_PARAMETER;
     bcnn_hip_context *hc = hctx(net);
+    bcnn_materialize_data(net, -1);
     bcnn_materialize_gradients(net, -1); /* a single worker reads and rewrites gradient tensors in place */
     /* outside the executor nobody promised that the gradients were left unfilled: accumulate like the reference */
     unsigned char *saved = hc->grad_fill_dead;

@@ -253,6 +253,12 @@ typedef struct bcnn_conv_param {
     float *bn_workspace_gpu;    /* pre-normalisation conv output, kept for backward */
     float *x_norm_gpu;          /* NULL: recomputed in backward */
     float *adam_m_gpu, *adam_v_gpu; /* weight moments, allocated by the first Adam step */
+    /* set by bcnn_compile_net when the node that follows is an eltwise node adding something to this node's (batch-norm,
+     * no activation) output (bcnn_link_conv_eltwise): inside a whole pass the eltwise work rides on this node's
+     * batch-norm sweeps */
+    int elt_node;      /* index of that eltwise node, -1: none */
+    int data_pending;  /* the last forward pass did not write this node's output tensor (nobody inside a pass reads it):
+                        * bcnn_materialize_data produces it from bn_workspace_gpu on demand */
 #endif
 } bcnn_conv_param;
 
@@ -307,6 +313,13 @@ typedef struct bcnn_eltwise_param {
     bcnn_activation activation;
     int stride[2];
     int min_dim[3];
+#ifdef BCNN_USE_HIP
+    int conv_node;     /* the convolution node that does this node's work inside a pass (see bcnn_conv_param), -1: none */
+    int done_forward;  /* that node already wrote this node's output in the running forward pass */
+    int deferred;      /* this node's backward was left to that node in the running backward pass */
+    int grad_pending;  /* the last backward pass did not rewrite this node's output gradient (dy *= act'(y),
+                        * bcnn_eltwise_layer.c:124-127): bcnn_materialize_gradients does on demand */
+#endif
 } bcnn_eltwise_param;
 
 typedef struct bcnn_fullc_param {
@@ -364,6 +377,8 @@ void bcnn_backward_cost_layer(bcnn_net *net, bcnn_node *node);
 
 /* SGD step on one node's parameters (bcnn_learner.c:67-104 in the reference) */
 void bcnn_link_depthwise_batchnorm(bcnn_net *net); /* bcnn_layers_hot.c; called by bcnn_compile_net */
+void bcnn_link_conv_eltwise(bcnn_net *net);        /* bcnn_layers_hot.c; called by bcnn_compile_net */
+void bcnn_materialize_data(bcnn_net *net, int tensor);      /* tensor < 0: every pending one */
 void bcnn_materialize_gradients(bcnn_net *net, int tensor); /* tensor < 0: every pending one */
 void bcnn_drop_pending_gradients(bcnn_net *net);
 int bcnn_grad_sole_writer(bcnn_net *net, int tensor); /* 1: this gradient's zero fill was skipped, assign instead of += */

@@ -106,6 +106,7 @@ bcnn_status bcnn_add_convolutional_layer(bcnn_net *net, int num_filters, int siz
     param->activation = activation;
     param->pad = pad; param->num = num_filters; param->size = size; param->stride = stride;
     param->num_groups = num_groups;
+    param->elt_node = -1;
     node.forward = bcnn_forward_conv_layer;
     node.backward = bcnn_backward_conv_layer;
     node.update = bcnn_update_conv_layer;
@@ -158,6 +159,22 @@ static conv_io conv_tensors(bcnn_net *net, bcnn_node *node) {
 void bcnn_forward_conv_layer(bcnn_net *net, bcnn_node *node) {
     bcnn_conv_param *p = (bcnn_conv_param *)node->param;
     conv_io io = conv_tensors(net, node);
+    p->data_pending = 0;
+    if (hctx(net)->in_pass == 1 && p->elt_node >= 0 && net->mode == BCNN_MODE_TRAIN) {
+        /* the eltwise node that runs next in this pass: its add + activation ride on this node's batch-norm apply sweep,
+         * whose result goes straight to the eltwise output; this node's own output tensor is not written */
+        bcnn_node *en = &net->nodes[p->elt_node];
+        bcnn_eltwise_param *ep = (bcnn_eltwise_param *)en->param;
+        bcnn_tensor *r = &net->tensors[en->src[1]], *out = &net->tensors[en->dst[0]];
+        bcnn_hip_conv_forward_residual(io.x->data_gpu, io.w->data_gpu, io.b->data_gpu, io.x->n, io.x->c, io.x->h, io.x->w,
+                                       p->num, p->size, p->stride, p->pad, p->num_groups, io.run_mean->data_gpu,
+                                       io.run_var->data_gpu, io.scales->data_gpu, p->saved_mean.data_gpu,
+                                       p->saved_variance.data_gpu, p->bn_workspace_gpu, r->data_gpu,
+                                       (size_t)ep->min_dim[0] * out->h * out->w, (int)ep->activation, out->data_gpu);
+        ep->done_forward = 1;
+        p->data_pending = 1;
+        return;
+    }
     bcnn_hip_conv_forward(io.x->data_gpu, io.w->data_gpu, io.b->data_gpu, io.y->data_gpu, io.x->n, io.x->c, io.x->h,
                           io.x->w, p->num, p->size, p->stride, p->pad, p->num_groups, (int)p->activation,
                           io.slopes ? io.slopes->data_gpu : NULL, p->batch_norm,
@@ -169,6 +186,23 @@ void bcnn_forward_conv_layer(bcnn_net *net, bcnn_node *node) {
 void bcnn_backward_conv_layer(bcnn_net *net, bcnn_node *node) {
     bcnn_conv_param *p = (bcnn_conv_param *)node->param;
     conv_io io = conv_tensors(net, node);
+    if (hctx(net)->in_pass == 2 && p->elt_node >= 0 && ((bcnn_eltwise_param *)net->nodes[p->elt_node].param)->deferred) {
+        /* the eltwise node (which ran just before in this pass) left its backward to this node's batch-norm sweeps */
+        bcnn_node *en = &net->nodes[p->elt_node];
+        bcnn_eltwise_param *ep = (bcnn_eltwise_param *)en->param;
+        bcnn_tensor *r = &net->tensors[en->src[1]], *out = &net->tensors[en->dst[0]];
+        ep->deferred = 0;
+        ep->grad_pending = 1;
+        bcnn_hip_conv_backward_residual(io.x->data_gpu, io.w->data_gpu, io.b->data_gpu, io.y->grad_data_gpu, io.x->grad_data_gpu,
+                                        io.w->grad_data_gpu, io.b->grad_data_gpu, io.x->n, io.x->c, io.x->h, io.x->w,
+                                        p->num, p->size, p->stride, p->pad, p->num_groups, io.scales->data_gpu,
+                                        io.scales->grad_data_gpu, p->saved_mean.data_gpu, p->saved_variance.data_gpu,
+                                        p->saved_mean.grad_data_gpu, p->saved_variance.grad_data_gpu, p->bn_workspace_gpu,
+                                        p->conv_workspace_gpu, hctx(net)->workspace_size, out->data_gpu,
+                                        out->grad_data_gpu, (int)ep->activation, r->data_gpu, r->grad_data_gpu,
+                                        (size_t)ep->min_dim[0] * out->h * out->w);
+        return;
+    }
     bcnn_hip_conv_backward(io.x->data_gpu, io.w->data_gpu, io.b->data_gpu, io.y->data_gpu, io.y->grad_data_gpu,
                            io.x->grad_data_gpu /* NULL for the net input: no dX */, io.w->grad_data_gpu,
                            io.b->grad_data_gpu, io.x->n, io.x->c, io.x->h, io.x->w, p->num, p->size, p->stride,
@@ -363,12 +397,83 @@ void bcnn_backward_batchnorm_layer(bcnn_net *net, bcnn_node *node) {
                                 x->h * x->w);
 }
 
+/* Pairs a convolution node (batch-norm, no activation) with the eltwise node right behind it that takes the convolution
+ * output as its FIRST operand (the one every element of which is used; the reference adds only min_c * h * w elements of
+ * the second, bcnn_eltwise_layer.c:96-101) -- the tail of a residual block. TRAIN-mode nets only (the pre-normalisation
+ * workspace has to exist). Recomputed at every compile. */
+void bcnn_link_conv_eltwise(bcnn_net *net) {
+    for (int i = 0; i < net->num_nodes; ++i) {
+        bcnn_node *nd = &net->nodes[i];
+        if (nd->type == BCNN_LAYER_CONV2D) {
+            ((bcnn_conv_param *)nd->param)->elt_node = -1;
+            ((bcnn_conv_param *)nd->param)->data_pending = 0;
+        } else if (nd->type == BCNN_LAYER_ELTWISE) {
+            bcnn_eltwise_param *ep = (bcnn_eltwise_param *)nd->param;
+            ep->conv_node = -1;
+            ep->done_forward = ep->deferred = ep->grad_pending = 0;
+        }
+    }
+    if (BCNN_EXP_ENV("BCNN_NO_NODE_FUSION")) return; /* A/B switch of the experiment build */
+    for (int e = 1; e < net->num_nodes; ++e) {
+        bcnn_node *en = &net->nodes[e], *cn = &net->nodes[e - 1];
+        if (en->type != BCNN_LAYER_ELTWISE || cn->type != BCNN_LAYER_CONV2D) continue;
+        bcnn_eltwise_param *ep = (bcnn_eltwise_param *)en->param;
+        bcnn_conv_param *cp = (bcnn_conv_param *)cn->param;
+        const int t = cn->dst[0];
+        if (ep->stride[0] != 1 || ep->stride[1] != 1 || en->src[0] != t || en->src[1] == t || en->dst[0] == t ||
+            en->dst[0] == en->src[1])
+            continue;
+        int writers = 0, consumers = 0;
+        for (int i = 0; i < net->num_nodes; ++i) {
+            for (int k = 0; k < net->nodes[i].num_dst; ++k) writers += net->nodes[i].dst[k] == t;
+            for (int k = 0; k < net->nodes[i].num_src; ++k) consumers += net->nodes[i].src[k] == t;
+        }
+        if (writers != 1 || consumers != 1) continue;
+        const bcnn_tensor *y = &net->tensors[t], *out = &net->tensors[en->dst[0]], *r = &net->tensors[en->src[1]];
+        if (bcnn_tensor_size(y) != bcnn_tensor_size(out) || !out->grad_data_gpu || !y->grad_data_gpu) continue;
+        if ((size_t)ep->min_dim[0] * out->h * out->w > (size_t)bcnn_tensor_size(r)) continue;
+        if (!bcnn_hip_conv_residual_fusable(cp->batch_norm, (int)cp->activation, (int)ep->activation, (int)net->mode,
+                                            cp->bn_workspace_gpu, r->data_gpu, out->data_gpu))
+            continue;
+        cp->elt_node = e;
+        ep->conv_node = e - 1;
+    }
+}
+
+/* What a fused forward pass did not write: the output tensor of a convolution node whose result went straight into the
+ * eltwise node behind it. Its pre-normalisation values and batch statistics are in place, so the tensor is one batch-norm
+ * apply sweep away (bcnn_batchnorm_layer.c:226-241 with the saved statistics). */
+void bcnn_materialize_data(bcnn_net *net, int tensor) {
+    for (int i = 0; i < net->num_nodes; ++i) {
+        bcnn_node *cn = &net->nodes[i];
+        if (cn->type != BCNN_LAYER_CONV2D) continue;
+        bcnn_conv_param *cp = (bcnn_conv_param *)cn->param;
+        if (!cp->data_pending || (tensor >= 0 && tensor != cn->dst[0])) continue;
+        cp->data_pending = 0;
+        bcnn_tensor *y = &net->tensors[cn->dst[0]];
+        bcnn_hip_batchnorm_apply(cp->bn_workspace_gpu, y->data_gpu, net->tensors[cn->src[5]].data_gpu,
+                                 net->tensors[cn->src[2]].data_gpu, cp->saved_mean.data_gpu, cp->saved_variance.data_gpu,
+                                 y->n, y->c, y->h * y->w, (int)cp->activation);
+    }
+}
+
 /* The fused backward of a depthwise / batch-norm pair leaves two gradient tensors unwritten that the reference's workers
  * rewrite in place: the batch-norm node's dst gradient (-> gradient w.r.t. its input, bcnn_batchnorm_layer.c:292-296)
  * and the depthwise node's dst gradient (that, times act'(y), bcnn_depthwise_conv_layer.c:311-314). Every input of those
  * two sweeps is still in place after the pass, so a caller that asks for either tensor (bcnn_get_tensor_by_*,
  * bcnn_download_tensor) gets them produced here, once, with the unfused kernels. */
 void bcnn_materialize_gradients(bcnn_net *net, int tensor) {
+    for (int i = 0; i < net->num_nodes; ++i) { /* eltwise nodes whose backward rode on the convolution node before them */
+        bcnn_node *en = &net->nodes[i];
+        if (en->type != BCNN_LAYER_ELTWISE) continue;
+        bcnn_eltwise_param *ep = (bcnn_eltwise_param *)en->param;
+        if (!ep->grad_pending || (tensor >= 0 && tensor != en->dst[0])) continue;
+        ep->grad_pending = 0;
+        bcnn_tensor *y = &net->tensors[en->dst[0]];
+        if (y->grad_data_gpu)
+            bcnn_hip_activation_backward(y->data_gpu, y->grad_data_gpu, (size_t)bcnn_tensor_size(y), (int)ep->activation, NULL,
+                                         NULL, y->h * y->w, y->c);
+    }
     for (int i = 0; i < net->num_nodes; ++i) {
         bcnn_node *dw = &net->nodes[i];
         if (dw->type != BCNN_LAYER_DEPTHWISE_CONV2D) continue;
@@ -390,9 +495,12 @@ void bcnn_materialize_gradients(bcnn_net *net, int tensor) {
 }
 
 void bcnn_drop_pending_gradients(bcnn_net *net) { /* a new forward pass: the reference zero-fills them (bcnn_net.c:361-375) */
-    for (int i = 0; i < net->num_nodes; ++i)
+    for (int i = 0; i < net->num_nodes; ++i) {
         if (net->nodes[i].type == BCNN_LAYER_DEPTHWISE_CONV2D)
             ((bcnn_depthwise_conv_param *)net->nodes[i].param)->grads_pending = 0;
+        else if (net->nodes[i].type == BCNN_LAYER_ELTWISE)
+            ((bcnn_eltwise_param *)net->nodes[i].param)->grad_pending = 0;
+    }
 }
 
 /* Pairs every depthwise node with the stand-alone batch-norm node that consumes its output (bcnn_compile_net; the

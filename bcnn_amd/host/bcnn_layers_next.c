@@ -26,6 +26,8 @@ static bcnn_status new_output(bcnn_net *net, bcnn_node *node, int n, int c, int 
     return bcnn_node_add_output(net, node, net->num_tensors - 1);
 }
 
+static bcnn_hip_context *hctx(bcnn_net *net) { return (bcnn_hip_context *)net->hip_ctx; }
+
 /* ================================================================================================
  * eltwise add (+ fused activation)
  * Two reference quirks are kept: the operand found LATER in the tensor list
@@ -54,6 +56,7 @@ bcnn_status bcnn_add_eltwise_layer(bcnn_net *net, bcnn_activation activation, co
     bcnn_eltwise_param *param = (bcnn_eltwise_param *)calloc(1, node.param_size);
     node.param = param;
     param->activation = activation;
+    param->conv_node = -1;
     param->min_dim[0] = imin(a.c, b.c); param->min_dim[1] = imin(a.h, b.h); param->min_dim[2] = imin(a.w, b.w);
     param->stride[0] = imax(1, st0); param->stride[1] = imax(1, st1);
     node.forward = bcnn_forward_eltwise_layer;
@@ -66,6 +69,10 @@ bcnn_status bcnn_add_eltwise_layer(bcnn_net *net, bcnn_activation activation, co
 
 void bcnn_forward_eltwise_layer(bcnn_net *net, bcnn_node *node) {
     bcnn_eltwise_param *p = (bcnn_eltwise_param *)node->param;
+    if (p->done_forward) { /* the convolution node before this one wrote the output in this pass (bcnn_link_conv_eltwise) */
+        p->done_forward = 0;
+        if (hctx(net)->in_pass == 1) return;
+    }
     bcnn_tensor *a = &net->tensors[node->src[0]], *b = &net->tensors[node->src[1]], *y = &net->tensors[node->dst[0]];
     const size_t sz = (size_t)bcnn_tensor_size(y);
     if (p->stride[0] == 1 && p->stride[1] == 1) { /* one fused pass; the second operand reaches image 0 only (quirk 5) */
@@ -83,6 +90,10 @@ void bcnn_forward_eltwise_layer(bcnn_net *net, bcnn_node *node) {
 
 void bcnn_backward_eltwise_layer(bcnn_net *net, bcnn_node *node) {
     bcnn_eltwise_param *p = (bcnn_eltwise_param *)node->param;
+    if (hctx(net)->in_pass == 2 && p->conv_node >= 0) { /* the convolution node that runs next in this pass takes it */
+        p->deferred = 1;
+        return;
+    }
     bcnn_tensor *a = &net->tensors[node->src[0]], *b = &net->tensors[node->src[1]], *y = &net->tensors[node->dst[0]];
     const size_t sz = (size_t)bcnn_tensor_size(y);
     if (p->stride[0] == 1 && p->stride[1] == 1) {

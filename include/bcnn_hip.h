@@ -175,6 +175,42 @@ void bcnn_hip_conv_backward(const float *x_d, const float *w_d, const float *bia
                             float *workspace_d, size_t workspace_elems);
 
 /* ---------------------------------------------------------------------------------------------
+ * A convolution node with batch-norm (no activation) whose output is the first operand of the eltwise node that
+ * follows it (the residual block: bcnn_conv_layer.c:367-485 then bcnn_eltwise_layer.c:82-113; backward
+ * bcnn_eltwise_layer.c:115-152 then bcnn_conv_layer.c:487-587). For an executor that runs whole passes:
+ *   bcnn_hip_conv_residual_fusable   non-zero when the pair below may replace the two workers (TRAIN mode, batch-norm
+ *                                    with its pre-normalisation workspace, cheap eltwise activation, aligned tensors)
+ *   bcnn_hip_conv_forward_residual   bcnn_hip_conv_forward whose batch-norm apply pass also adds res_d[0 .. res_count)
+ *                                    (the reference adds its second operand to the first min_c * h * w elements only)
+ *                                    and applies the eltwise activation; the result goes to res_out_d, the
+ *                                    convolution node's own output tensor is NOT written (bcnn_hip_batchnorm_apply on
+ *                                    bn_workspace_d produces it when somebody asks)
+ *   bcnn_hip_conv_backward_residual  the eltwise backward (g = dres_out_d * act'(res_out_d), dres_d[0 .. res_count) += g)
+ *                                    and bcnn_hip_conv_backward in one: dres_out_d is read, not rewritten; dy_d receives
+ *                                    the batch-norm backward of g as in bcnn_hip_conv_backward. Of res_out_d only the
+ *                                    first res_count elements are read: the value act' needs is recomputed from
+ *                                    bn_workspace_d, bias_d and res_d with the forward's own operations
+ *   bcnn_hip_batchnorm_apply         y = act((x - mean) / sqrtf(var + 1e-6) * scale + bias) with GIVEN statistics: the
+ *                                    apply sweep of a TRAIN-mode forward alone, no side effects
+ * ------------------------------------------------------------------------------------------- */
+int bcnn_hip_conv_residual_fusable(int batch_norm, int act, int res_act, int mode, const float *bn_workspace_d,
+                                   const float *res_d, const float *res_out_d);
+void bcnn_hip_conv_forward_residual(const float *x_d, const float *w_d, const float *bias_d, int n, int c, int h, int w,
+                                    int f, int k, int stride, int pad, int groups, float *run_mean_d, float *run_var_d,
+                                    const float *scales_d, float *saved_mean_d, float *saved_var_d,
+                                    float *bn_workspace_d, const float *res_d, size_t res_count, int res_act,
+                                    float *res_out_d);
+void bcnn_hip_conv_backward_residual(const float *x_d, const float *w_d, const float *bias_d, float *dy_d, float *dx_d,
+                                     float *dw_d, float *dbias_d, int n, int c, int h, int w, int f, int k, int stride,
+                                     int pad, int groups, const float *scales_d, float *dscales_d,
+                                     const float *saved_mean_d, const float *saved_var_d, float *dmean_d, float *dvar_d,
+                                     const float *bn_workspace_d, float *workspace_d, size_t workspace_elems,
+                                     const float *res_out_d, const float *dres_out_d, int res_act, const float *res_d,
+                                     float *dres_d, size_t res_count);
+void bcnn_hip_batchnorm_apply(const float *x_d, float *y_d, const float *scales_d, const float *bias_d,
+                              const float *saved_mean_d, const float *saved_var_d, int n, int c, int hw, int act);
+
+/* ---------------------------------------------------------------------------------------------
  * Pooling.  Replaces bcnn_forward/backward_maxpool_layer_gpu (bcnn_maxpool_layer.cu:28-166) and
  * bcnn_forward/backward_avgpool_layer_gpu (bcnn_avgpool_layer.cu:29-90); CPU semantics
  * bcnn_maxpool_layer.c:145-191, 258-273 and bcnn_avgpool_layer.c:82-125.

@@ -62,8 +62,11 @@ def test_experiment_host_runtime_with_every_gradient_fill_kept_trains_bit_identi
     lib = os.path.join(ROOT, "bcnn_amd", "lib")
     assert os.path.exists(os.path.join(lib, "libbcnn_exp.so")), "experiment host runtime missing: build() makes it"
     shas = []
+    # BCNN_NO_NODE_FUSION=1 on top: every worker runs alone, so the product run's convolution -> eltwise pairs (the add,
+    # the activation and their backward riding on the convolution node's batch-norm sweeps, bcnn_link_conv_eltwise) are
+    # pinned bit for bit against the separate workers as well
     for env in ({}, {"BCNN_LIB": os.path.join(lib, "libbcnn_exp.so"), "BCNN_HIP_LIB": os.path.join(lib, "libbcnn_hip_exp.so"),
-                     "BCNN_KEEP_ALL_GRAD_FILLS": "1"}):
+                     "BCNN_KEEP_ALL_GRAD_FILLS": "1", "BCNN_NO_NODE_FUSION": "1"}):
         e = dict(os.environ); e.update(env)
         r = subprocess.run([sys.executable, "-c", _TRAIN], cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
