@@ -75,6 +75,9 @@ SIGNATURES = {
     "bcnn_hip_conv_forward_residual": (None, [vp, vp, vp] + [i] * 9 + [vp] * 7 + [sz, i, vp]),
     "bcnn_hip_conv_backward_residual": (None, [vp] * 7 + [i] * 9 + [vp] * 7 + [vp, sz, vp, vp, i, vp, vp, sz]),
     "bcnn_hip_batchnorm_apply": (None, [vp] * 6 + [i, i, i, i]),
+    "bcnn_hip_maxpool_bn_fusable": (i, [i] * 9 + [vp]),
+    "bcnn_hip_conv_forward_stats_only": (None, [vp, vp, vp] + [i] * 9 + [vp] * 6),
+    "bcnn_hip_maxpool_forward_bn": (None, [vp, vp, vp] + [i] * 8 + [vp] * 4 + [i]),
     "bcnn_hip_sgd_update": (None, [vp, vp, vp, vp, sz, sz, i, f, f, f]),
     "bcnn_hip_sgd_update_chunks": (None, [vp, i, i, f, f, f]),
     "bcnn_hip_zero_chunks": (None, [vp, i]),

@@ -303,7 +303,8 @@ struct BnBwdApplyBody {
 // pre: statistics partials already produced by the convolution epilogue (pre->splits > 0), else NULL
 void batchnorm_forward_impl(const float* x, float* y, float* run_mean, float* run_var, const float* scales,
                             const float* bias, float* saved_mean, float* saved_var, float* x_norm, float* workspace,
-                            int n, int c, int hw, int mode, int act, const ConvStats* pre, const BnResidual* res) {
+                            int n, int c, int hw, int mode, int act, const ConvStats* pre, const BnResidual* res,
+                            bool stats_only) {
     const long long M = (long long)n * hw, total = M * c;
     if (!total) return;
     const bool have_pre = pre && pre->splits > 0 && mode == BCNN_HIP_MODE_TRAIN;
@@ -338,6 +339,7 @@ void batchnorm_forward_impl(const float* x, float* y, float* run_mean, float* ru
         KERNEL_CHECK();
         a.mean = saved_mean; a.var = saved_var;
     }
+    if (stats_only) return;  // the consumer normalises on the fly (bcnn_hip_maxpool_forward_bn)
     auto al16 = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     launch_chan_map(BnApplyBody{a, al16(x) && al16(y) && al16(a.ws) && al16(a.xn) && al16(a.res)}, n, c, hw);
     if (want_act != act) bcnn_hip_activation_forward(y, (size_t)total, want_act, nullptr, hw, c);
@@ -354,7 +356,7 @@ void bcnn_hip_batchnorm_forward(const float* x, float* y, float* run_mean, float
                                 float* saved_var, float* x_norm, float* workspace, int n, int c, int hw,
                                 int mode, int act) {
     batchnorm_forward_impl(x, y, run_mean, run_var, scales, bias, saved_mean, saved_var, x_norm, workspace, n, c, hw,
-                           mode, act, nullptr, nullptr);
+                           mode, act, nullptr, nullptr, false);
 }
 
 void bcnn_hip_batchnorm_forward_stats(const float* x, float* y, float* run_mean, float* run_var, const float* scales,
@@ -364,7 +366,7 @@ void bcnn_hip_batchnorm_forward_stats(const float* x, float* y, float* run_mean,
     ConvStats st;
     st.partials = const_cast<float*>(stats); st.splits = stats ? splits : 0; st.capacity = 0;
     batchnorm_forward_impl(x, y, run_mean, run_var, scales, bias, saved_mean, saved_var, x_norm, workspace, n, c, hw,
-                           mode, act, &st, nullptr);
+                           mode, act, &st, nullptr, false);
 }
 
 }  // extern "C"

@@ -9,7 +9,7 @@ void conv_forward_dispatch(const float* x, const float* w, const float* bias, co
 void batchnorm_forward_impl(const float* x, float* y, float* run_mean, float* run_var, const float* scales,
                             const float* bias, float* saved_mean, float* saved_var, float* x_norm, float* workspace,
                             int n, int c, int hw, int mode, int act, const ConvStats* pre,
-                            const BnResidual* res);  // batchnorm.hip
+                            const BnResidual* res, bool stats_only);  // batchnorm.hip
 void batchnorm_backward_residual(const float* dout, const float* out, int act_res, const float* res, float* dres,
                                  size_t res_count, float* dx, const float* scales, float* dscales, float* dbias,
                                  const float* fwd_bias, const float* saved_mean, const float* saved_var, float* dmean,
@@ -131,7 +131,7 @@ static void conv_forward_impl(const float* x, const float* w, const float* bias,
                               int wd, int f, int k, int stride, int pad, int groups, int act, const float* slopes,
                               int batch_norm, float* run_mean, float* run_var, const float* scales,
                               float* saved_mean, float* saved_var, float* x_norm, float* bn_workspace, int mode,
-                              const BnResidual* res, float* res_out) {
+                              const BnResidual* res, float* res_out, bool stats_only = false) {
     const ConvShape s = make_conv_shape(n, c, h, wd, f, k, stride, pad, groups);
     if (!batch_norm) {
         if (act_is_cheap(act)) {
@@ -162,7 +162,8 @@ static void conv_forward_impl(const float* x, const float* w, const float* bias,
     // output kept in bn_workspace (a full-tensor write and read less per layer and step).
     (void)x_norm;
     batchnorm_forward_impl(raw, res ? res_out : y, run_mean, run_var, scales, bias, saved_mean, saved_var, nullptr, raw, n, f,
-                           s.OHOW, mode, fused_act, &st, res);
+                           s.OHOW, mode, fused_act, &st, res, stats_only);
+    if (stats_only) return;
     if (act == BCNN_HIP_ACT_PRELU)
         bcnn_hip_activation_forward(y, (size_t)n * f * s.OHOW, act, slopes, s.OHOW, f);
 }
@@ -173,6 +174,16 @@ void bcnn_hip_conv_forward(const float* x, const float* w, const float* bias, fl
                            float* saved_mean, float* saved_var, float* x_norm, float* bn_workspace, int mode) {
     conv_forward_impl(x, w, bias, y, n, c, h, wd, f, k, stride, pad, groups, act, slopes, batch_norm, run_mean, run_var,
                       scales, saved_mean, saved_var, x_norm, bn_workspace, mode, nullptr, nullptr);
+}
+
+// The convolution and the batch statistics (saved / running) of bcnn_hip_conv_forward, TRAIN mode, WITHOUT the apply sweep:
+// the pre-normalisation values stay in bn_workspace and the consumer normalises them on the fly
+void bcnn_hip_conv_forward_stats_only(const float* x, const float* w, const float* bias, int n, int c, int h, int wd, int f,
+                                      int k, int stride, int pad, int groups, float* run_mean, float* run_var,
+                                      const float* scales, float* saved_mean, float* saved_var, float* bn_workspace) {
+    conv_forward_impl(x, w, bias, /*y=*/nullptr, n, c, h, wd, f, k, stride, pad, groups, BCNN_HIP_ACT_NONE, nullptr, 1,
+                      run_mean, run_var, scales, saved_mean, saved_var, nullptr, bn_workspace, BCNN_HIP_MODE_TRAIN, nullptr,
+                      nullptr, /*stats_only=*/true);
 }
 
 int bcnn_hip_conv_residual_fusable(int batch_norm, int act, int res_act, int mode, const float* bn_workspace,

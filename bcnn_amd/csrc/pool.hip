@@ -4,6 +4,7 @@
 // src/layers/bcnn_avgpool_layer.c:82-99, 109-125.
 #include <cfloat>
 
+#include "bn_math.h"
 #include "common.h"
 
 namespace bcnn_hip {
@@ -78,6 +79,67 @@ __global__ __launch_bounds__(256) void maxpool_fwd_s2_kernel(const float* __rest
     if ((int)(q * 2 + 1) < OW) {
         y[out + 1] = best[1];
         idx[out + 1] = bi[1];
+    }
+}
+
+// The same windows over act(batch-norm(x)) computed on the fly: the pooling node behind a convolution node with batch-norm
+// whose pre-normalisation output x is kept anyway (the ResNet stem). The normalised tensor -- four times the size of the
+// pooled one -- is then never written nor read back. Values, scan order and indexes are those of bn apply + the kernel
+// above (same bn_one arithmetic per element).
+template <int SIZE, int R>  // R consecutive output rows per thread: their 2R + SIZE - 2 source rows are normalised once each
+__global__ __launch_bounds__(256) void maxpool_fwd_s2_bn_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                int* __restrict__ idx, int C, int H, int W, int OH, int OW,
+                                                                unsigned total_items, const float* __restrict__ mean,
+                                                                const float* __restrict__ var, const float* __restrict__ scale,
+                                                                const float* __restrict__ bias, int act) {
+    const unsigned t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= total_items) return;
+    const unsigned ppr = (unsigned)(OW + 1) >> 1;       // output pairs per row
+    const unsigned rgs = (unsigned)(OH + R - 1) / R;    // row groups per plane
+    const unsigned rowid = t / ppr, q = t - rowid * ppr;
+    const unsigned plane = rowid / rgs, i0 = (rowid - plane * rgs) * R;
+    const int ch = (int)(plane % (unsigned)C);
+    const float m = mean[ch], rs = sqrtf(var[ch] + 0.000001f), sc = scale[ch], b = bias[ch];
+    const int base = (int)plane * H * W;
+    const int w0 = (int)q * 4;
+    float best[R][2];
+    int bi[R][2];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { best[r][0] = best[r][1] = -FLT_MAX; bi[r][0] = bi[r][1] = -1; }
+    float dummy;
+    const bool tail = SIZE == 3 && w0 + 4 < W;
+#pragma unroll
+    for (int rr = 0; rr < 2 * R + SIZE - 2; ++rr) {
+        const int hh = (int)i0 * 2 + rr;
+        if (hh >= H) continue;  // bottom padding: the row never wins
+        const int rb = base + hh * W + w0;
+        const float4 v4 = *reinterpret_cast<const float4*>(x + rb);
+        const float v[5] = {bn_one(v4.x, m, rs, sc, b, 0, act, &dummy), bn_one(v4.y, m, rs, sc, b, 0, act, &dummy),
+                            bn_one(v4.z, m, rs, sc, b, 0, act, &dummy), bn_one(v4.w, m, rs, sc, b, 0, act, &dummy),
+                            tail ? bn_one(x[rb + 4], m, rs, sc, b, 0, act, &dummy) : -FLT_MAX};
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int k = rr - 2 * r;  // window row of output row i0 + r; ascending rr == ascending k: the scan order
+            if (k < 0 || k >= SIZE) continue;
+#pragma unroll
+            for (int o = 0; o < 2; ++o)
+#pragma unroll
+                for (int c = 0; c < SIZE; ++c) {
+                    const float val = v[2 * o + c];
+                    if (val > best[r][o]) { best[r][o] = val; bi[r][o] = rb + 2 * o + c; }
+                }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if ((int)(i0 + r) >= OH) break;
+        const unsigned out = (plane * (unsigned)OH + i0 + r) * (unsigned)OW + q * 2;
+        y[out] = best[r][0];
+        idx[out] = bi[r][0];
+        if ((int)(q * 2 + 1) < OW) {
+            y[out + 1] = best[r][1];
+            idx[out + 1] = bi[r][1];
+        }
     }
 }
 
@@ -290,6 +352,35 @@ void bcnn_hip_maxpool_forward(const float* x, float* y, int* indexes, int n, int
     }
     maxpool_fwd_kernel<<<stream_grid((size_t)total, 256), 256, 0, current_stream()>>>(
         x, y, indexes, n * c, h, w, out_h, out_w, size, stride, (unsigned)total);
+    KERNEL_CHECK();
+}
+
+int bcnn_hip_maxpool_bn_fusable(int n, int c, int h, int w, int out_h, int out_w, int size, int stride, int act,
+                                 const float* x) {
+    return stride == 2 && (size == 2 || size == 3) && (w & 3) == 0 && out_w * 2 <= w + 1 &&
+           (long long)n * c * h * w < 0x7fffffffLL && x && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && act_is_cheap(act) &&
+           act != BCNN_HIP_ACT_PRELU;
+}
+
+void bcnn_hip_maxpool_forward_bn(const float* x, float* y, int* indexes, int n, int c, int h, int w, int out_h, int out_w,
+                                 int size, int stride, const float* scales, const float* bias, const float* mean,
+                                 const float* var, int act) {
+    const long long total = (long long)n * c * out_h * out_w;
+    if (!total) return;
+    if (!bcnn_hip_maxpool_bn_fusable(n, c, h, w, out_h, out_w, size, stride, act, x)) {
+        fprintf(stderr, "[bcnn_hip] bcnn_hip_maxpool_forward_bn: not fusable (ask bcnn_hip_maxpool_bn_fusable)\n");
+        exit(1);
+    }
+    KTimer kt(K_POOL, 0.0, 4.0 * ((double)n * c * h * w + 2.0 * (double)total));
+    constexpr int R = 4;
+    const long long items = (long long)n * c * ((out_h + R - 1) / R) * ((out_w + 1) / 2);
+    const unsigned blocks = (unsigned)((items + 255) / 256);
+    if (size == 2)
+        maxpool_fwd_s2_bn_kernel<2, R><<<blocks, 256, 0, current_stream()>>>(x, y, indexes, c, h, w, out_h, out_w,
+                                                                             (unsigned)items, mean, var, scales, bias, act);
+    else
+        maxpool_fwd_s2_bn_kernel<3, R><<<blocks, 256, 0, current_stream()>>>(x, y, indexes, c, h, w, out_h, out_w,
+                                                                             (unsigned)items, mean, var, scales, bias, act);
     KERNEL_CHECK();
 }
 

@@ -257,6 +257,9 @@ typedef struct bcnn_conv_param {
      * no activation) output (bcnn_link_conv_eltwise): inside a whole pass the eltwise work rides on this node's
      * batch-norm sweeps */
     int elt_node;      /* index of that eltwise node, -1: none */
+    int pool_node;     /* index of the max-pooling node that is this node's only consumer and normalises this node's
+                        * pre-normalisation output on the fly inside a forward pass (bcnn_link_conv_maxpool), -1: none */
+    int apply_skipped; /* this node left its batch-norm apply sweep to that node in the running forward pass */
     int data_pending;  /* the last forward pass did not write this node's output tensor (nobody inside a pass reads it):
                         * bcnn_materialize_data produces it from bn_workspace_gpu on demand */
 #endif
@@ -302,6 +305,7 @@ typedef struct bcnn_maxpool_param {
     int *indexes;
 #ifdef BCNN_USE_HIP
     int *indexes_gpu;
+    int conv_node;  /* the convolution node whose batch-norm this node applies on the fly (see bcnn_conv_param), -1: none */
 #endif
 } bcnn_maxpool_param;
 
@@ -378,6 +382,7 @@ void bcnn_backward_cost_layer(bcnn_net *net, bcnn_node *node);
 /* SGD step on one node's parameters (bcnn_learner.c:67-104 in the reference) */
 void bcnn_link_depthwise_batchnorm(bcnn_net *net); /* bcnn_layers_hot.c; called by bcnn_compile_net */
 void bcnn_link_conv_eltwise(bcnn_net *net);        /* bcnn_layers_hot.c; called by bcnn_compile_net */
+void bcnn_link_conv_maxpool(bcnn_net *net);
 void bcnn_materialize_data(bcnn_net *net, int tensor);      /* tensor < 0: every pending one */
 void bcnn_materialize_gradients(bcnn_net *net, int tensor); /* tensor < 0: every pending one */
 void bcnn_drop_pending_gradients(bcnn_net *net);

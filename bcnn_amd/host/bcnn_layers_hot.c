@@ -107,6 +107,7 @@ bcnn_status bcnn_add_convolutional_layer(bcnn_net *net, int num_filters, int siz
     param->pad = pad; param->num = num_filters; param->size = size; param->stride = stride;
     param->num_groups = num_groups;
     param->elt_node = -1;
+    param->pool_node = -1;
     node.forward = bcnn_forward_conv_layer;
     node.backward = bcnn_backward_conv_layer;
     node.update = bcnn_update_conv_layer;
@@ -160,6 +161,18 @@ void bcnn_forward_conv_layer(bcnn_net *net, bcnn_node *node) {
     bcnn_conv_param *p = (bcnn_conv_param *)node->param;
     conv_io io = conv_tensors(net, node);
     p->data_pending = 0;
+    p->apply_skipped = 0;
+    if (hctx(net)->in_pass == 1 && p->pool_node >= 0 && net->mode == BCNN_MODE_TRAIN) {
+        /* the max-pooling node that runs next in this pass normalises this node's pre-normalisation output on the fly:
+         * convolution and batch statistics only; this node's own output tensor is not written */
+        bcnn_hip_conv_forward_stats_only(io.x->data_gpu, io.w->data_gpu, io.b->data_gpu, io.x->n, io.x->c, io.x->h, io.x->w,
+                                         p->num, p->size, p->stride, p->pad, p->num_groups, io.run_mean->data_gpu,
+                                         io.run_var->data_gpu, io.scales->data_gpu, p->saved_mean.data_gpu,
+                                         p->saved_variance.data_gpu, p->bn_workspace_gpu);
+        p->apply_skipped = 1;
+        p->data_pending = 1;
+        return;
+    }
     if (hctx(net)->in_pass == 1 && p->elt_node >= 0 && net->mode == BCNN_MODE_TRAIN) {
         /* the eltwise node that runs next in this pass: its add + activation ride on this node's batch-norm apply sweep,
          * whose result goes straight to the eltwise output; this node's own output tensor is not written */
@@ -440,6 +453,45 @@ void bcnn_link_conv_eltwise(bcnn_net *net) {
     }
 }
 
+/* Pairs a convolution node (batch-norm, cheap activation) with the stride-2 max-pooling node right behind it when that node
+ * is the only consumer of the convolution output (the ResNet stem), TRAIN-mode nets: forward, the pooling kernel reads the
+ * pre-normalisation values and normalises them on the fly (bcnn_hip_maxpool_forward_bn); the normalised tensor -- four
+ * times the pooled one -- is not written (bcnn_materialize_data produces it on demand; the backward pass never reads it:
+ * the activation derivative is recomputed from the pre-normalisation values). */
+void bcnn_link_conv_maxpool(bcnn_net *net) {
+    for (int i = 0; i < net->num_nodes; ++i) {
+        bcnn_node *nd = &net->nodes[i];
+        if (nd->type == BCNN_LAYER_CONV2D) {
+            ((bcnn_conv_param *)nd->param)->pool_node = -1;
+            ((bcnn_conv_param *)nd->param)->apply_skipped = 0;
+        } else if (nd->type == BCNN_LAYER_MAXPOOL) {
+            ((bcnn_maxpool_param *)nd->param)->conv_node = -1;
+        }
+    }
+    if (BCNN_EXP_ENV("BCNN_NO_NODE_FUSION") || net->mode != BCNN_MODE_TRAIN) return;
+    for (int m = 1; m < net->num_nodes; ++m) {
+        bcnn_node *pn = &net->nodes[m], *cn = &net->nodes[m - 1];
+        if (pn->type != BCNN_LAYER_MAXPOOL || cn->type != BCNN_LAYER_CONV2D || pn->src[0] != cn->dst[0]) continue;
+        const int t = cn->dst[0];
+        int writers = 0, consumers = 0;
+        for (int i = 0; i < net->num_nodes; ++i) {
+            for (int k = 0; k < net->nodes[i].num_dst; ++k) writers += net->nodes[i].dst[k] == t;
+            for (int k = 0; k < net->nodes[i].num_src; ++k) consumers += net->nodes[i].src[k] == t;
+        }
+        if (writers != 1 || consumers != 1) continue;
+        bcnn_conv_param *cp = (bcnn_conv_param *)cn->param;
+        bcnn_maxpool_param *mp = (bcnn_maxpool_param *)pn->param;
+        const bcnn_tensor *y = &net->tensors[t], *py = &net->tensors[pn->dst[0]];
+        /* the backward pass must not need the normalised tensor: cheap activations are recomputed from the workspace */
+        if (!cp->batch_norm || !cp->bn_workspace_gpu || cp->activation == BCNN_ACT_PRELU ||
+            !bcnn_hip_maxpool_bn_fusable(y->n, y->c, y->h, y->w, py->h, py->w, mp->size, mp->stride, (int)cp->activation,
+                                         cp->bn_workspace_gpu))
+            continue;
+        cp->pool_node = m;
+        mp->conv_node = m - 1;
+    }
+}
+
 /* What a fused forward pass did not write: the output tensor of a convolution node whose result went straight into the
  * eltwise node behind it. Its pre-normalisation values and batch statistics are in place, so the tensor is one batch-norm
  * apply sweep away (bcnn_batchnorm_layer.c:226-241 with the saved statistics). */
@@ -610,6 +662,7 @@ bcnn_status bcnn_add_maxpool_layer(bcnn_net *net, int size, int stride, bcnn_pad
     bcnn_maxpool_param *param = (bcnn_maxpool_param *)calloc(1, node.param_size);
     node.param = param;
     param->size = size; param->stride = stride; param->padding = padding;
+    param->conv_node = -1;
     const size_t sz = (size_t)s.n * s.c * oh * ow;
     param->indexes = (int *)calloc(sz, sizeof(int));
     param->indexes_gpu = bcnn_hip_malloc_i32(sz);
@@ -625,6 +678,18 @@ bcnn_status bcnn_add_maxpool_layer(bcnn_net *net, int size, int stride, bcnn_pad
 void bcnn_forward_maxpool_layer(bcnn_net *net, bcnn_node *node) {
     bcnn_maxpool_param *p = (bcnn_maxpool_param *)node->param;
     bcnn_tensor *x = &net->tensors[node->src[0]], *y = &net->tensors[node->dst[0]];
+    if (hctx(net)->in_pass == 1 && p->conv_node >= 0) {
+        bcnn_node *cn = &net->nodes[p->conv_node];
+        bcnn_conv_param *cp = (bcnn_conv_param *)cn->param;
+        if (cp->apply_skipped) { /* the convolution node before this one left its pre-normalisation output and statistics */
+            cp->apply_skipped = 0;
+            bcnn_hip_maxpool_forward_bn(cp->bn_workspace_gpu, y->data_gpu, p->indexes_gpu, x->n, x->c, x->h, x->w, y->h, y->w,
+                                        p->size, p->stride, net->tensors[cn->src[5]].data_gpu,
+                                        net->tensors[cn->src[2]].data_gpu, cp->saved_mean.data_gpu,
+                                        cp->saved_variance.data_gpu, (int)cp->activation);
+            return;
+        }
+    }
     bcnn_hip_maxpool_forward(x->data_gpu, y->data_gpu, p->indexes_gpu, x->n, x->c, x->h, x->w, y->h, y->w, p->size,
                              p->stride);
 }

@@ -134,6 +134,26 @@ def depthwise_backward(x, wt, y, dy, dx, dw, dbias, k, stride, pad, act=0, overw
                                             _f32(dbias), n, c, h, w, k, stride, pad, act, 1 if overwrite else 0)
 
 
+def batchnorm_apply(x, y, scales, bias, mean, var, act=0):
+    """y = act((x - mean) / sqrtf(var + 1e-6) * scale + bias) with given statistics (bcnn_batchnorm_layer.c:226-241)"""
+    n, c, h, w = x.shape
+    _lib.load().bcnn_hip_batchnorm_apply(_f32(x), _f32(y), _f32(scales), _f32(bias), _f32(mean), _f32(var), n, c, h * w, act)
+
+
+def maxpool_bn_fusable(x, out_h, out_w, size, stride, act):
+    n, c, h, w = x.shape
+    return bool(_lib.load().bcnn_hip_maxpool_bn_fusable(n, c, h, w, out_h, out_w, size, stride, act, _f32(x)))
+
+
+def maxpool_forward_bn(x, y, indexes, size, stride, scales, bias, mean, var, act):
+    """max-pooling over act(batch-norm(x)) normalised on the fly: bcnn_forward_maxpool_layer_cpu
+    (bcnn_maxpool_layer.c:145-191) on the tensor bcnn_batchnorm_layer.c:226-241 would have written"""
+    n, c, h, w = x.shape
+    assert indexes.dtype == torch.int32
+    _lib.load().bcnn_hip_maxpool_forward_bn(_f32(x), _f32(y), _p(indexes), n, c, h, w, y.shape[2], y.shape[3], size, stride,
+                                            _f32(scales), _f32(bias), _f32(mean), _f32(var), act)
+
+
 def depthwise_forward_stats(x, wt, bias, y, k, stride, pad, act, stats):
     """bcnn_hip_depthwise_forward that also leaves per-channel (sum, sum of squares) partials of y in `stats`;
     returns the number of partials per channel (0: none, run the plain batch-norm forward)"""

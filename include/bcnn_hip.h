@@ -226,6 +226,21 @@ void bcnn_hip_maxpool_forward(const float *x_d, float *y_d, int *indexes_d, int 
                               int out_h, int out_w, int size, int stride);
 void bcnn_hip_maxpool_backward(const float *dy_d, const int *indexes_d, float *dx_d, int n, int c,
                                int h, int w, int out_h, int out_w, int size, int stride, int overwrite);
+/* The pooling node behind a convolution node with batch-norm (the ResNet stem), for an executor that runs whole passes:
+ * bcnn_hip_maxpool_forward over act(batch-norm(x_d)) computed on the fly from the convolution node's pre-normalisation
+ * output and saved statistics -- the values, scan order and indexes of bcnn_hip_batchnorm_apply followed by
+ * bcnn_hip_maxpool_forward, without writing and re-reading the normalised tensor. Ask bcnn_hip_maxpool_bn_fusable
+ * (stride 2, size 2 or 3, w % 4 == 0, cheap activation). bcnn_hip_conv_forward_stats_only is the convolution node's part:
+ * bcnn_hip_conv_forward (batch-norm, TRAIN mode) up to and including the batch statistics, without the apply sweep. */
+void bcnn_hip_conv_forward_stats_only(const float *x_d, const float *w_d, const float *bias_d, int n, int c, int h, int w,
+                                      int f, int k, int stride, int pad, int groups, float *run_mean_d, float *run_var_d,
+                                      const float *scales_d, float *saved_mean_d, float *saved_var_d,
+                                      float *bn_workspace_d);
+int bcnn_hip_maxpool_bn_fusable(int n, int c, int h, int w, int out_h, int out_w, int size, int stride, int act,
+                                const float *x_d);
+void bcnn_hip_maxpool_forward_bn(const float *x_d, float *y_d, int *indexes_d, int n, int c, int h, int w, int out_h,
+                                 int out_w, int size, int stride, const float *scales_d, const float *bias_d,
+                                 const float *saved_mean_d, const float *saved_var_d, int act);
 void bcnn_hip_avgpool_forward(const float *x_d, float *y_d, int n, int c, int h, int w);
 void bcnn_hip_avgpool_backward(const float *dy_d, float *dx_d, int n, int c, int h, int w);
 
