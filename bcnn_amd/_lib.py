@@ -71,6 +71,10 @@ SIGNATURES = {
     "bcnn_hip_batchnorm_backward_sums": (None, [vp] * 9 + [i, i, i]),
     "bcnn_hip_depthwise_backward_bn": (None, [vp] * 7 + [i] * 9 + [vp] * 5),
     "bcnn_hip_batchnorm_backward_apply": (None, [vp] * 8 + [i, i, i]),
+    "bcnn_hip_depthwise_bnin_fusable": (i, [i] * 9),
+    "bcnn_hip_depthwise_forward_bnin": (i, [vp, vp, vp, vp] + [i] * 8 + [vp, sz] + [vp] * 4 + [i]),
+    "bcnn_hip_depthwise_backward_bnin": (None, [vp] * 7 + [i] * 9 + [vp] * 4 + [i]),
+    "bcnn_hip_depthwise_backward_bn_bnin": (None, [vp] * 7 + [i] * 9 + [vp] * 5 + [vp] * 4 + [i]),
     "bcnn_hip_conv_residual_fusable": (i, [i, i, i, i, vp, vp, vp]),
     "bcnn_hip_conv_forward_residual": (None, [vp, vp, vp] + [i] * 9 + [vp] * 7 + [sz, i, vp]),
     "bcnn_hip_conv_backward_residual": (None, [vp] * 7 + [i] * 9 + [vp] * 7 + [vp, sz, vp, vp, i, vp, vp, sz]),

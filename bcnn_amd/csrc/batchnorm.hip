@@ -116,7 +116,7 @@ struct BnApplyBody {
     bool al;
     __device__ void operator()(unsigned off, int c, int cnt) const {
         const float mean = a.predict ? 0.f : a.mean[c];
-        const float rs = a.predict ? 1.f : sqrtf(a.var[c] + 0.000001f);
+        const BnDiv rs = bn_divisor(a.predict ? 1.f : sqrtf(a.var[c] + 0.000001f));
         const float sc = a.scale[c], b = a.bias[c];
         const bool side_ws = a.ws && a.ws != a.x, side_xn = a.xn && !a.predict;
         if (cnt == 4 && al && (off & 3u) == 0) {
@@ -160,7 +160,7 @@ struct BnApplyBody {
 // The value the forward pass stored for pre-normalisation input x at flat offset `off`, recomputed with the forward's
 // operations (bit-identical): act(bn(x)), or with a folded eltwise node (res != NULL) act(bn(x) + res[off]) for
 // off < res_count.
-__device__ __forceinline__ float bn_recompute_y(float x, float m, float rs, float sc, float b, int act, const float* res,
+__device__ __forceinline__ float bn_recompute_y(float x, float m, const BnDiv& rs, float sc, float b, int act, const float* res,
                                                 unsigned res_count, unsigned long long off) {
     float dummy;
     if (!res) return bn_one(x, m, rs, sc, b, 0, act, &dummy);
@@ -183,7 +183,7 @@ struct BwdSumsF {
     const float* res;     // folded eltwise node (with fwd_bias): its second operand and how much of it is added
     unsigned res_count;
     __device__ float fwd_y(float xv, int c, long long off) const {
-        return bn_recompute_y(xv, mean[c], sqrtf(var[c] + 0.000001f), scale[c], fwd_bias[c], act, res, res_count,
+        return bn_recompute_y(xv, mean[c], bn_divisor(sqrtf(var[c] + 0.000001f)), scale[c], fwd_bias[c], act, res, res_count,
                               (unsigned long long)off);
     }
     __device__ void operator()(long long off, int c, float (&acc)[2]) const {
@@ -200,7 +200,8 @@ struct BwdSumsF {
         if (act != BCNN_HIP_ACT_NONE) {
             float4 yv;
             if (fwd_bias) {
-                const float rs = sqrtf(var[c] + 0.000001f), sc = scale[c], b = fwd_bias[c];
+                const BnDiv rs = bn_divisor(sqrtf(var[c] + 0.000001f));
+                const float sc = scale[c], b = fwd_bias[c];
                 const unsigned long long o = (unsigned long long)off;
                 yv.x = bn_recompute_y(xv.x, m, rs, sc, b, act, res, res_count, o);
                 yv.y = bn_recompute_y(xv.y, m, rs, sc, b, act, res, res_count, o + 1);
@@ -263,11 +264,13 @@ struct BnBwdApplyBody {
     BnBwdApplyArgs a;
     bool al;
     __device__ void operator()(unsigned off, int c, int cnt) const {
-        const float fM = (float)a.M;
+        const BnDiv fM = bn_divisor((float)a.M);
         const bool use_act = a.act != BCNN_HIP_ACT_NONE, use_y = use_act && a.fwd_bias == nullptr;
-        const float mean = a.mean[c], rs = sqrtf(a.var[c] + 0.00001f), sc = a.scale[c];
-        const float rs_fwd = sqrtf(a.var[c] + 0.000001f), fb = a.fwd_bias ? a.fwd_bias[c] : 0.f;
-        const float dmm = __fdiv_rn(a.dmean[c], fM), dv = a.dvar[c];
+        const float mean = a.mean[c], sc = a.scale[c];
+        const BnDiv rs = bn_divisor(sqrtf(a.var[c] + 0.00001f));
+        const BnDiv rs_fwd = bn_divisor(use_act && !use_y ? sqrtf(a.var[c] + 0.000001f) : 1.0f);
+        const float fb = a.fwd_bias ? a.fwd_bias[c] : 0.f;
+        const float dmm = __fdiv_rn(a.dmean[c], fM.d), dv = a.dvar[c];
         if (cnt == 4 && al && (off & 3u) == 0) {
             const float4 g = *reinterpret_cast<const float4*>(a.dy + off);
             const float4 xv = *reinterpret_cast<const float4*>(a.x + off);

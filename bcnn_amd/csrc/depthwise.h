@@ -20,16 +20,28 @@ struct DwBnBwd {
     const float* dvar;
 };
 
+// The convolution node (batch-norm + cheap activation) whose output is this layer's input, when the executor let it stop
+// after its batch statistics: `x` handed to the kernels below is then that node's PRE-NORMALISATION output and every loaded
+// element goes through act(bn(.)) first (bn_one of bn_math.h: the values the producer's apply sweep would have written).
+struct DwBnIn {
+    const float* mean;   // saved batch mean [C]; NULL: x is the input itself
+    const float* var;
+    const float* scale;
+    const float* bias;
+    int act;
+};
+
 // depthwise_lds.hip. All return false (and launch nothing) when the shape is not theirs.
 bool depthwise_lds_ok(const DwShape& s);
 size_t depthwise_lds_stats_floats(const DwShape& s);    // capacity a ConvStats needs for depthwise_forward_lds
 size_t depthwise_lds_partial_floats(const DwShape& s);  // scratch of depthwise_backward_lds
 // y = act(dwconv(x) + bias); with `stats` also the per-channel sum / sum of squares partials of y
 bool depthwise_forward_lds(const float* x, const float* w, const float* bias, float* y, const DwShape& s, int act,
-                           ConvStats* stats);
+                           ConvStats* stats, const DwBnIn* in = nullptr);
 // g = dy * act'(y) (written back over dy when `write_back`), or with `bn` g = BNbackward(bn->dz) * act'(y) and dy is not
 // touched; dbias += sum g; dw += sum x * g; dx = (overwrite ? 0 : dx) + w * g
 bool depthwise_backward_lds(const float* x, const float* w, const float* y, float* dy, float* dx, float* dw, float* dbias,
-                            const DwShape& s, int act, int overwrite, int write_back, const DwBnBwd* bn);
+                            const DwShape& s, int act, int overwrite, int write_back, const DwBnBwd* bn,
+                            const DwBnIn* in = nullptr);
 
 }  // namespace bcnn_hip

@@ -595,6 +595,65 @@ void bcnn_hip_depthwise_backward_bn(const float* x, const float* w, const float*
     }
 }
 
+// ---- the same three with the producing convolution node's batch-norm applied to the input on the fly ----------------
+int bcnn_hip_depthwise_bnin_fusable(int n, int c, int h, int wd, int k, int stride, int pad, int act, int in_act) {
+    if (stride < 1 || k < 1) return 0;
+    DwShape s{n, c, h, wd, (h + 2 * pad - k) / stride + 1, (wd + 2 * pad - k) / stride + 1, k, stride, pad};
+    return depthwise_lds_ok(s) && act_is_cheap(act) && act_bwd_is_cheap(act) && act != BCNN_HIP_ACT_PRELU &&
+           act_is_cheap(in_act) && in_act != BCNN_HIP_ACT_PRELU;
+}
+
+static void dw_bnin_refused(const char* who) {
+    fprintf(stderr, "[bcnn_hip] %s: shape / activation not fusable (ask bcnn_hip_depthwise_bnin_fusable)\n", who);
+    exit(1);
+}
+
+int bcnn_hip_depthwise_forward_bnin(const float* x_raw, const float* w, const float* bias, float* y, int n, int c, int h,
+                                    int wd, int k, int stride, int pad, int act, float* stats, size_t stats_floats,
+                                    const float* in_mean, const float* in_var, const float* in_scale, const float* in_bias,
+                                    int in_act) {
+    DwShape s{n, c, h, wd, (h + 2 * pad - k) / stride + 1, (wd + 2 * pad - k) / stride + 1, k, stride, pad};
+    const long long total = (long long)n * c * s.OH * s.OW;
+    if (total <= 0) return 0;
+    KTimer kt(K_DEPTHWISE_FWD, 2.0 * (double)total * k * k, 4.0 * ((double)n * c * h * wd + (double)total));
+    ConvStats st;
+    st.partials = stats; st.capacity = stats_floats; st.splits = 0;
+    DwBnIn in{in_mean, in_var, in_scale, in_bias, in_act};
+    if (!depthwise_forward_lds(x_raw, w, bias, y, s, act, stats ? &st : nullptr, &in)) dw_bnin_refused("bcnn_hip_depthwise_forward_bnin");
+    return st.splits;
+}
+
+void bcnn_hip_depthwise_backward_bnin(const float* x_raw, const float* w, const float* y, float* dy, float* dx, float* dw,
+                                      float* dbias, int n, int c, int h, int wd, int k, int stride, int pad, int act,
+                                      int overwrite, const float* in_mean, const float* in_var, const float* in_scale,
+                                      const float* in_bias, int in_act) {
+    DwShape s{n, c, h, wd, (h + 2 * pad - k) / stride + 1, (wd + 2 * pad - k) / stride + 1, k, stride, pad};
+    const long long total_o = (long long)n * c * s.OH * s.OW;
+    if (total_o <= 0) return;
+    KTimer kt(K_DEPTHWISE_BWD, 4.0 * (double)total_o * k * k,
+              4.0 * (3.0 * (double)total_o + (overwrite ? 2.0 : 3.0) * (double)n * c * h * wd));
+    DwBnIn in{in_mean, in_var, in_scale, in_bias, in_act};
+    if (!dx || !depthwise_backward_lds(x_raw, w, y, dy, dx, dw, dbias, s, act, overwrite, /*write_back=*/1, nullptr, &in))
+        dw_bnin_refused("bcnn_hip_depthwise_backward_bnin");
+}
+
+void bcnn_hip_depthwise_backward_bn_bnin(const float* x_raw, const float* w, const float* y, const float* dz, float* dx,
+                                         float* dw, float* dbias, int n, int c, int h, int wd, int k, int stride, int pad,
+                                         int act, int overwrite, const float* bn_mean, const float* bn_var,
+                                         const float* bn_scales, const float* bn_dmean, const float* bn_dvar,
+                                         const float* in_mean, const float* in_var, const float* in_scale,
+                                         const float* in_bias, int in_act) {
+    DwShape s{n, c, h, wd, (h + 2 * pad - k) / stride + 1, (wd + 2 * pad - k) / stride + 1, k, stride, pad};
+    const long long total_o = (long long)n * c * s.OH * s.OW;
+    if (total_o <= 0) return;
+    KTimer kt(K_DEPTHWISE_BWD, 4.0 * (double)total_o * k * k,
+              4.0 * (2.0 * (double)total_o + (overwrite ? 2.0 : 3.0) * (double)n * c * h * wd));
+    DwBnBwd bn{dz, bn_mean, bn_var, bn_scales, bn_dmean, bn_dvar};
+    DwBnIn in{in_mean, in_var, in_scale, in_bias, in_act};
+    if (!dx || !depthwise_backward_lds(x_raw, w, y, nullptr, dx, dw, dbias, s, act, overwrite, 0, &bn, &in))
+        dw_bnin_refused("bcnn_hip_depthwise_backward_bn_bnin");
+}
+
 void bcnn_hip_depthwise_backward(const float* x, const float* w, const float* y, float* dy, float* dx,
                                  float* dw, float* dbias, int n, int c, int h, int wd, int k, int stride,
                                  int pad, int act, int overwrite) {

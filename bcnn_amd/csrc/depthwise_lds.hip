@@ -40,7 +40,8 @@ constexpr int kTileFloats = DWL_TILE;  // most a tile reads per stream: 4 x 16 b
 constexpr int kMaxQ = kTileFloats / 4 / 256;
 constexpr int kImageFloats = DWL_IMAGE;  // padded LDS image of a multi-plane tile (x and g each)
 constexpr int kSlack = 4;          // LDS rows behind an image that ragged row groups may read (values discarded)
-constexpr int kConst = 16;         // floats per plane in the constants table: 9 taps, bias | mean, rs, scale, dmean/M, dvar
+constexpr int kConst = 24;         // floats per plane in the constants table: 9 taps, bias | mean, rs, scale, dmean/M, dvar,
+                                   // 1/rs (14); 16..20: mean, rs, scale, bias, 1/rs of the batch-norm applied to the INPUT
 
 struct DwlGeom {
     int P;    // planes per tile: 1, or a multiple of 4 (whole planes)
@@ -191,6 +192,55 @@ __device__ __forceinline__ void dwl_scatter(const float* g, int count, bool vec,
     }
 }
 
+// slots 16..20 of a plane's constants: mean, sqrt(var + 1e-6), scale, bias, 1 / sqrt(var + 1e-6) of the input's batch-norm
+__device__ __forceinline__ float dwl_bnin_const(const DwBnIn& in, int c, int t) {
+    if (t == 16) return in.mean[c];
+    if (t == 18) return in.scale[c];
+    if (t == 19) return in.bias[c];
+    const float rs = sqrtf(in.var[c] + 0.000001f);
+    return t == 17 ? rs : __fdiv_rn(1.0f, rs);
+}
+
+// the same with act(bn(.)) of the producing convolution node applied to every element on its way into the image (the pad
+// cells keep their zeros: padding applies to the normalised tensor)
+template <int NQ>
+__device__ __forceinline__ void dwl_scatter_bn(const float* g, int count, bool vec, bool rowvec, bool multi, const DwlImg& m,
+                                               const float4 (&v)[NQ], float* img, const float* wl, int act) {
+    int j, row;
+    float dummy;
+    auto one = [&](float x, int jj) -> float {
+        const float* k = wl + jj * kConst + 16;
+        const BnDiv rs{k[1], k[4]};
+        return bn_one(x, k[0], rs, k[2], k[3], 0, act, &dummy);
+    };
+    if (vec) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int e = (threadIdx.x + q * 256) * 4;
+            if (e >= count) continue;
+            if (rowvec) {
+                const int slot = dwl_slot(m, e, multi, j, row);
+                *reinterpret_cast<float4*>(img + slot) = make_float4(one(v[q].x, j), one(v[q].y, j), one(v[q].z, j), one(v[q].w, j));
+            } else {
+                int slot = dwl_slot(m, e, multi, j, row);
+                int col = slot - ((j * m.RP + m.lr0 + row) * m.PW + 4);
+                img[slot] = one(v[q].x, j);
+                dwl_next(m, multi, slot, j, row, col);
+                img[slot] = one(v[q].y, j);
+                dwl_next(m, multi, slot, j, row, col);
+                img[slot] = one(v[q].z, j);
+                dwl_next(m, multi, slot, j, row, col);
+                img[slot] = one(v[q].w, j);
+            }
+        }
+    } else {
+        for (int e = threadIdx.x; e < count; e += 256) {
+            const int slot = dwl_slot(m, e, multi, j, row);
+            img[slot] = one(g[e], j);
+        }
+    }
+}
+
 // contiguous LDS piece -> contiguous global piece
 __device__ __forceinline__ void dwl_copy_out(const float* stage, float* dst, int count) {
     if (((reinterpret_cast<uintptr_t>(dst) & 15) == 0) && (count & 3) == 0) {
@@ -207,13 +257,14 @@ struct DwlFwdArgs {
     const float* bias;
     float* y;
     float* stats;  // NULL: none
+    DwBnIn in;     // BNIN kernels: the producer's batch-norm, applied while staging x
     int C, H, W, OH, OW, planes, act, splits, RG;
     DwlGeom g;
     DwlDiv w_magic, h_magic, ow_magic, rg_magic;
     int x_floats;  // LDS floats of the x image (multiple of 4)
 };
 
-template <int S, int VR>
+template <int S, int VR, bool BNIN>
 __global__ __launch_bounds__(256) void dwl_fwd_kernel(const DwlFwdArgs a) {
     extern __shared__ float4 dwl_smem[];
     __shared__ float red[4][2];
@@ -241,10 +292,13 @@ __global__ __launch_bounds__(256) void dwl_fwd_kernel(const DwlFwdArgs a) {
     dwl_zero(xl, a.x_floats);
     for (int i = tid; i < Pe * kConst; i += 256) {
         const int j = i / kConst, t = i - j * kConst, c = (p0 + j) % a.C;
-        wl[i] = t < 9 ? a.w[c * 9 + t] : (t == 9 ? a.bias[c] : 0.f);
+        float v = t < 9 ? a.w[c * 9 + t] : (t == 9 ? a.bias[c] : 0.f);
+        if (BNIN && t >= 16 && t <= 20) v = dwl_bnin_const(a.in, c, t);
+        wl[i] = v;
     }
     __syncthreads();
-    dwl_scatter<kMaxQ>(gx, count, vec, rowvec, multi, m, xv, xl);
+    if (BNIN) dwl_scatter_bn<kMaxQ>(gx, count, vec, rowvec, multi, m, xv, xl, wl, a.in.act);
+    else dwl_scatter<kMaxQ>(gx, count, vec, rowvec, multi, m, xv, xl);
     __syncthreads();
 
     constexpr int NR = (VR - 1) * S + 3;
@@ -334,7 +388,8 @@ struct DwlBwdArgs {
     float* dx;
     float* partials;  // [C][splits][12]: nine taps, bias sum
     DwBnBwd bn;
-    float fM;         // N * OH * OW as float (batch-norm)
+    DwBnIn in;        // BNIN kernels: the producer's batch-norm, applied while staging x
+    float fM, rfM;    // N * OH * OW as float (batch-norm) and its correctly rounded reciprocal
     int C, H, W, OH, OW, planes, act, overwrite, write_back, splits, RG;
     DwlGeom g;
     DwlDiv w_magic, h_magic, ow_magic, oh_magic, rg_magic, rgx_magic, hw2_magic;
@@ -344,7 +399,7 @@ struct DwlBwdArgs {
 
 constexpr int kPart = 12;
 
-template <int S, int VR, bool BN>
+template <int S, int VR, bool BN, bool BNIN>
 __global__ __launch_bounds__(256) void dwl_bwd_kernel(const DwlBwdArgs a) {
     extern __shared__ float4 dwl_smem[];
     __shared__ float red[4][10];
@@ -404,18 +459,22 @@ __global__ __launch_bounds__(256) void dwl_bwd_kernel(const DwlBwdArgs a) {
             else if (t == 11) v = a.bn.scale[c];
             else if (t == 12) v = __fdiv_rn(a.bn.dmean[c], a.fM);
             else if (t == 13) v = a.bn.dvar[c];
+            else if (t == 14) v = __fdiv_rn(1.0f, sqrtf(a.bn.var[c] + 0.00001f));
         }
+        if (BNIN && t >= 16 && t <= 20) v = dwl_bnin_const(a.in, c, t);
         wl[i] = v;
     }
     __syncthreads();
-    dwl_scatter<kMaxQ>(gx, xcount, xvec, xrowvec, multi, mx, xv, xl);
+    if (BNIN) dwl_scatter_bn<kMaxQ>(gx, xcount, xvec, xrowvec, multi, mx, xv, xl, wl, a.in.act);
+    else dwl_scatter<kMaxQ>(gx, xcount, xvec, xrowvec, multi, mx, xv, xl);
     {
         // g = [batch-norm backward of dz] * act'(y), into the image and (own rows, no batch-norm) back over dy
         auto one = [&](float gin, float yv, int j) -> float {
             float g = gin;
             if (BN && !(DWL_ABL & 4)) {
                 const float* k = wl + j * kConst;
-                g = bn_bwd_one(gin, 0.f, yv, k[9], k[10], k[11], k[12], k[13], a.fM, BCNN_HIP_ACT_NONE);
+                const BnDiv rs{k[10], k[14]}, fM{a.fM, a.rfM};
+                g = bn_bwd_one(gin, 0.f, yv, k[9], rs, k[11], k[12], k[13], fM, BCNN_HIP_ACT_NONE);
             }
             if (a.act != BCNN_HIP_ACT_NONE) g *= act_bwd_cheap(yv, a.act, 0.f);
             return g;
@@ -677,8 +736,9 @@ size_t depthwise_lds_partial_floats(const DwShape& s) {
 }
 
 bool depthwise_forward_lds(const float* x, const float* w, const float* bias, float* y, const DwShape& s, int act,
-                           ConvStats* stats) {
+                           ConvStats* stats, const DwBnIn* in) {
     if (!depthwise_lds_ok(s) || !act_is_cheap(act) || act == BCNN_HIP_ACT_PRELU) return false;
+    if (in && (!in->mean || !act_is_cheap(in->act) || in->act == BCNN_HIP_ACT_PRELU)) return false;
     DwlFwdArgs a;
     a.g = dwl_plan(s);
     const int VR = s.stride == 1 ? kVR1 : kVR2;
@@ -700,15 +760,24 @@ bool depthwise_forward_lds(const float* x, const float* w, const float* bias, fl
     const size_t lds = (size_t)(a.x_floats + a.g.stage_floats + a.g.P * kConst) * sizeof(float);
     if (lds > 64 * 1024) return false;
     const unsigned tiles = (unsigned)ceil_div((long long)a.planes, a.g.P) * (unsigned)a.g.NB;
-    if (s.stride == 1) dwl_fwd_kernel<1, kVR1><<<tiles, 256, lds, current_stream()>>>(a);
-    else dwl_fwd_kernel<2, kVR2><<<tiles, 256, lds, current_stream()>>>(a);
+    if (in) {
+        a.in = *in;
+        if (s.stride == 1) dwl_fwd_kernel<1, kVR1, true><<<tiles, 256, lds, current_stream()>>>(a);
+        else dwl_fwd_kernel<2, kVR2, true><<<tiles, 256, lds, current_stream()>>>(a);
+    } else {
+        a.in = DwBnIn{nullptr, nullptr, nullptr, nullptr, 0};
+        if (s.stride == 1) dwl_fwd_kernel<1, kVR1, false><<<tiles, 256, lds, current_stream()>>>(a);
+        else dwl_fwd_kernel<2, kVR2, false><<<tiles, 256, lds, current_stream()>>>(a);
+    }
     KERNEL_CHECK();
     return true;
 }
 
 bool depthwise_backward_lds(const float* x, const float* w, const float* y, float* dy, float* dx, float* dw, float* dbias,
-                            const DwShape& s, int act, int overwrite, int write_back, const DwBnBwd* bn) {
+                            const DwShape& s, int act, int overwrite, int write_back, const DwBnBwd* bn,
+                            const DwBnIn* in) {
     if (!depthwise_lds_ok(s) || !act_bwd_is_cheap(act) || act == BCNN_HIP_ACT_PRELU || !dx) return false;
+    if (in && (!in->mean || !act_is_cheap(in->act) || in->act == BCNN_HIP_ACT_PRELU)) return false;
     DwlBwdArgs a;
     a.g = dwl_plan(s);
     const int S = s.stride, VR = S == 1 ? kVR1 : kVR2;
@@ -728,6 +797,7 @@ bool depthwise_backward_lds(const float* x, const float* w, const float* y, floa
     a.rg_magic = dwl_magic((unsigned)a.RG); a.rgx_magic = dwl_magic((unsigned)a.RGX);
     a.hw2_magic = dwl_magic((unsigned)((s.W + 1) >> 1));
     a.fM = (float)((long long)s.N * s.OH * s.OW);
+    a.rfM = 1.0f / a.fM;  // host division: IEEE, round to nearest
     if (bn) a.bn = *bn;
     else a.bn = DwBnBwd{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     const size_t lds = (size_t)(a.x_floats + a.g_floats + a.g.P * kConst) * sizeof(float);
@@ -735,13 +805,17 @@ bool depthwise_backward_lds(const float* x, const float* w, const float* y, floa
     a.partials = reduce_scratch((size_t)s.C * a.splits * kPart);
     const unsigned tiles = (unsigned)ceil_div((long long)a.planes, a.g.P) * (unsigned)a.g.NB;
     hipStream_t st = current_stream();
-    if (S == 1) {
-        if (bn) dwl_bwd_kernel<1, kVR1, true><<<tiles, 256, lds, st>>>(a);
-        else dwl_bwd_kernel<1, kVR1, false><<<tiles, 256, lds, st>>>(a);
-    } else {
-        if (bn) dwl_bwd_kernel<2, kVR2, true><<<tiles, 256, lds, st>>>(a);
-        else dwl_bwd_kernel<2, kVR2, false><<<tiles, 256, lds, st>>>(a);
-    }
+    a.in = in ? *in : DwBnIn{nullptr, nullptr, nullptr, nullptr, 0};
+#define DWL_LAUNCH(SV, VRV)                                                                     \
+    do {                                                                                        \
+        if (bn && in) dwl_bwd_kernel<SV, VRV, true, true><<<tiles, 256, lds, st>>>(a);          \
+        else if (bn) dwl_bwd_kernel<SV, VRV, true, false><<<tiles, 256, lds, st>>>(a);          \
+        else if (in) dwl_bwd_kernel<SV, VRV, false, true><<<tiles, 256, lds, st>>>(a);          \
+        else dwl_bwd_kernel<SV, VRV, false, false><<<tiles, 256, lds, st>>>(a);                 \
+    } while (0)
+    if (S == 1) DWL_LAUNCH(1, kVR1);
+    else DWL_LAUNCH(2, kVR2);
+#undef DWL_LAUNCH
     KERNEL_CHECK();
     dwl_finalize_kernel<<<s.C, 256, 0, st>>>(a.partials, a.splits, dw, dbias);
     KERNEL_CHECK();

@@ -99,7 +99,8 @@ __global__ __launch_bounds__(256) void maxpool_fwd_s2_bn_kernel(const float* __r
     const unsigned rowid = t / ppr, q = t - rowid * ppr;
     const unsigned plane = rowid / rgs, i0 = (rowid - plane * rgs) * R;
     const int ch = (int)(plane % (unsigned)C);
-    const float m = mean[ch], rs = sqrtf(var[ch] + 0.000001f), sc = scale[ch], b = bias[ch];
+    const float m = mean[ch], sc = scale[ch], b = bias[ch];
+    const BnDiv rs = bn_divisor(sqrtf(var[ch] + 0.000001f));
     const int base = (int)plane * H * W;
     const int w0 = (int)q * 4;
     float best[R][2];

@@ -259,7 +259,9 @@ typedef struct bcnn_conv_param {
     int elt_node;      /* index of that eltwise node, -1: none */
     int pool_node;     /* index of the max-pooling node that is this node's only consumer and normalises this node's
                         * pre-normalisation output on the fly inside a forward pass (bcnn_link_conv_maxpool), -1: none */
-    int apply_skipped; /* this node left its batch-norm apply sweep to that node in the running forward pass */
+    int dw_node;       /* index of the depthwise node that is this node's only consumer and normalises this node's
+                        * pre-normalisation output while staging it (bcnn_link_conv_depthwise), -1: none */
+    int apply_skipped; /* this node left its batch-norm apply sweep to its consumer in the running forward pass */
     int data_pending;  /* the last forward pass did not write this node's output tensor (nobody inside a pass reads it):
                         * bcnn_materialize_data produces it from bn_workspace_gpu on demand */
 #endif
@@ -278,6 +280,8 @@ typedef struct bcnn_depthwise_conv_param {
     float *stats_gpu;    /* per-channel statistics partials of the last forward (TRAIN) */
     size_t stats_floats;
     int stats_splits;    /* > 0: stats_gpu holds the statistics of the output written by the last forward of this pass */
+    int conv_node;       /* the convolution node whose batch-norm this node applies to its input on the fly, -1: none */
+    int raw_input;       /* the last forward pass read that node's pre-normalisation output: so must its backward */
     int grads_pending;   /* the last backward pass did not write the gradient of this node's output nor rewrite the
                           * batch-norm node's output gradient (nothing inside a pass reads them): they are produced on
                           * demand by bcnn_materialize_gradients, as the reference's two workers leave them */
@@ -383,6 +387,7 @@ void bcnn_backward_cost_layer(bcnn_net *net, bcnn_node *node);
 void bcnn_link_depthwise_batchnorm(bcnn_net *net); /* bcnn_layers_hot.c; called by bcnn_compile_net */
 void bcnn_link_conv_eltwise(bcnn_net *net);        /* bcnn_layers_hot.c; called by bcnn_compile_net */
 void bcnn_link_conv_maxpool(bcnn_net *net);
+void bcnn_link_conv_depthwise(bcnn_net *net);
 void bcnn_materialize_data(bcnn_net *net, int tensor);      /* tensor < 0: every pending one */
 void bcnn_materialize_gradients(bcnn_net *net, int tensor); /* tensor < 0: every pending one */
 void bcnn_drop_pending_gradients(bcnn_net *net);

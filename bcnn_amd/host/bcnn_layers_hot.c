@@ -108,6 +108,7 @@ bcnn_status bcnn_add_convolutional_layer(bcnn_net *net, int num_filters, int siz
     param->num_groups = num_groups;
     param->elt_node = -1;
     param->pool_node = -1;
+    param->dw_node = -1;
     node.forward = bcnn_forward_conv_layer;
     node.backward = bcnn_backward_conv_layer;
     node.update = bcnn_update_conv_layer;
@@ -162,9 +163,9 @@ void bcnn_forward_conv_layer(bcnn_net *net, bcnn_node *node) {
     conv_io io = conv_tensors(net, node);
     p->data_pending = 0;
     p->apply_skipped = 0;
-    if (hctx(net)->in_pass == 1 && p->pool_node >= 0 && net->mode == BCNN_MODE_TRAIN) {
-        /* the max-pooling node that runs next in this pass normalises this node's pre-normalisation output on the fly:
-         * convolution and batch statistics only; this node's own output tensor is not written */
+    if (hctx(net)->in_pass == 1 && (p->pool_node >= 0 || p->dw_node >= 0) && net->mode == BCNN_MODE_TRAIN) {
+        /* the max-pooling / depthwise node that runs next in this pass normalises this node's pre-normalisation output on
+         * the fly: convolution and batch statistics only; this node's own output tensor is not written */
         bcnn_hip_conv_forward_stats_only(io.x->data_gpu, io.w->data_gpu, io.b->data_gpu, io.x->n, io.x->c, io.x->h, io.x->w,
                                          p->num, p->size, p->stride, p->pad, p->num_groups, io.run_mean->data_gpu,
                                          io.run_var->data_gpu, io.scales->data_gpu, p->saved_mean.data_gpu,
@@ -268,6 +269,7 @@ bcnn_status bcnn_add_depthwise_conv_layer(bcnn_net *net, int size, int stride, i
     node.param = param;
     param->activation = activation; param->size = size; param->stride = stride; param->pad = pad;
     param->bn_node = -1;
+    param->conv_node = -1;
     node.forward = bcnn_forward_depthwise_conv_layer;
     node.backward = bcnn_backward_depthwise_conv_layer;
     node.update = bcnn_update_depthwise_conv_layer;
@@ -285,6 +287,23 @@ void bcnn_forward_depthwise_conv_layer(bcnn_net *net, bcnn_node *node) {
     bcnn_tensor *x = &net->tensors[node->src[0]], *w = &net->tensors[node->src[1]];
     bcnn_tensor *b = &net->tensors[node->src[2]], *y = &net->tensors[node->dst[0]];
     p->stats_splits = 0;
+    p->raw_input = 0;
+    if (hctx(net)->in_pass == 1 && p->conv_node >= 0 && ((bcnn_conv_param *)net->nodes[p->conv_node].param)->apply_skipped) {
+        /* the convolution node before this one stopped after its batch statistics: its pre-normalisation output is
+         * normalised while it is staged (and again by this node's backward, which needs the same values) */
+        bcnn_node *cn = &net->nodes[p->conv_node];
+        bcnn_conv_param *cp = (bcnn_conv_param *)cn->param;
+        const int want_stats = net->mode == BCNN_MODE_TRAIN && p->bn_node >= 0 && p->stats_gpu;
+        cp->apply_skipped = 0;
+        p->raw_input = 1;
+        p->stats_splits = bcnn_hip_depthwise_forward_bnin(cp->bn_workspace_gpu, w->data_gpu, b->data_gpu, y->data_gpu, x->n,
+                                                          x->c, x->h, x->w, p->size, p->stride, p->pad, (int)p->activation,
+                                                          want_stats ? p->stats_gpu : NULL, want_stats ? p->stats_floats : 0,
+                                                          cp->saved_mean.data_gpu, cp->saved_variance.data_gpu,
+                                                          net->tensors[cn->src[5]].data_gpu,
+                                                          net->tensors[cn->src[2]].data_gpu, (int)cp->activation);
+        return;
+    }
     if (hctx(net)->in_pass == 1 && net->mode == BCNN_MODE_TRAIN && p->bn_node >= 0 && p->stats_gpu) {
         /* the batch-norm node that runs next in this pass takes its statistics from this kernel's epilogue */
         p->stats_splits = bcnn_hip_depthwise_forward_stats(x->data_gpu, w->data_gpu, b->data_gpu, y->data_gpu, x->n, x->c,
@@ -300,6 +319,31 @@ void bcnn_backward_depthwise_conv_layer(bcnn_net *net, bcnn_node *node) {
     bcnn_depthwise_conv_param *p = (bcnn_depthwise_conv_param *)node->param;
     bcnn_tensor *x = &net->tensors[node->src[0]], *w = &net->tensors[node->src[1]];
     bcnn_tensor *b = &net->tensors[node->src[2]], *y = &net->tensors[node->dst[0]];
+    if (hctx(net)->in_pass == 2 && p->raw_input && p->conv_node >= 0 && x->grad_data_gpu) {
+        /* this pass's forward read the producer's pre-normalisation output: the input tensor itself was never written */
+        bcnn_node *cn = &net->nodes[p->conv_node];
+        bcnn_conv_param *cp = (bcnn_conv_param *)cn->param;
+        const float *im = cp->saved_mean.data_gpu, *iv = cp->saved_variance.data_gpu;
+        const float *is = net->tensors[cn->src[5]].data_gpu, *ib = net->tensors[cn->src[2]].data_gpu;
+        if (p->bn_fused_bwd) {
+            const bcnn_node *bn = &net->nodes[p->bn_node];
+            const bcnn_batchnorm_param *bp = (const bcnn_batchnorm_param *)bn->param;
+            bcnn_hip_depthwise_backward_bn_bnin(cp->bn_workspace_gpu, w->data_gpu, y->data_gpu,
+                                                net->tensors[bn->dst[0]].grad_data_gpu, x->grad_data_gpu, w->grad_data_gpu,
+                                                b->grad_data_gpu, x->n, x->c, x->h, x->w, p->size, p->stride, p->pad,
+                                                (int)p->activation, bcnn_grad_sole_writer(net, node->src[0]),
+                                                bp->saved_mean.data_gpu, bp->saved_variance.data_gpu,
+                                                net->tensors[bn->src[3]].data_gpu, bp->saved_mean.grad_data_gpu,
+                                                bp->saved_variance.grad_data_gpu, im, iv, is, ib, (int)cp->activation);
+            p->grads_pending = 1;
+        } else {
+            bcnn_hip_depthwise_backward_bnin(cp->bn_workspace_gpu, w->data_gpu, y->data_gpu, y->grad_data_gpu,
+                                             x->grad_data_gpu, w->grad_data_gpu, b->grad_data_gpu, x->n, x->c, x->h, x->w,
+                                             p->size, p->stride, p->pad, (int)p->activation,
+                                             bcnn_grad_sole_writer(net, node->src[0]), im, iv, is, ib, (int)cp->activation);
+        }
+        return;
+    }
     if (hctx(net)->in_pass == 2 && p->bn_fused_bwd && x->grad_data_gpu) {
         /* the batch-norm node (which ran just before in this pass) only produced its sums: its apply sweep
          * (bcnn_batchnorm_layer.c:292-296) happens inside this node's kernel, on the gradient of ITS output */
@@ -489,6 +533,44 @@ void bcnn_link_conv_maxpool(bcnn_net *net) {
             continue;
         cp->pool_node = m;
         mp->conv_node = m - 1;
+    }
+}
+
+/* Pairs a convolution node (batch-norm, cheap activation) with the depthwise node right behind it when that node is the
+ * only consumer of the convolution output and runs on the LDS-staged kernels (MobileNet: every 1x1 convolution and the
+ * stem), TRAIN-mode nets: the convolution node stops after its batch statistics, the depthwise kernels normalise its
+ * pre-normalisation output while staging it -- forward and backward (the weight gradient needs the same input values).
+ * The convolution output tensor is not written (bcnn_materialize_data). */
+void bcnn_link_conv_depthwise(bcnn_net *net) {
+    for (int i = 0; i < net->num_nodes; ++i) {
+        bcnn_node *nd = &net->nodes[i];
+        if (nd->type == BCNN_LAYER_CONV2D) ((bcnn_conv_param *)nd->param)->dw_node = -1;
+        else if (nd->type == BCNN_LAYER_DEPTHWISE_CONV2D) {
+            ((bcnn_depthwise_conv_param *)nd->param)->conv_node = -1;
+            ((bcnn_depthwise_conv_param *)nd->param)->raw_input = 0;
+        }
+    }
+    if (BCNN_EXP_ENV("BCNN_NO_NODE_FUSION") || BCNN_EXP_ENV("BCNN_NO_CONV_DW_FUSION") || net->mode != BCNN_MODE_TRAIN) return;
+    for (int d = 1; d < net->num_nodes; ++d) {
+        bcnn_node *dn = &net->nodes[d], *cn = &net->nodes[d - 1];
+        if (dn->type != BCNN_LAYER_DEPTHWISE_CONV2D || cn->type != BCNN_LAYER_CONV2D || dn->src[0] != cn->dst[0]) continue;
+        const int t = cn->dst[0];
+        int writers = 0, consumers = 0;
+        for (int i = 0; i < net->num_nodes; ++i) {
+            for (int k = 0; k < net->nodes[i].num_dst; ++k) writers += net->nodes[i].dst[k] == t;
+            for (int k = 0; k < net->nodes[i].num_src; ++k) consumers += net->nodes[i].src[k] == t;
+        }
+        if (writers != 1 || consumers != 1) continue;
+        bcnn_conv_param *cp = (bcnn_conv_param *)cn->param;
+        bcnn_depthwise_conv_param *dp = (bcnn_depthwise_conv_param *)dn->param;
+        const bcnn_tensor *x = &net->tensors[t];
+        if (!cp->batch_norm || !cp->bn_workspace_gpu || !x->grad_data_gpu ||
+            ((uintptr_t)cp->bn_workspace_gpu & 15) != 0 ||
+            !bcnn_hip_depthwise_bnin_fusable(x->n, x->c, x->h, x->w, dp->size, dp->stride, dp->pad, (int)dp->activation,
+                                             (int)cp->activation))
+            continue;
+        cp->dw_node = d;
+        dp->conv_node = d - 1;
     }
 }
 

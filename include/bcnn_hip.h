@@ -304,6 +304,29 @@ void bcnn_hip_depthwise_backward_bn(const float *x_d, const float *w_d, const fl
                                     const float *bn_var_d, const float *bn_scales_d, const float *bn_dmean_d,
                                     const float *bn_dvar_d);
 
+/* A depthwise layer whose INPUT is the output of a convolution node with batch-norm (+ cheap activation) that has no other
+ * consumer (MobileNet: every 1x1 convolution feeds the next block's depthwise layer). For an executor that runs whole
+ * passes: the convolution node stops after its batch statistics (bcnn_hip_conv_forward_stats_only) and these three read
+ * its PRE-NORMALISATION output x_raw_d, applying act(batch-norm(.)) with the in_* vectors (saved mean / variance, scales,
+ * bias of that node) to every element on its way in -- the values the producer's apply sweep would have written
+ * (bcnn_batchnorm_layer.c:226-241), so results are those of bcnn_hip_depthwise_forward_stats / _backward / _backward_bn.
+ * Ask bcnn_hip_depthwise_bnin_fusable first. */
+int bcnn_hip_depthwise_bnin_fusable(int n, int c, int h, int w, int k, int stride, int pad, int act, int in_act);
+int bcnn_hip_depthwise_forward_bnin(const float *x_raw_d, const float *w_d, const float *bias_d, float *y_d, int n, int c,
+                                    int h, int w, int k, int stride, int pad, int act, float *stats_d, size_t stats_floats,
+                                    const float *in_mean_d, const float *in_var_d, const float *in_scale_d,
+                                    const float *in_bias_d, int in_act);
+void bcnn_hip_depthwise_backward_bnin(const float *x_raw_d, const float *w_d, const float *y_d, float *dy_d, float *dx_d,
+                                      float *dw_d, float *dbias_d, int n, int c, int h, int w, int k, int stride, int pad,
+                                      int act, int overwrite, const float *in_mean_d, const float *in_var_d,
+                                      const float *in_scale_d, const float *in_bias_d, int in_act);
+void bcnn_hip_depthwise_backward_bn_bnin(const float *x_raw_d, const float *w_d, const float *y_d, const float *dz_d,
+                                         float *dx_d, float *dw_d, float *dbias_d, int n, int c, int h, int w, int k,
+                                         int stride, int pad, int act, int overwrite, const float *bn_mean_d,
+                                         const float *bn_var_d, const float *bn_scales_d, const float *bn_dmean_d,
+                                         const float *bn_dvar_d, const float *in_mean_d, const float *in_var_d,
+                                         const float *in_scale_d, const float *in_bias_d, int in_act);
+
 /* ---------------------------------------------------------------------------------------------
  * SGD step on a parameter arena.  Replaces bcnn_sgd_update_gpu (bcnn_learner.c:86-104); semantics
  * of bcnn_sgd_update_cpu (:67-83) fused into one pass per buffer:
