@@ -72,6 +72,9 @@ SIGNATURES = {
     "bcnn_hip_depthwise_backward_bn": (None, [vp] * 7 + [i] * 9 + [vp] * 5),
     "bcnn_hip_batchnorm_backward_apply": (None, [vp] * 8 + [i, i, i]),
     "bcnn_hip_depthwise_bnin_fusable": (i, [i] * 9),
+    "bcnn_hip_conv_bnsums_size": (sz, [i] * 4),
+    "bcnn_hip_conv_backward_bnsums": (i, [vp] * 8 + [i] * 10 + [vp, vp, i] + [vp] * 8 + [vp, sz] + [vp, vp, vp, sz]),
+    "bcnn_hip_batchnorm_backward_finalize": (None, [vp, i] + [vp] * 6 + [i]),
     "bcnn_hip_depthwise_forward_bnin": (i, [vp, vp, vp, vp] + [i] * 8 + [vp, sz] + [vp] * 4 + [i]),
     "bcnn_hip_depthwise_backward_bnin": (None, [vp] * 7 + [i] * 9 + [vp] * 4 + [i]),
     "bcnn_hip_depthwise_backward_bn_bnin": (None, [vp] * 7 + [i] * 9 + [vp] * 5 + [vp] * 4 + [i]),

@@ -242,6 +242,47 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int C
     dvar[c] = vd;
 }
 
+// The same for MANY partials per channel (a 1x1 convolution's data-gradient epilogue emits one per 64 pixels): one workgroup
+// per channel, four loads in flight per thread, fixed-shape reduction in double.
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_wide_kernel(const float* __restrict__ partials, int C, int splits,
+                                                                   const float* __restrict__ scale,
+                                                                   const float* __restrict__ var, float* __restrict__ dbias,
+                                                                   float* __restrict__ dscales, float* __restrict__ dmean,
+                                                                   float* __restrict__ dvar) {
+    __shared__ double red[16][2];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c = blockIdx.x;
+    const float2* p = reinterpret_cast<const float2*>(partials) + (long long)c * splits;
+    double s1 = 0.0, s2 = 0.0;
+    int i = threadIdx.x;
+    for (; i + 3 * 1024 < splits; i += 4 * 1024) {
+        const float2 v0 = p[i], v1 = p[i + 1024], v2 = p[i + 2048], v3 = p[i + 3072];
+        s1 += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
+        s2 += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+    }
+    for (; i < splits; i += 1024) {
+        const float2 v = p[i];
+        s1 += (double)v.x;
+        s2 += (double)v.y;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if (lane == 0) { red[wid][0] = s1; red[wid][1] = s2; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    s1 = 0.0;
+    s2 = 0.0;
+    for (int w = 0; w < 16; ++w) { s1 += red[w][0]; s2 += red[w][1]; }
+    const float v = var[c], sc = scale[c];
+    dbias[c] += (float)s1;
+    dscales[c] += (float)(s2 / (double)sqrtf(v + 0.000001f));
+    float md = (float)(s1 * (double)sc);
+    float vd = (float)(s2 * (double)sc);
+    md *= (-1.0f / sqrtf(v + 0.00001f));
+    vd *= -0.5f / (v * sqrtf(v) + 0.00001f);
+    dmean[c] = md;
+    dvar[c] = vd;
+}
+
 struct BnBwdApplyArgs {
     float* dy;        // in/out
     float* dx;        // optional copy
@@ -471,6 +512,14 @@ void bcnn_hip_batchnorm_apply(const float* x, float* y, const float* scales, con
     auto al16 = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     launch_chan_map(BnApplyBody{a, al16(x) && al16(y)}, n, c, hw);
     if (a.act != act) bcnn_hip_activation_forward(y, (size_t)total, act, nullptr, hw, c);
+}
+
+void bcnn_hip_batchnorm_backward_finalize(const float* sums, int splits, const float* scales, float* dscales, float* dbias,
+                                          const float* saved_var, float* dmean, float* dvar, int c) {
+    if (c <= 0 || splits <= 0) return;
+    bn_bwd_finalize_wide_kernel<<<c, 1024, 0, current_stream()>>>(sums, c, splits, scales, saved_var, dbias, dscales, dmean,
+                                                                  dvar);
+    KERNEL_CHECK();
 }
 
 void bcnn_hip_batchnorm_backward_sums(const float* dy, const float* scales, float* dscales, float* dbias,

@@ -21,7 +21,7 @@ float* reduce_scratch(size_t floats);                                           
 size_t conv_dw_workspace_floats(const ConvShape& s);
 bool conv_backward_weights(const float* x, const float* dy, float* dw, float* dbias, const ConvShape& s,
                            float* workspace, size_t workspace_floats, bool want_bias);
-void conv_backward_data(const float* w, const float* dy, float* dx, const ConvShape& s);
+void conv_backward_data(const float* w, const float* dy, float* dx, const ConvShape& s, DxBnSums* bs = nullptr);
 // conv_dw_dma.hip: per-tap GEMM with LDS-DMA staging (the general fast path)
 size_t conv_dw_dma_workspace_floats(const ConvShape& s);
 bool conv_backward_weights_dma(const float* x, const float* dy, float* dw, const ConvShape& s, float* workspace,
@@ -217,7 +217,7 @@ static void conv_backward_impl(const float* x, const float* w, const float* bias
                                const float* scales, float* dscales, const float* saved_mean,
                                const float* saved_var, float* dmean, float* dvar, const float* x_norm,
                                const float* bn_workspace, float* workspace, size_t workspace_elems,
-                               const ConvResidualBwd* rb) {
+                               const ConvResidualBwd* rb, DxBnSums* bs = nullptr) {
     const ConvShape s = make_conv_shape(n, c, h, wd, f, k, stride, pad, groups);
     const size_t ysize = (size_t)n * f * s.OHOW;
     if (rb) {
@@ -280,8 +280,9 @@ static void conv_backward_impl(const float* x, const float* w, const float* bias
         set_current_stream(main_stream);
     }
     if (!batch_norm && !bias_done) bcnn_hip_grad_bias(dbias, dy, n, f, s.OHOW);  // uses the shared reduce scratch
+    if (bs) bs->splits = 0;
     if (dx && !conv_backward_data_winograd_fused(w, dy, dx, s) && !conv_backward_data_winograd(w, dy, dx, s))
-        conv_backward_data(w, dy, dx, s);
+        conv_backward_data(w, dy, dx, s, bs);
     if (side) HIP_CHECK(hipStreamWaitEvent(main_stream, side->done, 0));
 }
 
@@ -294,6 +295,24 @@ void bcnn_hip_conv_backward(const float* x, const float* w, const float* bias, c
     conv_backward_impl(x, w, bias, y, dy, dx, dw, dbias, n, c, h, wd, f, k, stride, pad, groups, act, slopes, dslopes,
                        batch_norm, scales, dscales, saved_mean, saved_var, dmean, dvar, x_norm, bn_workspace, workspace,
                        workspace_elems, nullptr);
+}
+
+size_t bcnn_hip_conv_bnsums_size(int n, int c, int h, int wd) {
+    return (size_t)c * (size_t)ceil_div((long long)n * h * wd, 64) * 2;
+}
+
+int bcnn_hip_conv_backward_bnsums(const float* x, const float* w, const float* bias, const float* y, float* dy, float* dx,
+                                  float* dw, float* dbias, int n, int c, int h, int wd, int f, int k, int stride, int pad,
+                                  int groups, int act, const float* slopes, float* dslopes, int batch_norm,
+                                  const float* scales, float* dscales, const float* saved_mean, const float* saved_var,
+                                  float* dmean, float* dvar, const float* x_norm, const float* bn_workspace,
+                                  float* workspace, size_t workspace_elems, const float* prev_y, const float* prev_mean,
+                                  float* sums, size_t sums_floats) {
+    DxBnSums bs{prev_y, prev_mean, sums, sums_floats, 0};
+    conv_backward_impl(x, w, bias, y, dy, dx, dw, dbias, n, c, h, wd, f, k, stride, pad, groups, act, slopes, dslopes,
+                       batch_norm, scales, dscales, saved_mean, saved_var, dmean, dvar, x_norm, bn_workspace, workspace,
+                       workspace_elems, nullptr, (sums && prev_y && prev_mean) ? &bs : nullptr);
+    return bs.splits;
 }
 
 void bcnn_hip_conv_backward_residual(const float* x, const float* w, const float* bias, float* dy, float* dx, float* dw,

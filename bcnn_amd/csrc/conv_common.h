@@ -36,6 +36,18 @@ struct ConvStats {
     size_t capacity;  // floats behind `partials`; every forward path checks its own slot count against it
 };
 
+// Backward sums of the stand-alone batch-norm node IN FRONT of a 1x1 convolution, emitted by that convolution's data-gradient
+// kernel from the tile it is about to store (bcnn_batchnorm_layer.c:263-281 needs S1 = sum dz, S2 = sum dz * (y - mean)
+// over (n, h, w) per channel; dz is this kernel's output, y the batch-norm node's input):
+// partials[(channel * splits + column tile) * 2 + {S1, S2}], the layout bn_bwd_finalize consumes.
+struct DxBnSums {
+    const float* y;      // the batch-norm node's input (same shape as the convolution's input)
+    const float* mean;   // its saved batch mean [C]
+    float* partials;
+    size_t capacity;     // floats behind `partials`
+    int splits;          // out: partials per channel written, 0 = this path does not emit them
+};
+
 // A following eltwise node folded into a convolution node's batch-norm apply pass (bcnn_eltwise_layer.c:82-113)
 struct BnResidual {
     const float* res;  // the eltwise node's second operand

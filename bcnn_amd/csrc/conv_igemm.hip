@@ -312,7 +312,7 @@ static void dispatch_igemm(IgemmArgs& a, long long max_cols) {
 
 bool conv_forward_dma(const float* x, const float* w, const float* bias, const float* slopes, float* y,
                       const ConvShape& s, int act, int raw, ConvStats* stats);        // conv_igemm_dma.hip
-bool conv_backward_data_dma(const float* w, const float* dy, float* dx, const ConvShape& s);
+bool conv_backward_data_dma(const float* w, const float* dy, float* dx, const ConvShape& s, DxBnSums* bs);
 bool conv_forward_small_c(const float* x, const float* w, const float* bias, const float* slopes, float* y,
                           const ConvShape& s, int act, int raw, ConvStats* stats);   // conv_igemm_dma.hip
 
@@ -441,7 +441,8 @@ static bool conv_backward_data_small_c(const float* w, const float* dy, float* d
     return true;
 }
 
-void conv_backward_data(const float* w, const float* dy, float* dx, const ConvShape& s) {
+void conv_backward_data(const float* w, const float* dy, float* dx, const ConvShape& s, DxBnSums* bs) {
+    if (bs) bs->splits = 0;
     if (s.total_p == 0 || s.Cg == 0) return;
     if (s.ksz > 7 && !s.pointwise) {
         fprintf(stderr, "[bcnn_hip] conv backward: kernel size %d > 7 is not supported\n", s.ksz);
@@ -450,7 +451,7 @@ void conv_backward_data(const float* w, const float* dy, float* dx, const ConvSh
     KTimer kt(K_CONV_DX, 2.0 * (double)s.total_q * s.Mg * s.K * s.groups,
               4.0 * ((double)s.N * s.C * s.HW + (double)s.F * s.K + (double)s.N * s.F * s.OHOW));
     if (conv_backward_data_small_c(w, dy, dx, s)) return;
-    if (dma_enabled() && conv_backward_data_dma(w, dy, dx, s)) return;
+    if (dma_enabled() && conv_backward_data_dma(w, dy, dx, s, bs)) return;
     IgemmArgs a;
     a.a_base = w; a.b_base = dy; a.out = dx; a.bias = nullptr; a.slopes = nullptr; a.s = s;
     a.mode = 1; a.act = BCNN_HIP_ACT_NONE; a.add_bias = 0;

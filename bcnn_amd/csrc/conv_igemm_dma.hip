@@ -81,6 +81,11 @@ struct DmaArgs {
     // stats[((g*Mg + m) * stats_splits + column tile) * 2 + {0: sum, 1: sum of squares}]
     float* stats;
     int stats_splits;
+    // 1x1 dX only, optional (DxBnSums, conv_common.h): S1 = sum of the stored values, S2 = sum of stored value * (bs_y - mean)
+    // per ROW (input channel), one pair per column tile like `stats`
+    const float* bs_y;
+    const float* bs_mean;
+    float* bs_out;
     // rowmode (few input channels, e.g. the 7x7 RGB stem): the gathered tensor is a zero-padded copy of x and the
     // reduction runs over ALL (c, kr, kc) rows as ONE "tap": row j reads the lane's pixel at the wave-uniform offset
     // c * plane + kr * pitch + kc, (c, kr, kc) = (j / kk, (j % kk) / ks, j % ks) by magic multiplies on the scalar unit
@@ -89,7 +94,9 @@ struct DmaArgs {
     DmaClass cls[kDmaMaxClasses];
 };
 
-template <int WM, int WN, int TM, int TN>
+// BS: the variant that can emit the batch-norm backward sums of DxBnSums (its epilogue needs ~35 more registers, which would
+// cost every other launch three of its eight waves per SIMD)
+template <int WM, int WN, int TM, int TN, bool BS = false>
 __global__ __launch_bounds__(64 * WM * WN, ABL_LB) void conv_igemm_dma_kernel(const DmaArgs a) {
     constexpr int BK = kDmaBK;
     constexpr int NW = WM * WN;         // waves per workgroup (4, or 2 for the 64 x 32 tile)
@@ -333,8 +340,8 @@ __global__ __launch_bounds__(64 * WM * WN, ABL_LB) void conv_igemm_dma_kernel(co
     // Each wave transposes its 32x32 accumulator tile through a private XOR-swizzled LDS pad so that a lane
     // owns half a ROW (16 values): ~50 VALU per tile instead of the ~600 a shuffle butterfly over the
     // accumulator layout costs -- fp32 MFMAs and VALU share the SIMD, epilogue VALU is not free.
+    __shared__ float s_stat[BM][WN * TN][2];  // shared by the two statistics epilogues below (never both in one launch)
     if (a.stats != nullptr) {
-        __shared__ float s_stat[BM][WN * TN][2];
         float* pad = smem + wid * 1024;
         const int prow = lane & 31, phalf = lane >> 5;
 #pragma unroll
@@ -372,6 +379,81 @@ __global__ __launch_bounds__(64 * WM * WN, ABL_LB) void conv_igemm_dma_kernel(co
 #pragma unroll
             for (int k = 0; k < WN * TN; ++k) { s0 += s_stat[tid][k][0]; s1 += s_stat[tid][k][1]; }
             float* dst = a.stats + ((size_t)(g * s.Mg + m0 + tid) * a.stats_splits + pt) * 2;
+            dst[0] = s0; dst[1] = s1;
+        }
+    }
+
+    // ---- the same transposition for the batch-norm node in front of a 1x1 convolution (dX): S1 and S2 of its backward --
+    if (BS && a.bs_out != nullptr) {
+        float (*s_bs)[WN * TN][2] = s_stat;
+        float* pad = smem + wid * 1024;
+        const int prow = lane & 31, phalf = lane >> 5;
+        const bool vec4 = (col_per_img & 3) == 0 && (reinterpret_cast<uintptr_t>(a.bs_y) & 15) == 0;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                // the lane's 16 partners y - mean are requested first: they arrive while the tile is transposed
+                const int row = m0 + (wm * TM + i) * 32 + prow;  // input channel of this lane's half row
+                const bool rok = row < a.M;
+                const float mu = rok ? a.bs_mean[row] : 0.f;
+                const int q0 = p0 + (wn * TN + j) * 32 + phalf * 16;  // first of the lane's 16 columns
+                unsigned n = (unsigned)q0 / (unsigned)col_per_img, pix = (unsigned)q0 - n * (unsigned)col_per_img;
+                float yv[16];
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    // columns past the end hold exact zeros in the tile: any finite partner will do
+                    yv[c4 * 4] = yv[c4 * 4 + 1] = yv[c4 * 4 + 2] = yv[c4 * 4 + 3] = mu;
+                    const int q = q0 + c4 * 4;
+                    if (rok && q < total_cols) {
+                        const float* yp = a.bs_y + ((size_t)n * (size_t)s.C + (size_t)row) * (size_t)s.HW + pix;
+                        if (vec4) {  // four columns stay inside one image and are 16-byte aligned
+                            const float4 t4 = *reinterpret_cast<const float4*>(yp);
+                            yv[c4 * 4] = t4.x; yv[c4 * 4 + 1] = t4.y; yv[c4 * 4 + 2] = t4.z; yv[c4 * 4 + 3] = t4.w;
+                        } else {
+                            unsigned nn = n, pp = pix;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                if (q + k < total_cols)
+                                    yv[c4 * 4 + k] = a.bs_y[((size_t)nn * (size_t)s.C + (size_t)row) * (size_t)s.HW + pp];
+                                if (++pp == (unsigned)col_per_img) { pp = 0; ++nn; }
+                            }
+                        }
+                    }
+                    pix += 4;
+                    if (pix >= (unsigned)col_per_img) { pix -= (unsigned)col_per_img; ++n; }
+                }
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r];
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int prw = mfma_row(r, lane);
+                    pad[prw * 32 + (l31 ^ prw)] = v[r];
+                }
+                __syncthreads();
+                float sv = 0.f, sq = 0.f;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    const float t = pad[prow * 32 + ((phalf * 16 + c) ^ prow)];
+                    sv += t;
+                    sq += t * (yv[c] - mu);
+                }
+                sv += __shfl_xor(sv, 32);
+                sq += __shfl_xor(sq, 32);
+                if (phalf == 0) {
+                    const int trow = (wm * TM + i) * 32 + prow;
+                    s_bs[trow][wn * TN + j][0] = sv;
+                    s_bs[trow][wn * TN + j][1] = sq;
+                }
+            }
+        __syncthreads();
+        if (tid < BM && m0 + tid < a.M) {
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < WN * TN; ++k) { s0 += s_bs[tid][k][0]; s1 += s_bs[tid][k][1]; }
+            float* dst = a.bs_out + ((size_t)(m0 + tid) * a.stats_splits + pt) * 2;
             dst[0] = s0; dst[1] = s1;
         }
     }
@@ -508,6 +590,15 @@ static void launch_dma_cfg(DmaArgs& a, int max_cols) {
     a.mtiles = ceil_div(a.M, BM);
     a.stats_splits = ceil_div(max_cols, BN);
     dim3 grid((unsigned)(a.mtiles * a.stats_splits), (unsigned)a.s.groups, (unsigned)a.nclass);
+    if (a.bs_out != nullptr) {
+        if (WM == 2 && WN == 2 && TM == 1 && TN == 1) {
+            conv_igemm_dma_kernel<2, 2, 1, 1, true><<<grid, 256, 0, current_stream()>>>(a);
+            KERNEL_CHECK();
+            return;
+        }
+        fprintf(stderr, "[bcnn_hip] conv_igemm_dma: batch-norm sums are emitted by the 64 x 64 tile only\n");
+        exit(1);
+    }
     conv_igemm_dma_kernel<WM, WN, TM, TN><<<grid, 64 * WM * WN, 0, current_stream()>>>(a);
     KERNEL_CHECK();
 }
@@ -560,6 +651,7 @@ bool conv_forward_dma(const float* x, const float* w, const float* bias, const f
     for (int t = 0; t < kk2; ++t) tapoff[t] = (unsigned char)t;
     pack_weights(w, at, s, 0, a.M, a.J, a.Jpad, a.Mpad, kk2, tapoff);
     a.stats = (stats && raw) ? stats->partials : nullptr;
+    a.bs_out = nullptr; a.bs_y = nullptr; a.bs_mean = nullptr;
     launch_dma(a, (int)s.total_q);
     if (a.stats) stats->splits = a.stats_splits;
     return true;
@@ -632,18 +724,21 @@ bool conv_forward_small_c(const float* x, const float* w, const float* bias, con
     tapoff[0] = 0;
     pack_weights(w, at, ws, 0, a.M, a.J, a.Jpad, a.Mpad, 1, tapoff);
     a.stats = (stats && raw) ? stats->partials : nullptr;
+    a.bs_out = nullptr; a.bs_y = nullptr; a.bs_mean = nullptr;
     launch_dma(a, (int)s.total_q);
     if (a.stats) stats->splits = a.stats_splits;
     return true;
 }
 
-bool conv_backward_data_dma(const float* w, const float* dy, float* dx, const ConvShape& s) {
+bool conv_backward_data_dma(const float* w, const float* dy, float* dx, const ConvShape& s, DxBnSums* bs) {
+    if (bs) bs->splits = 0;
     if (!dma_supported(s, s.Cg, s.Mg, (size_t)s.N * s.F * s.OHOW)) return false;
     const int kk2 = s.pointwise ? 1 : s.ksz * s.ksz;
     DmaArgs a;
     a.rowmode = 0;
     a.b_base = dy; a.out = dx; a.bias = nullptr; a.slopes = nullptr; a.s = s;
     a.mode = 1; a.act = BCNN_HIP_ACT_NONE; a.add_bias = 0; a.stats = nullptr; a.stats_splits = 0;
+    a.bs_out = nullptr; a.bs_y = nullptr; a.bs_mean = nullptr;
     a.M = s.Cg; a.J = s.Mg; a.Jpad = round_up(a.J, kDmaBK); a.Mpad = round_up(a.M, 128); a.kk2 = kk2;
     const size_t at_floats = (size_t)s.groups * kk2 * a.Jpad * a.Mpad;
     float* at = dma_scratch(at_floats);
@@ -657,7 +752,15 @@ bool conv_backward_data_dma(const float* w, const float* dy, float* dx, const Co
         ci.ih0 = 0; ci.iw0 = 0; ci.Hc = s.OH; ci.Wc = s.OW; ci.ntaps = 1; ci.tap0 = 0; ci.nkx = 1; ci.sgn = -1;
         tapoff[0] = 0;
         pack_weights(w, at, s, 1, a.M, a.J, a.Jpad, a.Mpad, kk2, tapoff);
+        // one group, stride 1 (the raw-view quirk then is the identity): the stored tile IS the gradient of the tensor
+        // the batch-norm node in front wrote
+        if (bs && bs->partials && pick_dma_tile(a, (int)s.total_q) == 4 && s.groups == 1 && s.HW == s.OHOW &&
+            s.total_q == s.total_p &&
+            bs->capacity >= (size_t)s.C * (size_t)ceil_div(s.total_q, 64) * 2) {
+            a.bs_out = bs->partials; a.bs_y = bs->y; a.bs_mean = bs->mean;
+        }
         launch_dma(a, (int)s.total_q);
+        if (a.bs_out) bs->splits = a.stats_splits;
         return true;
     }
     // stride-parity classes; the packed tap order is class-major

@@ -452,6 +452,7 @@ bcnn_status bcnn_compile_net(bcnn_net *net) {
     bcnn_link_conv_eltwise(net);
     bcnn_link_conv_maxpool(net);
     bcnn_link_conv_depthwise(net);
+    bcnn_link_batchnorm_conv(net);
     if (hc->fill_chunks_gpu) { /* the table of live fills follows the dead-fill marks */
         bcnn_hip_sync();
         bcnn_hip_free(hc->fill_chunks_gpu);

@@ -259,6 +259,8 @@ typedef struct bcnn_conv_param {
     int elt_node;      /* index of that eltwise node, -1: none */
     int pool_node;     /* index of the max-pooling node that is this node's only consumer and normalises this node's
                         * pre-normalisation output on the fly inside a forward pass (bcnn_link_conv_maxpool), -1: none */
+    int bnsums_node;   /* the stand-alone batch-norm node in front of this (1x1) node whose backward sums this node's
+                        * data-gradient kernel emits inside a backward pass (bcnn_link_batchnorm_conv), -1: none */
     int dw_node;       /* index of the depthwise node that is this node's only consumer and normalises this node's
                         * pre-normalisation output while staging it (bcnn_link_conv_depthwise), -1: none */
     int apply_skipped; /* this node left its batch-norm apply sweep to its consumer in the running forward pass */
@@ -298,6 +300,11 @@ typedef struct bcnn_batchnorm_param {
     float *x_norm_gpu;
     int dw_node;         /* the depthwise node that produces this node's input (see bcnn_depthwise_conv_param), -1: none */
     int dw_fused_bwd;    /* that node applies this node's backward to the gradient it consumes */
+    int sums_conv;       /* the 1x1 convolution node that is this node's only consumer: inside a backward pass its
+                          * data-gradient kernel emits the partial sums this node's backward starts with, -1: none */
+    float *bsums_gpu;    /* those partials (bcnn_hip_conv_bnsums_size floats) */
+    size_t bsums_floats;
+    int bsums_splits;    /* > 0: bsums_gpu holds the sums of the gradient written in the running backward pass */
     int input_kept;      /* the input tensor is not this node's output and has no other consumer: it IS the copy of the
                           * input the reference keeps in `workspace` (bcnn_batchnorm_layer.c:208) */
 #endif
@@ -388,6 +395,7 @@ void bcnn_link_depthwise_batchnorm(bcnn_net *net); /* bcnn_layers_hot.c; called 
 void bcnn_link_conv_eltwise(bcnn_net *net);        /* bcnn_layers_hot.c; called by bcnn_compile_net */
 void bcnn_link_conv_maxpool(bcnn_net *net);
 void bcnn_link_conv_depthwise(bcnn_net *net);
+void bcnn_link_batchnorm_conv(bcnn_net *net);
 void bcnn_materialize_data(bcnn_net *net, int tensor);      /* tensor < 0: every pending one */
 void bcnn_materialize_gradients(bcnn_net *net, int tensor); /* tensor < 0: every pending one */
 void bcnn_drop_pending_gradients(bcnn_net *net);

@@ -109,6 +109,7 @@ bcnn_status bcnn_add_convolutional_layer(bcnn_net *net, int num_filters, int siz
     param->elt_node = -1;
     param->pool_node = -1;
     param->dw_node = -1;
+    param->bnsums_node = -1;
     node.forward = bcnn_forward_conv_layer;
     node.backward = bcnn_backward_conv_layer;
     node.update = bcnn_update_conv_layer;
@@ -215,6 +216,23 @@ void bcnn_backward_conv_layer(bcnn_net *net, bcnn_node *node) {
                                         p->conv_workspace_gpu, hctx(net)->workspace_size, out->data_gpu,
                                         out->grad_data_gpu, (int)ep->activation, r->data_gpu, r->grad_data_gpu,
                                         (size_t)ep->min_dim[0] * out->h * out->w);
+        return;
+    }
+    if (hctx(net)->in_pass == 2 && p->bnsums_node >= 0 && io.x->grad_data_gpu) {
+        /* the stand-alone batch-norm node that runs next in this pass gets the partial sums of the gradient this node's
+         * data-gradient kernel writes, straight from that kernel's epilogue */
+        bcnn_node *bn = &net->nodes[p->bnsums_node];
+        bcnn_batchnorm_param *bp = (bcnn_batchnorm_param *)bn->param;
+        const bcnn_tensor *bx = &net->tensors[bn->src[0]];
+        bp->bsums_splits = bcnn_hip_conv_backward_bnsums(
+            io.x->data_gpu, io.w->data_gpu, io.b->data_gpu, io.y->data_gpu, io.y->grad_data_gpu, io.x->grad_data_gpu,
+            io.w->grad_data_gpu, io.b->grad_data_gpu, io.x->n, io.x->c, io.x->h, io.x->w, p->num, p->size, p->stride, p->pad,
+            p->num_groups, (int)p->activation, io.slopes ? io.slopes->data_gpu : NULL,
+            io.slopes ? io.slopes->grad_data_gpu : NULL, p->batch_norm, io.scales ? io.scales->data_gpu : NULL,
+            io.scales ? io.scales->grad_data_gpu : NULL, p->saved_mean.data_gpu, p->saved_variance.data_gpu,
+            p->saved_mean.grad_data_gpu, p->saved_variance.grad_data_gpu, p->x_norm_gpu, p->bn_workspace_gpu,
+            p->conv_workspace_gpu, hctx(net)->workspace_size, bx->data_gpu, bp->saved_mean.data_gpu, bp->bsums_gpu,
+            bp->bsums_floats);
         return;
     }
     bcnn_hip_conv_backward(io.x->data_gpu, io.w->data_gpu, io.b->data_gpu, io.y->data_gpu, io.y->grad_data_gpu,
@@ -390,6 +408,7 @@ bcnn_status bcnn_add_batchnorm_layer(bcnn_net *net, const char *src_id, const ch
     bcnn_batchnorm_param *param = (bcnn_batchnorm_param *)calloc(1, node.param_size);
     node.param = param;
     param->dw_node = -1;
+    param->sums_conv = -1;
     node.forward = bcnn_forward_batchnorm_layer;
     node.backward = bcnn_backward_batchnorm_layer;
     node.release_param = bcnn_release_param_batchnorm_layer;
@@ -440,12 +459,21 @@ void bcnn_backward_batchnorm_layer(bcnn_net *net, bcnn_node *node) {
     bcnn_tensor *scales = &net->tensors[node->src[3]], *biases = &net->tensors[node->src[4]];
     if (hctx(net)->in_pass == 2 && p->dw_fused_bwd && net->tensors[net->nodes[p->dw_node].src[0]].grad_data_gpu) {
         /* sums only: the depthwise node that runs next in this pass applies :292-296 inside its own kernel */
+        if (p->bsums_splits > 0) { /* and the 1x1 convolution that ran just before already left the partial sums */
+            const int splits = p->bsums_splits;
+            p->bsums_splits = 0;
+            bcnn_hip_batchnorm_backward_finalize(p->bsums_gpu, splits, scales->data_gpu, scales->grad_data_gpu,
+                                                 biases->grad_data_gpu, p->saved_variance.data_gpu,
+                                                 p->saved_mean.grad_data_gpu, p->saved_variance.grad_data_gpu, x->c);
+            return;
+        }
         bcnn_hip_batchnorm_backward_sums(y->grad_data_gpu, scales->data_gpu, scales->grad_data_gpu, biases->grad_data_gpu,
                                          p->saved_mean.data_gpu, p->saved_variance.data_gpu,
                                          p->saved_mean.grad_data_gpu, p->saved_variance.grad_data_gpu,
                                          batchnorm_kept_input(p, x), x->n, x->c, x->h * x->w);
         return;
     }
+    p->bsums_splits = 0; /* sums left by the consumer are used by the sums-only path above alone */
     /* VALID-mode backward would use the running statistics (reference :306-309); only TRAIN is meaningful */
     bcnn_hip_batchnorm_backward(y->grad_data_gpu, x->grad_data_gpu, NULL, BCNN_HIP_ACT_NONE, scales->data_gpu,
                                 scales->grad_data_gpu, biases->grad_data_gpu, p->saved_mean.data_gpu,
@@ -571,6 +599,46 @@ void bcnn_link_conv_depthwise(bcnn_net *net) {
             continue;
         cp->dw_node = d;
         dp->conv_node = d - 1;
+    }
+}
+
+/* Pairs a stand-alone batch-norm node whose backward is of the sums-only kind (dw_fused_bwd: the depthwise node in front of
+ * it applies the rest) with the 1x1 / stride 1 / one-group convolution node right behind it that is its only consumer
+ * (MobileNet: [depthwise] -> [batchnorm] -> [conv 1x1]): that node's data-gradient kernel then emits the sums. Call after
+ * bcnn_link_depthwise_batchnorm. */
+void bcnn_link_batchnorm_conv(bcnn_net *net) {
+    for (int i = 0; i < net->num_nodes; ++i) {
+        bcnn_node *nd = &net->nodes[i];
+        if (nd->type == BCNN_LAYER_CONV2D) ((bcnn_conv_param *)nd->param)->bnsums_node = -1;
+        else if (nd->type == BCNN_LAYER_BATCHNORM) {
+            ((bcnn_batchnorm_param *)nd->param)->sums_conv = -1;
+            ((bcnn_batchnorm_param *)nd->param)->bsums_splits = 0;
+        }
+    }
+    if (BCNN_EXP_ENV("BCNN_NO_NODE_FUSION") || BCNN_EXP_ENV("BCNN_NO_BN_CONV_FUSION")) return;
+    for (int c = 1; c < net->num_nodes; ++c) {
+        bcnn_node *cn = &net->nodes[c], *bn = &net->nodes[c - 1];
+        if (cn->type != BCNN_LAYER_CONV2D || bn->type != BCNN_LAYER_BATCHNORM || cn->src[0] != bn->dst[0]) continue;
+        bcnn_batchnorm_param *bp = (bcnn_batchnorm_param *)bn->param;
+        bcnn_conv_param *cp = (bcnn_conv_param *)cn->param;
+        if (!bp->dw_fused_bwd || cp->size != 1 || cp->stride != 1 || cp->pad != 0 || cp->num_groups != 1) continue;
+        const int t = bn->dst[0];
+        int writers = 0, consumers = 0;
+        for (int i = 0; i < net->num_nodes; ++i) {
+            for (int k = 0; k < net->nodes[i].num_dst; ++k) writers += net->nodes[i].dst[k] == t;
+            for (int k = 0; k < net->nodes[i].num_src; ++k) consumers += net->nodes[i].src[k] == t;
+        }
+        const bcnn_tensor *z = &net->tensors[t];
+        if (writers != 1 || consumers != 1 || !z->grad_data_gpu) continue;
+        const size_t need = bcnn_hip_conv_bnsums_size(z->n, z->c, z->h, z->w);
+        if (need > bp->bsums_floats) {
+            bcnn_hip_sync();
+            bcnn_hip_free(bp->bsums_gpu);
+            bp->bsums_gpu = bcnn_hip_malloc_f32(need);
+            bp->bsums_floats = need;
+        }
+        bp->sums_conv = c;
+        cp->bnsums_node = c - 1;
     }
 }
 
@@ -718,6 +786,7 @@ void bcnn_release_param_batchnorm_layer(bcnn_node *node) {
     bcnn_tensor_destroy(&p->saved_variance);
     bcnn_hip_free(p->workspace_gpu);
     bcnn_hip_free(p->x_norm_gpu);
+    bcnn_hip_free(p->bsums_gpu);
 }
 
 /* ================================================================================================

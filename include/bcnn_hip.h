@@ -226,6 +226,24 @@ void bcnn_hip_maxpool_forward(const float *x_d, float *y_d, int *indexes_d, int 
                               int out_h, int out_w, int size, int stride);
 void bcnn_hip_maxpool_backward(const float *dy_d, const int *indexes_d, float *dx_d, int n, int c,
                                int h, int w, int out_h, int out_w, int size, int stride, int overwrite);
+/* A 1x1 convolution node whose input is the output of a stand-alone batch-norm node (MobileNet: [batchnorm] -> [conv 1x1]).
+ * bcnn_hip_conv_backward_bnsums is bcnn_hip_conv_backward whose data-gradient kernel also emits, from the tile it stores,
+ * the per-channel partial sums the batch-norm node's backward starts with (S1 = sum dz, S2 = sum dz * (prev_y - prev_mean),
+ * bcnn_batchnorm_layer.c:263-281; prev_y_d = that node's INPUT, prev_mean_d its saved mean) into sums_d
+ * (bcnn_hip_conv_bnsums_size floats). Returns the number of partials per channel, 0 when this shape's kernel does not
+ * emit them (then run bcnn_hip_batchnorm_backward_sums). bcnn_hip_batchnorm_backward_finalize turns the partials into
+ * dbias / dscales (accumulated) and dmean / dvar (written), like the finalize step of bcnn_hip_batchnorm_backward_sums. */
+size_t bcnn_hip_conv_bnsums_size(int n, int c, int h, int w);
+int bcnn_hip_conv_backward_bnsums(const float *x_d, const float *w_d, const float *bias_d, const float *y_d, float *dy_d,
+                                  float *dx_d, float *dw_d, float *dbias_d, int n, int c, int h, int w, int f, int k,
+                                  int stride, int pad, int groups, int act, const float *slopes_d, float *dslopes_d,
+                                  int batch_norm, const float *scales_d, float *dscales_d, const float *saved_mean_d,
+                                  const float *saved_var_d, float *dmean_d, float *dvar_d, const float *x_norm_d,
+                                  const float *bn_workspace_d, float *workspace_d, size_t workspace_elems,
+                                  const float *prev_y_d, const float *prev_mean_d, float *sums_d, size_t sums_floats);
+void bcnn_hip_batchnorm_backward_finalize(const float *sums_d, int splits, const float *scales_d, float *dscales_d,
+                                          float *dbias_d, const float *saved_var_d, float *dmean_d, float *dvar_d, int c);
+
 /* The pooling node behind a convolution node with batch-norm (the ResNet stem), for an executor that runs whole passes:
  * bcnn_hip_maxpool_forward over act(batch-norm(x_d)) computed on the fly from the convolution node's pre-normalisation
  * output and saved statistics -- the values, scan order and indexes of bcnn_hip_batchnorm_apply followed by

@@ -102,7 +102,7 @@ def test_depthwise_batchnorm_backward_fusion_trains_bit_identically():
     """bcnn_link_depthwise_batchnorm (host/bcnn_layers_hot.c) lets a depthwise node and the batch-norm node behind it
     share work inside bcnn_forward / bcnn_backward. The experiment host runtime can switch the sharing off:
     BCNN_NO_NODE_FUSION=1 runs every worker on its own like the reference does, BCNN_NO_DW_STATS=1 only stops the
-    forward statistics hand-off. With the SAME batch statistics (hand-off off in both runs) the fused backward -- the
+    forward statistics hand-off. With the SAME batch statistics and gradient sums (hand-offs off in both runs) the fused backward -- the
     batch-norm backward applied on the fly inside the depthwise kernel, no copy of the batch-norm input, gradient tensors
     not written -- performs the separate workers' operations in their order, so three SGD steps of MobileNet-v1 (64 x 64
     input: planes from 32 x 32 down to 2 x 2) must leave bit-identical parameters. (With the hand-off on, the statistics
@@ -112,7 +112,9 @@ def test_depthwise_batchnorm_backward_fusion_trains_bit_identically():
     lib = os.path.join(ROOT, "bcnn_amd", "lib")
     exp = {"BCNN_LIB": os.path.join(lib, "libbcnn_exp.so"), "BCNN_HIP_LIB": os.path.join(lib, "libbcnn_hip_exp.so")}
     shas = []
-    for extra in ({"BCNN_NO_DW_STATS": "1"}, {"BCNN_NO_NODE_FUSION": "1"}):
+    # BCNN_NO_BN_CONV_FUSION: the batch-norm backward sums otherwise come from the 1x1 convolution's data-gradient epilogue
+    # (one partial per 64 pixels): the same sums in another order again (tests/test_bn_sums_from_conv.py pins that path)
+    for extra in ({"BCNN_NO_DW_STATS": "1", "BCNN_NO_BN_CONV_FUSION": "1"}, {"BCNN_NO_NODE_FUSION": "1"}):
         e = dict(os.environ); e.update(exp); e.update(extra)
         r = subprocess.run([sys.executable, "-c", _TRAIN_MB], cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
