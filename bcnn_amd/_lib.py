@@ -82,6 +82,8 @@ SIGNATURES = {
     "bcnn_hip_conv_forward_residual": (None, [vp, vp, vp] + [i] * 9 + [vp] * 7 + [sz, i, vp]),
     "bcnn_hip_conv_backward_residual": (None, [vp] * 7 + [i] * 9 + [vp] * 7 + [vp, sz, vp, vp, i, vp, vp, sz]),
     "bcnn_hip_batchnorm_apply": (None, [vp] * 6 + [i, i, i, i]),
+    "bcnn_hip_conv_prepack": (None, [vp, i, i]),
+    "bcnn_hip_conv_prepack_reset": (None, []),
     "bcnn_hip_maxpool_bn_fusable": (i, [i] * 9 + [vp]),
     "bcnn_hip_conv_forward_stats_only": (None, [vp, vp, vp] + [i] * 9 + [vp] * 6),
     "bcnn_hip_maxpool_forward_bn": (None, [vp, vp, vp] + [i] * 8 + [vp] * 4 + [i]),

@@ -2,6 +2,8 @@
 // implicit-GEMM kernels (conv_fwd.hip, conv_bwd.hip) with the batch-norm / activation kernels the way
 // bcnn_forward_conv_layer_cpu / bcnn_backward_conv_layer_cpu do (reference bcnn_conv_layer.c:367-587).
 #include "conv_common.h"
+#include <cstring>
+#include <vector>
 
 namespace bcnn_hip {
 void conv_forward_dispatch(const float* x, const float* w, const float* bias, const float* slopes, float* y,
@@ -100,11 +102,150 @@ static void conv_fwd_any(const float* x, const float* w, const float* bias, cons
     if (conv_forward_winograd(x, w, bias, slopes, y, s, act, raw, stats)) return;
     conv_forward_dispatch(x, w, bias, slopes, y, s, act, raw, stats);
 }
+
+// ---- weight packs made ahead of their use (bcnn_hip_conv_prepack) -------------------------------------------------
+struct PrepackEntry {
+    const float* w;
+    int kind, mode;
+    float* buf;
+    size_t cap, floats;
+    unsigned long long epoch;
+    bool fresh;
+};
+struct PrepackStore {
+    std::vector<PrepackEntry> entries;
+    unsigned long long epoch = 0;
+    int dev = -1;
+    void* table_dev[PREPACK_KINDS][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    size_t table_cap[PREPACK_KINDS][2] = {{0, 0}, {0, 0}};
+    std::vector<char> table_host[PREPACK_KINDS][2];
+};
+static thread_local PrepackStore g_prepack;
+
+float* prepack_take(const float* w, int kind, int mode, size_t floats) {
+    PrepackStore& st = g_prepack;
+    for (PrepackEntry& e : st.entries)
+        if (e.w == w && e.kind == kind && e.mode == mode && e.fresh && e.epoch == st.epoch && e.floats == floats) {
+            e.fresh = false;  // single use: a second call packs the (possibly rewritten) weights itself
+            return e.buf;
+        }
+    return nullptr;
+}
+
+static void prepack_free_all(PrepackStore& st) {
+    HIP_CHECK(hipDeviceSynchronize());
+    for (PrepackEntry& e : st.entries)
+        if (e.buf) HIP_CHECK(hipFree(e.buf));
+    st.entries.clear();
+    for (int k = 0; k < PREPACK_KINDS; ++k)
+        for (int m = 0; m < 2; ++m) {
+            if (st.table_dev[k][m]) HIP_CHECK(hipFree(st.table_dev[k][m]));
+            st.table_dev[k][m] = nullptr;
+            st.table_cap[k][m] = 0;
+            st.table_host[k][m].clear();
+        }
+}
+
+static PrepackEntry* prepack_entry(PrepackStore& st, const float* w, int kind, int mode, size_t floats) {
+    PrepackEntry* e = nullptr;
+    for (PrepackEntry& c : st.entries)
+        if (c.w == w && c.kind == kind && c.mode == mode) { e = &c; break; }
+    if (!e) {
+        st.entries.push_back(PrepackEntry{w, kind, mode, nullptr, 0, 0, 0, false});
+        e = &st.entries.back();
+    }
+    if (e->cap < floats) {
+        if (e->buf) {
+            HIP_CHECK(hipStreamSynchronize(current_stream()));
+            HIP_CHECK(hipFree(e->buf));
+        }
+        HIP_CHECK(hipMalloc((void**)&e->buf, floats * sizeof(float)));
+        e->cap = floats;
+    }
+    e->floats = floats;
+    e->epoch = st.epoch;
+    e->fresh = true;
+    return e;
+}
+
+// the job table of one (kind, mode) on the device; uploaded only when it differs from the one already there
+static const void* prepack_table(PrepackStore& st, int kind, int mode, const void* jobs, size_t bytes) {
+    std::vector<char>& host = st.table_host[kind][mode];
+    if (host.size() == bytes && memcmp(host.data(), jobs, bytes) == 0) return st.table_dev[kind][mode];
+    HIP_CHECK(hipStreamSynchronize(current_stream()));  // a launch still reading the old table
+    if (st.table_cap[kind][mode] < bytes) {
+        if (st.table_dev[kind][mode]) HIP_CHECK(hipFree(st.table_dev[kind][mode]));
+        HIP_CHECK(hipMalloc(&st.table_dev[kind][mode], bytes * 2));
+        st.table_cap[kind][mode] = bytes * 2;
+    }
+    HIP_CHECK(hipMemcpy(st.table_dev[kind][mode], jobs, bytes, hipMemcpyHostToDevice));
+    host.assign((const char*)jobs, (const char*)jobs + bytes);
+    return st.table_dev[kind][mode];
+}
 }  // namespace bcnn_hip
 
 using namespace bcnn_hip;
 
 extern "C" {
+
+void bcnn_hip_conv_prepack(const bcnn_hip_conv_desc* layers, int count, int data_gradient) {
+    PrepackStore& st = g_prepack;
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    if (st.dev != dev) {  // buffers of another device are left to that device's thread / context
+        if (st.dev >= 0) prepack_free_all(st);
+        st.dev = dev;
+    }
+    ++st.epoch;  // every copy made earlier and not used is stale now
+    const int mode = data_gradient ? 1 : 0;
+    std::vector<WinoPackJob> wj;
+    std::vector<IgemmPackJob> ij;
+    int wmax = 0, imax = 0;
+    for (int i = 0; i < count; ++i) {
+        const bcnn_hip_conv_desc& d = layers[i];
+        if (!d.w_d || d.groups <= 0 || d.n <= 0) continue;
+        const ConvShape s = make_conv_shape(d.n, d.c, d.h, d.w, d.f, d.k, d.stride, d.pad, d.groups);
+        if (s.total_q <= 0 || s.Mg == 0 || s.Cg == 0) continue;
+        // the order bcnn_hip_conv_forward / _backward try their kernels in (conv_fwd_any, conv_backward_impl): the kernels
+        // for few input channels (window, stem, direct, small-C dX) read the weights as they are
+        WinoPackJob w1;
+        IgemmPackJob i1;
+        memset(&w1, 0, sizeof(w1));  // padding bytes too: the tables are compared bytewise against the uploaded ones
+        memset(&i1, 0, sizeof(i1));
+        size_t floats = 0;
+        if (wino_fused_pack_plan(s, mode, &w1, &floats)) {
+            PrepackEntry* e = prepack_entry(st, d.w_d, PREPACK_WINO, mode, floats);
+            w1.w = d.w_d; w1.u = e->buf;
+            if (w1.blocks > wmax) wmax = w1.blocks;
+            wj.push_back(w1);
+        } else if (conv_winograd_unfused_takes(s)) {
+            continue;  // transforms its weights inside its own first kernel
+        } else if (mode == 1 && !s.pointwise && s.groups == 1 && s.K <= 32 && s.Mg >= 32) {
+            continue;  // conv_backward_data_small_c
+        } else if (dma_pack_plan(s, mode, &i1, &floats)) {
+            PrepackEntry* e = prepack_entry(st, d.w_d, PREPACK_IGEMM, mode, floats);
+            i1.w = d.w_d; i1.at = e->buf;
+            const int blocks = i1.gx * i1.gy * i1.gz;
+            if (blocks > imax) imax = blocks;
+            ij.push_back(i1);
+        }
+    }
+    if (!wj.empty()) {
+        const void* t = prepack_table(st, PREPACK_WINO, mode, wj.data(), wj.size() * sizeof(WinoPackJob));
+        wino_fused_pack_launch((const WinoPackJob*)t, (int)wj.size(), wmax);
+    }
+    if (!ij.empty()) {
+        const void* t = prepack_table(st, PREPACK_IGEMM, mode, ij.data(), ij.size() * sizeof(IgemmPackJob));
+        dma_pack_launch((const IgemmPackJob*)t, (int)ij.size(), imax);
+    }
+}
+
+void bcnn_hip_conv_prepack_reset(void) {
+    PrepackStore& st = g_prepack;
+    if (st.dev < 0) return;
+    prepack_free_all(st);
+    ++st.epoch;
+}
 
 size_t bcnn_hip_conv_workspace_size(int n, int c, int h, int w, int f, int k, int stride, int pad, int groups) {
     const ConvShape s = make_conv_shape(n, c, h, w, f, k, stride, pad, groups);

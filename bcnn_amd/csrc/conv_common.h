@@ -55,6 +55,36 @@ struct BnResidual {
     int act;           // the eltwise node's activation
 };
 
+// ---- weight packs made ahead of their use, for many layers in one launch (conv.hip: bcnn_hip_conv_prepack) -------
+// The convolution kernels read the filter bank re-arranged: G g G^T in [16][Jpad][Mpad] (fused Winograd), A^T in
+// [group][tap][Jpad][Mpad] (LDS-DMA GEMM). Stand-alone calls pack right before the kernel (one ~5 us launch per call);
+// a caller that knows all layers of a pass hands them over at its start and the packs of a kind become ONE launch.
+enum { PREPACK_WINO = 0, PREPACK_IGEMM = 1, PREPACK_KINDS = 2 };
+struct WinoPackJob {
+    const float* w;
+    float* u;
+    int F, C, dx_mode, Jpad, Mpad;
+    int blocks;  // of 256 threads
+};
+constexpr int kPackMaxTaps = 49;
+struct IgemmPackJob {
+    const float* w;
+    float* at;
+    int Mg, Cg, kk2, ksz;
+    int M, J, Jpad, Mpad;
+    int mode, groups;
+    int gx, gy, gz;  // block grid of this job: 64 m x 4 j per block, gz = groups * taps
+    unsigned char tapoff[kPackMaxTaps];  // kr*ksz + kc of packed tap index
+};
+// the pack of (w, kind, mode) made by the current prepack batch and not yet used, or nullptr (conv.hip)
+float* prepack_take(const float* w, int kind, int mode, size_t floats);
+// what the kernel a layer will run on needs packed; false: nothing (another kernel takes the layer)
+bool wino_fused_pack_plan(const ConvShape& s, int dx_mode, WinoPackJob* job, size_t* floats);  // conv_winograd_fused.hip
+bool dma_pack_plan(const ConvShape& s, int dx_mode, IgemmPackJob* job, size_t* floats);        // conv_igemm_dma.hip
+bool conv_winograd_unfused_takes(const ConvShape& s);                                          // conv_winograd.hip
+void wino_fused_pack_launch(const WinoPackJob* jobs_dev, int n, int max_blocks);
+void dma_pack_launch(const IgemmPackJob* jobs_dev, int n, int max_blocks);
+
 #ifdef __HIPCC__
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

@@ -505,20 +505,12 @@ __global__ __launch_bounds__(64 * WM * WN, ABL_LB) void conv_igemm_dma_kernel(co
 }
 
 // ---- weight re-pack: At[g][tap][j][m] = W[g*Mg + f][c][kr][kc] with (m, j) = (f, c) forward, (c, f) dX ----
-struct PackArgs {
-    const float* w;
-    float* at;
-    int Mg, Cg, kk2, ksz;
-    int M, J, Jpad, Mpad;
-    int mode, groups;
-    unsigned char tapoff[kDmaMaxTaps];  // kr*ksz + kc of packed tap index
-};
+static_assert(kPackMaxTaps == kDmaMaxTaps, "IgemmPackJob::tapoff holds one entry per tap");
 
-__global__ __launch_bounds__(256) void conv_pack_weights_kernel(const PackArgs a) {
-    // block: 64 m x 4 j of one (g, tap); m fastest so writes are coalesced
-    const int m = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int j = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int gt = blockIdx.z;
+// block b of a job's (gx, gy, gz) grid: 64 m x 4 j of one (g, tap); m fastest so writes are coalesced
+__device__ __forceinline__ void pack_weights_block(const IgemmPackJob& a, int bx, int by, int gt) {
+    const int m = bx * 64 + (threadIdx.x & 63);
+    const int j = by * 4 + (threadIdx.x >> 6);
     const int g = gt / a.kk2, t = gt - g * a.kk2;
     if (m >= a.Mpad || j >= a.Jpad) return;
     float v = 0.f;
@@ -529,7 +521,22 @@ __global__ __launch_bounds__(256) void conv_pack_weights_kernel(const PackArgs a
     a.at[((size_t)gt * a.Jpad + j) * a.Mpad + m] = v;
 }
 
+__global__ __launch_bounds__(256) void conv_pack_weights_kernel(const IgemmPackJob a) {
+    pack_weights_block(a, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// the packs of many layers in one launch (bcnn_hip_conv_prepack): blockIdx.y = job, blockIdx.x = its linear block
+__global__ __launch_bounds__(256) void conv_pack_weights_multi_kernel(const IgemmPackJob* __restrict__ jobs) {
+    const IgemmPackJob& a = jobs[blockIdx.y];
+    const int b = blockIdx.x;
+    if (b >= a.gx * a.gy * a.gz) return;
+    const int bx = b % a.gx, r = b / a.gx;
+    pack_weights_block(a, bx, r % a.gy, r / a.gy);
+}
+
 // ---- host side ------------------------------------------------------------------------------------------
+static int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
 struct DmaScratch {
     float* p = nullptr;
     size_t cap = 0;
@@ -550,8 +557,6 @@ static float* dma_scratch(size_t floats) {
     }
     return sc.p;
 }
-
-static int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 // Shapes the DMA kernel takes; everything else stays on conv_igemm.hip.
 static bool dma_supported(const ConvShape& s, int M, int J, size_t b_elems) {
@@ -614,14 +619,51 @@ static void launch_dma(DmaArgs& a, int max_cols) {
     }
 }
 
-static void pack_weights(const float* w, float* at, const ConvShape& s, int mode, int M, int J, int Jpad, int Mpad,
-                         int kk2, const unsigned char* tapoff) {
-    PackArgs p;
+static void fill_pack_job(IgemmPackJob& p, const float* w, float* at, const ConvShape& s, int mode, int M, int J, int Jpad,
+                          int Mpad, int kk2, const unsigned char* tapoff) {
     p.w = w; p.at = at; p.Mg = s.Mg; p.Cg = s.Cg; p.kk2 = kk2; p.ksz = s.ksz;
     p.M = M; p.J = J; p.Jpad = Jpad; p.Mpad = Mpad; p.mode = mode; p.groups = s.groups;
-    for (int t = 0; t < kk2; ++t) p.tapoff[t] = tapoff[t];
-    dim3 grid((unsigned)(Mpad / 64), (unsigned)ceil_div(Jpad, 4), (unsigned)(s.groups * kk2));
+    for (int t = 0; t < kPackMaxTaps; ++t) p.tapoff[t] = t < kk2 ? tapoff[t] : (unsigned char)0;
+    p.gx = Mpad / 64; p.gy = ceil_div(Jpad, 4); p.gz = s.groups * kk2;
+}
+
+static void pack_weights(const float* w, float* at, const ConvShape& s, int mode, int M, int J, int Jpad, int Mpad,
+                         int kk2, const unsigned char* tapoff) {
+    IgemmPackJob p;
+    fill_pack_job(p, w, at, s, mode, M, J, Jpad, Mpad, kk2, tapoff);
+    dim3 grid((unsigned)p.gx, (unsigned)p.gy, (unsigned)p.gz);
     conv_pack_weights_kernel<<<grid, 256, 0, current_stream()>>>(p);
+    KERNEL_CHECK();
+}
+
+// packed tap order of the data-gradient form: pointwise = the one tap; otherwise stride-parity classes, class-major
+static int dx_tap_order(const ConvShape& s, unsigned char* tapoff) {
+    if (s.pointwise) { tapoff[0] = 0; return 1; }
+    const int st = s.stride;
+    int n = 0;
+    for (int ra = 0; ra < st; ++ra)
+        for (int rb = 0; rb < st; ++rb)
+            for (int kr = ra; kr < s.ksz; kr += st)
+                for (int kc = rb; kc < s.ksz; kc += st) tapoff[n++] = (unsigned char)(kr * s.ksz + kc);
+    return n;
+}
+
+// bcnn_hip_conv_prepack: the A^T this layer's forward (dx_mode 0) / data-gradient (1) kernel will ask prepack_take for
+bool dma_pack_plan(const ConvShape& s, int dx_mode, IgemmPackJob* job, size_t* floats) {
+    const int M = dx_mode ? s.Cg : s.Mg, J = dx_mode ? s.Mg : s.Cg;
+    if (!dma_supported(s, M, J, dx_mode ? (size_t)s.N * s.F * s.OHOW : (size_t)s.N * s.C * s.HW)) return false;
+    const int kk2 = s.pointwise ? 1 : s.ksz * s.ksz;
+    const int Jpad = round_up(J, kDmaBK), Mpad = round_up(M, 128);
+    unsigned char tapoff[kDmaMaxTaps];
+    if (dx_mode) dx_tap_order(s, tapoff);
+    else for (int t = 0; t < kk2; ++t) tapoff[t] = (unsigned char)t;
+    fill_pack_job(*job, nullptr, nullptr, s, dx_mode, M, J, Jpad, Mpad, kk2, tapoff);
+    *floats = (size_t)s.groups * kk2 * Jpad * Mpad;
+    return true;
+}
+
+void dma_pack_launch(const IgemmPackJob* jobs_dev, int n, int max_blocks) {
+    conv_pack_weights_multi_kernel<<<dim3((unsigned)max_blocks, (unsigned)n), 256, 0, current_stream()>>>(jobs_dev);
     KERNEL_CHECK();
 }
 
@@ -639,7 +681,9 @@ bool conv_forward_dma(const float* x, const float* w, const float* bias, const f
     a.mode = 0; a.act = raw ? BCNN_HIP_ACT_NONE : act; a.add_bias = raw ? 0 : 1;
     a.M = s.Mg; a.J = s.Cg; a.Jpad = round_up(a.J, kDmaBK); a.Mpad = round_up(a.M, 128); a.kk2 = kk2;
     const size_t at_floats = (size_t)s.groups * kk2 * a.Jpad * a.Mpad;
-    float* at = dma_scratch(at_floats);
+    float* at = prepack_take(w, PREPACK_IGEMM, 0, at_floats);  // packed ahead by bcnn_hip_conv_prepack?
+    const bool packed = at != nullptr;
+    if (!packed) at = dma_scratch(at_floats);
     a.at = at; a.at_bytes = (unsigned)(at_floats * 4);
     a.b_bytes = (unsigned)((size_t)s.N * s.C * s.HW * 4);
     a.b_major_stride = s.pointwise ? s.OHOW : s.HW;
@@ -649,7 +693,7 @@ bool conv_forward_dma(const float* x, const float* w, const float* bias, const f
     unsigned char tapoff[kDmaMaxTaps];
     ci.nkx = s.pointwise ? 1 : s.ksz; ci.sgn = 1;
     for (int t = 0; t < kk2; ++t) tapoff[t] = (unsigned char)t;
-    pack_weights(w, at, s, 0, a.M, a.J, a.Jpad, a.Mpad, kk2, tapoff);
+    if (!packed) pack_weights(w, at, s, 0, a.M, a.J, a.Jpad, a.Mpad, kk2, tapoff);
     a.stats = (stats && raw) ? stats->partials : nullptr;
     a.bs_out = nullptr; a.bs_y = nullptr; a.bs_mean = nullptr;
     launch_dma(a, (int)s.total_q);
@@ -741,17 +785,19 @@ bool conv_backward_data_dma(const float* w, const float* dy, float* dx, const Co
     a.bs_out = nullptr; a.bs_y = nullptr; a.bs_mean = nullptr;
     a.M = s.Cg; a.J = s.Mg; a.Jpad = round_up(a.J, kDmaBK); a.Mpad = round_up(a.M, 128); a.kk2 = kk2;
     const size_t at_floats = (size_t)s.groups * kk2 * a.Jpad * a.Mpad;
-    float* at = dma_scratch(at_floats);
+    float* at = prepack_take(w, PREPACK_IGEMM, 1, at_floats);  // packed ahead by bcnn_hip_conv_prepack?
+    const bool packed = at != nullptr;
+    if (!packed) at = dma_scratch(at_floats);
     a.at = at; a.at_bytes = (unsigned)(at_floats * 4);
     a.b_bytes = (unsigned)((size_t)s.N * s.F * s.OHOW * 4);
     a.b_major_stride = s.OHOW;
     unsigned char tapoff[kDmaMaxTaps];
+    dx_tap_order(s, tapoff);
     if (s.pointwise) {
         a.nclass = 1;
         DmaClass& ci = a.cls[0];
         ci.ih0 = 0; ci.iw0 = 0; ci.Hc = s.OH; ci.Wc = s.OW; ci.ntaps = 1; ci.tap0 = 0; ci.nkx = 1; ci.sgn = -1;
-        tapoff[0] = 0;
-        pack_weights(w, at, s, 1, a.M, a.J, a.Jpad, a.Mpad, kk2, tapoff);
+        if (!packed) pack_weights(w, at, s, 1, a.M, a.J, a.Jpad, a.Mpad, kk2, tapoff);
         // one group, stride 1 (the raw-view quirk then is the identity): the stored tile IS the gradient of the tensor
         // the batch-norm node in front wrote
         if (bs && bs->partials && pick_dma_tile(a, (int)s.total_q) == 4 && s.groups == 1 && s.HW == s.OHOW &&
@@ -778,16 +824,13 @@ bool conv_backward_data_dma(const float* w, const float* dy, float* dx, const Co
             ci.ntaps = 0; ci.tap0 = tap0; ci.sgn = -1;
             ci.nkx = rb < s.ksz ? (s.ksz - rb + st - 1) / st : 0;  // kc = rb, rb + st, ... ; tap (i, j) <-> (kr/st, kc/st)
             for (int kr = ra; kr < s.ksz; kr += st)
-                for (int kc = rb; kc < s.ksz; kc += st) {
-                    tapoff[tap0 + ci.ntaps] = (unsigned char)(kr * s.ksz + kc);
-                    ++ci.ntaps;
-                }
+                for (int kc = rb; kc < s.ksz; kc += st) ++ci.ntaps;  // dx_tap_order lists them in this order
             tap0 += ci.ntaps;
             all[ncls].c = ci;
             all[ncls].cols = s.N * ci.Hc * ci.Wc;
             ++ncls;
         }
-    pack_weights(w, at, s, 1, a.M, a.J, a.Jpad, a.Mpad, kk2, tapoff);
+    if (!packed) pack_weights(w, at, s, 1, a.M, a.J, a.Jpad, a.Mpad, kk2, tapoff);
     for (int c0 = 0; c0 < ncls; c0 += kDmaMaxClasses) {
         int nc = 0, max_cols = 0;
         for (int c = c0; c < ncls && nc < kDmaMaxClasses; ++c, ++nc) {

@@ -357,6 +357,8 @@ static double wino_bytes(const ConvShape& s) {
 }
 
 // Returns false when the layer stays on the direct kernels.
+bool conv_winograd_unfused_takes(const ConvShape& s) { return wino_applicable(s) && wino_profitable(s); }
+
 bool conv_forward_winograd(const float* x, const float* w, const float* bias, const float* slopes, float* y,
                            const ConvShape& s, int act, int raw, ConvStats* stats) {
     if (!wino_applicable(s) || !wino_profitable(s)) return false;

@@ -791,9 +791,8 @@ __global__ __launch_bounds__(256) void wino_pack_bf16_kernel(const float* __rest
 
 // U[xi][j][m] = (G g G^T)[xi] packed [16][Jpad][Mpad] with zero padding.
 //   forward: m = f, j = c; dX: m = c, j = f and the filter rotated by 180 degrees
-__global__ __launch_bounds__(256) void wino_pack_weights_kernel(const float* __restrict__ w, float* __restrict__ u, int F,
-                                                                int C, int dx_mode, int Jpad, int Mpad) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void wino_pack_one(const float* __restrict__ w, float* __restrict__ u, int F, int C, int dx_mode,
+                                              int Jpad, int Mpad, int idx) {
     if (idx >= Jpad * Mpad) return;
     const int j = idx / Mpad, m = idx - j * Mpad;
     const int M = dx_mode ? C : F, J = dx_mode ? F : C;
@@ -828,6 +827,18 @@ __global__ __launch_bounds__(256) void wino_pack_weights_kernel(const float* __r
         dst[(size_t)(4 * r + 2) * plane] = 0.5f * (t[r][0] - t[r][1] + t[r][2]);
         dst[(size_t)(4 * r + 3) * plane] = t[r][2];
     }
+}
+
+__global__ __launch_bounds__(256) void wino_pack_weights_kernel(const float* __restrict__ w, float* __restrict__ u, int F,
+                                                                int C, int dx_mode, int Jpad, int Mpad) {
+    wino_pack_one(w, u, F, C, dx_mode, Jpad, Mpad, blockIdx.x * 256 + threadIdx.x);
+}
+
+// the transformed weights of many layers in one launch (bcnn_hip_conv_prepack): blockIdx.y = job
+__global__ __launch_bounds__(256) void wino_pack_weights_multi_kernel(const WinoPackJob* __restrict__ jobs) {
+    const WinoPackJob j = jobs[blockIdx.y];
+    if ((int)blockIdx.x >= j.blocks) return;
+    wino_pack_one(j.w, j.u, j.F, j.C, j.dx_mode, j.Jpad, j.Mpad, blockIdx.x * 256 + threadIdx.x);
 }
 
 // ---- host side ------------------------------------------------------------------------------------------
@@ -917,11 +928,14 @@ static void wino_fused_run(const float* src, const float* w, float* dst, const C
     if (!parts) {
         const size_t u_floats = (size_t)16 * a.Jpad * a.Mpad;
         a.upk_bytes = (unsigned)(u_floats * 4);
-        float* U = wf_scratch(u_floats);
+        float* U = prepack_take(w, PREPACK_WINO, dx_mode, u_floats);  // transformed ahead by bcnn_hip_conv_prepack?
+        if (!U) {
+            U = wf_scratch(u_floats);
+            wino_pack_weights_kernel<<<ceil_div((long long)a.Jpad * a.Mpad, 256), 256, 0, current_stream()>>>(w, U, s.F, s.C, dx_mode,
+                                                                                                            a.Jpad, a.Mpad);
+            KERNEL_CHECK();
+        }
         a.upk = U;
-        wino_pack_weights_kernel<<<ceil_div((long long)a.Jpad * a.Mpad, 256), 256, 0, current_stream()>>>(w, U, s.F, s.C, dx_mode,
-                                                                                                        a.Jpad, a.Mpad);
-        KERNEL_CHECK();
     }
     a.stats = (stats && stats->partials) ? stats->partials : nullptr;
     const int nblocks = a.tblocks * a.mblocks;
@@ -949,6 +963,25 @@ static void wino_fused_run(const float* src, const float* w, float* dst, const C
     else wino_fused_kernel<2, false><<<grid, 512, 0, current_stream()>>>(a);
     KERNEL_CHECK();
     if (stats) stats->splits = a.stats ? 2 * a.tblocks : 0;
+}
+
+// bcnn_hip_conv_prepack: the transformed weights this layer's forward (dx_mode 0) / data-gradient (1) kernel will ask
+// prepack_take for; false when the layer does not run on wino_fused_kernel
+bool wino_fused_pack_plan(const ConvShape& s, int dx_mode, WinoPackJob* job, size_t* floats) {
+    const int J = dx_mode ? s.F : s.C, M = dx_mode ? s.C : s.F;
+    if (!wino_fused_wanted(s, J, M) || wino_bf16_parts(J) != 0) return false;
+    job->w = nullptr; job->u = nullptr;
+    job->F = s.F; job->C = s.C; job->dx_mode = dx_mode;
+    job->Jpad = (J + WF_KC - 1) / WF_KC * WF_KC;
+    job->Mpad = (M + WF_BF - 1) / WF_BF * WF_BF;
+    job->blocks = (int)ceil_div((long long)job->Jpad * job->Mpad, 256);
+    *floats = (size_t)16 * job->Jpad * job->Mpad;
+    return true;
+}
+
+void wino_fused_pack_launch(const WinoPackJob* jobs_dev, int n, int max_blocks) {
+    wino_pack_weights_multi_kernel<<<dim3((unsigned)max_blocks, (unsigned)n), 256, 0, current_stream()>>>(jobs_dev);
+    KERNEL_CHECK();
 }
 
 static double wf_flops(const ConvShape& s) {

@@ -254,6 +254,7 @@ void bcnn_end_net(bcnn_net **pnet) {
     bcnn_net *net = *pnet;
     if (!net) return;
     bcnn_hip_sync();
+    bcnn_hip_conv_prepack_reset(); /* the packed copies of this net's filter banks */
     bcnn_hip_context *hc = hctx(net);
     if (hc->comm_active) bcnn_hip_comm_destroy();
     /* arena members do not own their device buffers */
@@ -517,6 +518,7 @@ void bcnn_forward(bcnn_net *net) {
         bcnn_hip_zero_chunks((const bcnn_hip_fill_chunk *)hc->fill_chunks_gpu, hc->num_fill_chunks);
     }
     bcnn_drop_pending_gradients(net);
+    bcnn_prepack_conv_weights(net, 0);
     hc->in_pass = 1;
     for (int i = 0; i < net->num_nodes; ++i) net->nodes[i].forward(net, &net->nodes[i]);
     hc->in_pass = 0;
@@ -541,6 +543,7 @@ void bcnn_backward(bcnn_net *net) {
     bcnn_hip_context *hc = hctx(net);
     size_t ready_from = hc->arena_size;
     if (hc->comm_active) hc->comm_lo = hc->comm_hi = hc->arena_size;
+    bcnn_prepack_conv_weights(net, 1);
     hc->in_pass = 2;
     for (int i = net->num_nodes - 1; i >= 0; --i) {
         net->nodes[i].backward(net, &net->nodes[i]);

@@ -399,6 +399,7 @@ void bcnn_link_batchnorm_conv(bcnn_net *net);
 void bcnn_materialize_data(bcnn_net *net, int tensor);      /* tensor < 0: every pending one */
 void bcnn_materialize_gradients(bcnn_net *net, int tensor); /* tensor < 0: every pending one */
 void bcnn_drop_pending_gradients(bcnn_net *net);
+void bcnn_prepack_conv_weights(bcnn_net *net, int data_gradient); /* bcnn_layers_hot.c */
 int bcnn_grad_sole_writer(bcnn_net *net, int tensor); /* 1: this gradient's zero fill was skipped, assign instead of += */
 void bcnn_node_sgd_step(bcnn_net *net, bcnn_tensor *weights, bcnn_tensor *biases);
 void bcnn_node_optim_step(bcnn_net *net, bcnn_tensor *weights, bcnn_tensor *biases, float **adam_m_gpu,

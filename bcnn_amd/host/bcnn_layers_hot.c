@@ -246,6 +246,28 @@ void bcnn_backward_conv_layer(bcnn_net *net, bcnn_node *node) {
                            p->conv_workspace_gpu, hctx(net)->workspace_size);
 }
 
+/* The filter banks of every convolution node re-arranged for its kernel in ONE launch per kind, at the start of a pass
+ * (the nodes' own calls would each pack right before their kernel: ~40 launches of ~5 us per ResNet-18 step).
+ * data_gradient = 0: forward forms; 1: data-gradient forms, of the nodes whose source carries a gradient. */
+void bcnn_prepack_conv_weights(bcnn_net *net, int data_gradient) {
+    enum { MAXL = 256 };
+    bcnn_hip_conv_desc d[MAXL];
+    int n = 0;
+    if (BCNN_EXP_ENV("BCNN_NO_PREPACK")) return; /* A/B switch of the experiment build: every node packs for itself */
+    for (int i = 0; i < net->num_nodes && n < MAXL; ++i) {
+        bcnn_node *node = &net->nodes[i];
+        if (node->type != BCNN_LAYER_CONV2D) continue;
+        const bcnn_conv_param *p = (const bcnn_conv_param *)node->param;
+        const bcnn_tensor *x = &net->tensors[node->src[0]], *w = &net->tensors[node->src[1]];
+        if (!w->data_gpu || (data_gradient && !x->grad_data_gpu)) continue;
+        d[n].w_d = w->data_gpu;
+        d[n].n = x->n; d[n].c = x->c; d[n].h = x->h; d[n].w = x->w;
+        d[n].f = p->num; d[n].k = p->size; d[n].stride = p->stride; d[n].pad = p->pad; d[n].groups = p->num_groups;
+        ++n;
+    }
+    if (n > 0) bcnn_hip_conv_prepack(d, n, data_gradient);
+}
+
 void bcnn_update_conv_layer(bcnn_net *net, bcnn_node *node) { /* reference bcnn_conv_layer.c:810-855 */
     bcnn_conv_param *p = (bcnn_conv_param *)node->param;
     bcnn_node_optim_step(net, &net->tensors[node->src[1]], &net->tensors[node->src[2]], &p->adam_m_gpu, &p->adam_v_gpu);

@@ -210,6 +210,22 @@ void bcnn_hip_conv_backward_residual(const float *x_d, const float *w_d, const f
 void bcnn_hip_batchnorm_apply(const float *x_d, float *y_d, const float *scales_d, const float *bias_d,
                               const float *saved_mean_d, const float *saved_var_d, int n, int c, int hw, int act);
 
+/* Weight packs of a whole pass in one launch, for an executor that knows its layers (bcnn_forward / bcnn_backward).
+ * The convolution kernels read the filter bank re-arranged (transformed G g G^T for the Winograd kernels, A^T per tap
+ * for the LDS-DMA GEMM); bcnn_hip_conv_forward / _backward make that copy right before their kernel, one small launch
+ * per call. bcnn_hip_conv_prepack makes the copies of `count` layers at once -- forward form (data_gradient = 0) or
+ * data-gradient form (1) -- into buffers the library keeps; the NEXT forward (resp. backward) call for each of these
+ * layers (same weight pointer and shape, this thread, this stream) uses its copy instead of packing again. A copy is
+ * used at most once, and a later bcnn_hip_conv_prepack call discards every unused copy, so the caller only has to leave
+ * the weights unwritten between the prepack call and the calls that consume it. Layers whose kernel needs no copy are
+ * skipped. bcnn_hip_conv_prepack_reset frees the buffers (synchronises the device). */
+typedef struct {
+    const float *w_d;
+    int n, c, h, w, f, k, stride, pad, groups;
+} bcnn_hip_conv_desc;
+void bcnn_hip_conv_prepack(const bcnn_hip_conv_desc *layers, int count, int data_gradient);
+void bcnn_hip_conv_prepack_reset(void);
+
 /* ---------------------------------------------------------------------------------------------
  * Pooling.  Replaces bcnn_forward/backward_maxpool_layer_gpu (bcnn_maxpool_layer.cu:28-166) and
  * bcnn_forward/backward_avgpool_layer_gpu (bcnn_avgpool_layer.cu:29-90); CPU semantics
