@@ -83,6 +83,9 @@ SIGNATURES = {
     "bcnn_hip_conv_backward_residual": (None, [vp] * 7 + [i] * 9 + [vp] * 7 + [vp, sz, vp, vp, i, vp, vp, sz]),
     "bcnn_hip_batchnorm_apply": (None, [vp] * 6 + [i, i, i, i]),
     "bcnn_hip_conv_prepack": (None, [vp, i, i]),
+    "bcnn_hip_depthwise_insums_size": (sz, [i] * 7),
+    "bcnn_hip_depthwise_backward_bnin_sums": (i, [vp] * 7 + [i] * 9 + [vp] * 5 + [vp] * 4 + [i] + [vp, sz]),
+    "bcnn_hip_conv_backward_presummed": (i, [vp] * 8 + [i] * 10 + [vp, vp, i] + [vp] * 8 + [vp, sz] + [vp, i] + [vp, vp, vp, sz]),
     "bcnn_hip_conv_prepack_reset": (None, []),
     "bcnn_hip_maxpool_bn_fusable": (i, [i] * 9 + [vp]),
     "bcnn_hip_conv_forward_stats_only": (None, [vp, vp, vp] + [i] * 9 + [vp] * 6),

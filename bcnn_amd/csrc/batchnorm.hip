@@ -467,6 +467,21 @@ void batchnorm_backward_impl(float* dy, float* dx, const float* y, int act, cons
                             fwd_bias);
     batchnorm_backward_apply(dy, dx, y, act, scales, saved_mean, saved_var, dmean, dvar, workspace, n, c, hw, fwd_bias);
 }
+// batchnorm_backward_impl whose sums a producer of dy already left as partials[(channel * splits + i) * 2 + {S1, S2}]
+// (the depthwise kernel that wrote dy: depthwise_lds.hip): finalize + the apply sweep, no read-only sweep
+void batchnorm_backward_presummed(float* dy, const float* y, int act, const float* scales, float* dscales, float* dbias,
+                                  const float* saved_mean, const float* saved_var, float* dmean, float* dvar,
+                                  const float* workspace, int n, int c, int hw, const float* fwd_bias, const float* sums,
+                                  int splits) {
+    const long long M = (long long)n * hw, total = M * c;
+    if (!total) return;
+    if (act == BCNN_HIP_ACT_NONE) fwd_bias = nullptr;
+    KTimer kt(K_BN_BWD, 0.0, 4.0 * ((act != BCNN_HIP_ACT_NONE && !fwd_bias) ? 4.0 : 3.0) * (double)total);
+    bn_bwd_finalize_wide_kernel<<<c, 1024, 0, current_stream()>>>(sums, c, splits, scales, saved_var, dbias, dscales, dmean,
+                                                                  dvar);
+    KERNEL_CHECK();
+    batchnorm_backward_apply(dy, nullptr, y, act, scales, saved_mean, saved_var, dmean, dvar, workspace, n, c, hw, fwd_bias);
+}
 // d(res)[i] += dout[i] * act'(out[i]) for the first `count` elements (the partial operand of the folded eltwise node)
 __global__ __launch_bounds__(256) void bn_residual_grad_kernel(const float* __restrict__ out, const float* __restrict__ dout,
                                                                float* __restrict__ dres, unsigned count, int act) {

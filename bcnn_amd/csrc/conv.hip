@@ -19,6 +19,10 @@ void batchnorm_backward_residual(const float* dout, const float* out, int act_re
 void batchnorm_backward_impl(float* dy, float* dx, const float* y, int act, const float* scales, float* dscales,
                              float* dbias, const float* saved_mean, const float* saved_var, float* dmean,
                              float* dvar, const float* workspace, int n, int c, int hw, const float* fwd_bias);
+void batchnorm_backward_presummed(float* dy, const float* y, int act, const float* scales, float* dscales, float* dbias,
+                                  const float* saved_mean, const float* saved_var, float* dmean, float* dvar,
+                                  const float* workspace, int n, int c, int hw, const float* fwd_bias, const float* sums,
+                                  int splits);  // batchnorm.hip
 float* reduce_scratch(size_t floats);                                                        // blas1.hip
 size_t conv_dw_workspace_floats(const ConvShape& s);
 bool conv_backward_weights(const float* x, const float* dy, float* dw, float* dbias, const ConvShape& s,
@@ -358,7 +362,8 @@ static void conv_backward_impl(const float* x, const float* w, const float* bias
                                const float* scales, float* dscales, const float* saved_mean,
                                const float* saved_var, float* dmean, float* dvar, const float* x_norm,
                                const float* bn_workspace, float* workspace, size_t workspace_elems,
-                               const ConvResidualBwd* rb, DxBnSums* bs = nullptr) {
+                               const ConvResidualBwd* rb, DxBnSums* bs = nullptr, const float* own_sums = nullptr,
+                               int own_splits = 0) {
     const ConvShape s = make_conv_shape(n, c, h, wd, f, k, stride, pad, groups);
     const size_t ysize = (size_t)n * f * s.OHOW;
     if (rb) {
@@ -374,8 +379,12 @@ static void conv_backward_impl(const float* x, const float* w, const float* bias
         }
         // `bias` lets the batch-norm backward recompute the forward output from bn_workspace (no read of y)
         (void)x_norm;
-        batchnorm_backward_impl(dy, nullptr, y, fused_act, scales, dscales, dbias, saved_mean, saved_var, dmean, dvar,
-                                bn_workspace, n, f, s.OHOW, bias);
+        if (own_sums && own_splits > 0 && fused_act == act && act_bwd_is_cheap(act))  // whoever wrote dy left the sums
+            batchnorm_backward_presummed(dy, y, act, scales, dscales, dbias, saved_mean, saved_var, dmean, dvar, bn_workspace, n,
+                                         f, s.OHOW, bias, own_sums, own_splits);
+        else
+            batchnorm_backward_impl(dy, nullptr, y, fused_act, scales, dscales, dbias, saved_mean, saved_var, dmean, dvar,
+                                    bn_workspace, n, f, s.OHOW, bias);
     } else {
         bcnn_hip_activation_backward(y, dy, ysize, act, slopes, dslopes, s.OHOW, f);
     }
@@ -453,6 +462,20 @@ int bcnn_hip_conv_backward_bnsums(const float* x, const float* w, const float* b
     conv_backward_impl(x, w, bias, y, dy, dx, dw, dbias, n, c, h, wd, f, k, stride, pad, groups, act, slopes, dslopes,
                        batch_norm, scales, dscales, saved_mean, saved_var, dmean, dvar, x_norm, bn_workspace, workspace,
                        workspace_elems, nullptr, (sums && prev_y && prev_mean) ? &bs : nullptr);
+    return bs.splits;
+}
+
+int bcnn_hip_conv_backward_presummed(const float* x, const float* w, const float* bias, const float* y, float* dy, float* dx,
+                                     float* dw, float* dbias, int n, int c, int h, int wd, int f, int k, int stride, int pad,
+                                     int groups, int act, const float* slopes, float* dslopes, int batch_norm,
+                                     const float* scales, float* dscales, const float* saved_mean, const float* saved_var,
+                                     float* dmean, float* dvar, const float* x_norm, const float* bn_workspace,
+                                     float* workspace, size_t workspace_elems, const float* own_sums, int own_splits,
+                                     const float* prev_y, const float* prev_mean, float* prev_sums, size_t prev_sums_floats) {
+    DxBnSums bs{prev_y, prev_mean, prev_sums, prev_sums_floats, 0};
+    conv_backward_impl(x, w, bias, y, dy, dx, dw, dbias, n, c, h, wd, f, k, stride, pad, groups, act, slopes, dslopes,
+                       batch_norm, scales, dscales, saved_mean, saved_var, dmean, dvar, x_norm, bn_workspace, workspace,
+                       workspace_elems, nullptr, (prev_sums && prev_y && prev_mean) ? &bs : nullptr, own_sums, own_splits);
     return bs.splits;
 }
 

@@ -147,6 +147,9 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
         }
     };
     auto dma_u = [&](int kc, int stage) {  // each wave brings in two positions: 2 x 8 rows of 64 floats
+#ifdef WF_ABL_NODMA
+        if (kc > 0) return;
+#endif
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int xi = 2 * wid + (q >> 1), r0 = (q & 1) * 4;
@@ -173,6 +176,15 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
             tt[3][j] = d[1][j] - d[3][j];
         }
         float* v = lds + stage * WF_STAGE + 16 * WF_KC * WF_BF + wid * WF_BT + lane;
+#ifdef WF_ABL_NOVWRITE
+        {
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sum += (tt[i][0] - tt[i][2]) + (tt[i][1] + tt[i][2]) * 2.f + (tt[i][2] - tt[i][1]) * 3.f + (tt[i][1] - tt[i][3]) * 5.f;
+            if (sum == 123.456f) v[0] = sum;
+            return;
+        }
+#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             v[(4 * i + 0) * WF_KC * WF_BT] = tt[i][0] - tt[i][2];
@@ -224,12 +236,16 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
 #ifdef WF_ABL_CLOCK
             if (kc == 3) WF_STAMP(41);
 #endif
-            if (kc + 2 < nchunks) load_patch(kc + 2);
+#endif
+            // the U slab first: it is what the barrier at the end of this chunk waits for -- the patch requests behind it
+            // (needed a whole chunk later) may still be in flight then (vmcnt retires in order)
+            if (kc + 1 < nchunks) dma_u(kc + 1, (kc & 1) ^ 1);
 #ifdef WF_ABL_CLOCK
             if (kc == 3) WF_STAMP(42);
 #endif
+#ifndef WF_ABL_NOXFORM
+            if (kc + 2 < nchunks) load_patch(kc + 2);
 #endif
-            if (kc + 1 < nchunks) dma_u(kc + 1, (kc & 1) ^ 1);
 #ifdef WF_ABL_CLOCK
             if (kc == 3) WF_STAMP(43);
 #endif
@@ -249,7 +265,11 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
 #pragma unroll
             for (int ks = 0; ks < WF_KC / 2; ++ks) {
                 const int fc = ks & 1, fn = fc ^ 1;
+#ifdef WF_ABL_NOLDSRD
+                if (false) {
+#else
                 if (ks + 1 < WF_KC / 2) {
+#endif
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         af[fn][j] = us[(j * WF_KC + 2 * ks + 2 + lhi) * WF_BF];
@@ -257,6 +277,12 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
                         bf[fn][j][1] = vs[(j * WF_KC + 2 * ks + 2 + lhi) * WF_BT + 32];
                     }
                 }
+#ifdef WF_ABL_NOLDSRD
+                if (ks + 1 < WF_KC / 2) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { af[fn][j] = af[fc][j] + 1.f; bf[fn][j][0] = bf[fc][j][0]; bf[fn][j][1] = bf[fc][j][1]; }
+                }
+#endif
                 __builtin_amdgcn_sched_barrier(0);
                 if (ks == 0 && first) {  // uniform
                     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -299,8 +325,14 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
             multiply(cur, early ? -1 : kc, kc == 0, kc);
             __builtin_amdgcn_sched_barrier(0);
             if (kc < 8) WF_STAMP(6 + 3 * kc);
+#ifndef WF_ABL_NOXFORM
+            if (kc + 2 < nchunks) dma_wait_n<8>(); else dma_wait();  // uniform; 8 = the loads of one load_patch
+#else
             dma_wait();
+#endif
+#ifndef WF_ABL_NOBAR
             __syncthreads();
+#endif
         }
 
         // ---- epilogue, with the next unit's chunk 0 started underneath it ---------------------------------

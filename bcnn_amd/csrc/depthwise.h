@@ -40,8 +40,11 @@ bool depthwise_forward_lds(const float* x, const float* w, const float* bias, fl
                            ConvStats* stats, const DwBnIn* in = nullptr);
 // g = dy * act'(y) (written back over dy when `write_back`), or with `bn` g = BNbackward(bn->dz) * act'(y) and dy is not
 // touched; dbias += sum g; dw += sum x * g; dx = (overwrite ? 0 : dx) + w * g
+// in_sums (with `in`, overwrite): the kernel also emits the backward sums of the producer's batch-norm over the dx it
+// writes -- partials[(channel * splits + i) * 2 + {S1, S2}], the layout bn_bwd_finalize consumes; out: splits (0: not emitted)
+size_t depthwise_lds_in_sums_floats(const DwShape& s);
 bool depthwise_backward_lds(const float* x, const float* w, const float* y, float* dy, float* dx, float* dw, float* dbias,
                             const DwShape& s, int act, int overwrite, int write_back, const DwBnBwd* bn,
-                            const DwBnIn* in = nullptr);
+                            const DwBnIn* in = nullptr, ConvStats* in_sums = nullptr);
 
 }  // namespace bcnn_hip

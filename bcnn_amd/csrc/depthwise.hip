@@ -654,6 +654,35 @@ void bcnn_hip_depthwise_backward_bn_bnin(const float* x_raw, const float* w, con
         dw_bnin_refused("bcnn_hip_depthwise_backward_bn_bnin");
 }
 
+size_t bcnn_hip_depthwise_insums_size(int n, int c, int h, int wd, int k, int stride, int pad) {
+    if (stride < 1 || k < 1) return 0;
+    DwShape s{n, c, h, wd, (h + 2 * pad - k) / stride + 1, (wd + 2 * pad - k) / stride + 1, k, stride, pad};
+    return depthwise_lds_in_sums_floats(s);
+}
+
+// bcnn_hip_depthwise_backward_bnin (bn_mean == NULL) / _bn_bnin whose kernel also leaves the backward sums of the PRODUCER's
+// batch-norm in in_sums; returns the partials per channel (0: not emitted -- dx accumulates, or the buffer is too small)
+int bcnn_hip_depthwise_backward_bnin_sums(const float* x_raw, const float* w, const float* y, float* dy, float* dx, float* dw,
+                                          float* dbias, int n, int c, int h, int wd, int k, int stride, int pad, int act,
+                                          int overwrite, const float* bn_mean, const float* bn_var, const float* bn_scales,
+                                          const float* bn_dmean, const float* bn_dvar, const float* in_mean,
+                                          const float* in_var, const float* in_scale, const float* in_bias, int in_act,
+                                          float* in_sums, size_t in_sums_floats) {
+    DwShape s{n, c, h, wd, (h + 2 * pad - k) / stride + 1, (wd + 2 * pad - k) / stride + 1, k, stride, pad};
+    const long long total_o = (long long)n * c * s.OH * s.OW;
+    if (total_o <= 0) return 0;
+    KTimer kt(K_DEPTHWISE_BWD, 4.0 * (double)total_o * k * k,
+              4.0 * ((bn_mean ? 2.0 : 3.0) * (double)total_o + (overwrite ? 2.0 : 3.0) * (double)n * c * h * wd));
+    DwBnBwd bn{dy, bn_mean, bn_var, bn_scales, bn_dmean, bn_dvar};
+    DwBnIn in{in_mean, in_var, in_scale, in_bias, in_act};
+    ConvStats st;
+    st.partials = in_sums; st.capacity = in_sums_floats; st.splits = 0;
+    if (!dx || !depthwise_backward_lds(x_raw, w, y, bn_mean ? nullptr : dy, dx, dw, dbias, s, act, overwrite,
+                                       /*write_back=*/bn_mean ? 0 : 1, bn_mean ? &bn : nullptr, &in, in_sums ? &st : nullptr))
+        dw_bnin_refused("bcnn_hip_depthwise_backward_bnin_sums");
+    return st.splits;
+}
+
 void bcnn_hip_depthwise_backward(const float* x, const float* w, const float* y, float* dy, float* dx,
                                  float* dw, float* dbias, int n, int c, int h, int wd, int k, int stride,
                                  int pad, int act, int overwrite) {

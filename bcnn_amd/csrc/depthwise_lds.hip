@@ -203,42 +203,57 @@ __device__ __forceinline__ float dwl_bnin_const(const DwBnIn& in, int c, int t) 
 
 // the same with act(bn(.)) of the producing convolution node applied to every element on its way into the image (the pad
 // cells keep their zeros: padding applies to the normalised tensor)
+// mbits (optional): bit i of it = the activation's derivative at the thread's i-th element is 1 (not 0) -- element
+// (tid + q * 256) * 4 + k <-> bit 4 q + k on the vector path, element tid + 256 i <-> bit i otherwise; meaningful for
+// activations whose derivative is 0 or 1 (none, ReLU)
 template <int NQ>
 __device__ __forceinline__ void dwl_scatter_bn(const float* g, int count, bool vec, bool rowvec, bool multi, const DwlImg& m,
-                                               const float4 (&v)[NQ], float* img, const float* wl, int act) {
+                                               const float4 (&v)[NQ], float* img, const float* wl, int act,
+                                               unsigned* mbits = nullptr) {
     int j, row;
     float dummy;
+    unsigned bits = 0u;
+    int bit = 0;
     auto one = [&](float x, int jj) -> float {
         const float* k = wl + jj * kConst + 16;
         const BnDiv rs{k[1], k[4]};
-        return bn_one(x, k[0], rs, k[2], k[3], 0, act, &dummy);
+        const float y = bn_one(x, k[0], rs, k[2], k[3], 0, act, &dummy);
+        if (mbits) bits |= (act_bwd_cheap(y, act, 0.f) != 0.f ? 1u : 0u) << bit;
+        return y;
     };
     if (vec) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int e = (threadIdx.x + q * 256) * 4;
             if (e >= count) continue;
+            bit = 4 * q;
             if (rowvec) {
                 const int slot = dwl_slot(m, e, multi, j, row);
-                *reinterpret_cast<float4*>(img + slot) = make_float4(one(v[q].x, j), one(v[q].y, j), one(v[q].z, j), one(v[q].w, j));
+                float4 o;
+                o.x = one(v[q].x, j); ++bit;
+                o.y = one(v[q].y, j); ++bit;
+                o.z = one(v[q].z, j); ++bit;
+                o.w = one(v[q].w, j);
+                *reinterpret_cast<float4*>(img + slot) = o;
             } else {
                 int slot = dwl_slot(m, e, multi, j, row);
                 int col = slot - ((j * m.RP + m.lr0 + row) * m.PW + 4);
-                img[slot] = one(v[q].x, j);
+                img[slot] = one(v[q].x, j); ++bit;
                 dwl_next(m, multi, slot, j, row, col);
-                img[slot] = one(v[q].y, j);
+                img[slot] = one(v[q].y, j); ++bit;
                 dwl_next(m, multi, slot, j, row, col);
-                img[slot] = one(v[q].z, j);
+                img[slot] = one(v[q].z, j); ++bit;
                 dwl_next(m, multi, slot, j, row, col);
                 img[slot] = one(v[q].w, j);
             }
         }
     } else {
-        for (int e = threadIdx.x; e < count; e += 256) {
+        for (int e = threadIdx.x; e < count; e += 256, ++bit) {
             const int slot = dwl_slot(m, e, multi, j, row);
             img[slot] = one(g[e], j);
         }
     }
+    if (mbits) *mbits = bits;
 }
 
 // contiguous LDS piece -> contiguous global piece
@@ -387,12 +402,13 @@ struct DwlBwdArgs {
     float* dy;        // read (no batch-norm), written back when write_back
     float* dx;
     float* partials;  // [C][splits][12]: nine taps, bias sum
+    float* in_sums;   // BNIN kernels, optional: [C][splits][2] backward sums of the producer's batch-norm (see the kernel's end)
     DwBnBwd bn;
     DwBnIn in;        // BNIN kernels: the producer's batch-norm, applied while staging x
     float fM, rfM;    // N * OH * OW as float (batch-norm) and its correctly rounded reciprocal
     int C, H, W, OH, OW, planes, act, overwrite, write_back, splits, RG;
     DwlGeom g;
-    DwlDiv w_magic, h_magic, ow_magic, oh_magic, rg_magic, rgx_magic, hw2_magic;
+    DwlDiv w_magic, h_magic, ow_magic, oh_magic, rg_magic, rgx_magic, hw2_magic, hw_magic;
     int RGX;          // stride 1: ceil(own rows / 4) of a full band; stride 2: unused
     int x_floats, g_floats;
 };
@@ -465,7 +481,8 @@ __global__ __launch_bounds__(256) void dwl_bwd_kernel(const DwlBwdArgs a) {
         wl[i] = v;
     }
     __syncthreads();
-    if (BNIN) dwl_scatter_bn<kMaxQ>(gx, xcount, xvec, xrowvec, multi, mx, xv, xl, wl, a.in.act);
+    unsigned in_pass_bits = 0u;  // BNIN with sums: which of this thread's staged elements the producer's activation passes
+    if (BNIN) dwl_scatter_bn<kMaxQ>(gx, xcount, xvec, xrowvec, multi, mx, xv, xl, wl, a.in.act, a.in_sums ? &in_pass_bits : nullptr);
     else dwl_scatter<kMaxQ>(gx, xcount, xvec, xrowvec, multi, mx, xv, xl);
     {
         // g = [batch-norm backward of dz] * act'(y), into the image and (own rows, no batch-norm) back over dy
@@ -554,9 +571,11 @@ __global__ __launch_bounds__(256) void dwl_bwd_kernel(const DwlBwdArgs a) {
                     for (int r = 0; r < VR; ++r) {
                         const int kh = i - r * S;
                         if (kh < 0 || kh > 2) continue;
-                        acc[kh * 3 + 0] += x0 * gvv[r];
-                        acc[kh * 3 + 1] += x1 * gvv[r];
-                        acc[kh * 3 + 2] += x2 * gvv[r];
+                        // fused multiply-add: these are partial sums in this kernel's own order (the reference's sum over
+                        // the batch is reproduced to 1e-4, not bit for bit) and the kernel is vector-ALU bound
+                        acc[kh * 3 + 0] = __fmaf_rn(x0, gvv[r], acc[kh * 3 + 0]);
+                        acc[kh * 3 + 1] = __fmaf_rn(x1, gvv[r], acc[kh * 3 + 1]);
+                        acc[kh * 3 + 2] = __fmaf_rn(x2, gvv[r], acc[kh * 3 + 2]);
                     }
                 }
             }
@@ -673,7 +692,104 @@ __global__ __launch_bounds__(256) void dwl_bwd_kernel(const DwlBwdArgs a) {
         }
     }
     __syncthreads();
-    dwl_copy_out(dl, gdx, dcount);
+    // whole planes with 16-byte pieces: the thread that staged elements 4 i .. 4 i + 3 also copies them out (below)
+    const bool sums_fused = BNIN && a.in_sums != nullptr && multi && xvec && dcount == xcount && a.H * a.W >= 4 &&
+                            ((reinterpret_cast<uintptr_t>(gdx) & 15) == 0);
+    if (!sums_fused) dwl_copy_out(dl, gdx, dcount);
+    // ---- the producer's batch-norm backward starts with S1 = sum g, S2 = sum g * (raw - mean) over (n, h, w) per channel,
+    //      g = dx * act'(y_in) (bcnn_batchnorm_layer.c:263-281 behind bcnn_backward_activation_cpu). dx is complete here,
+    //      raw is the piece this thread staged (still in its registers) and act'(y_in) in {0, 1} was noted while staging it,
+    //      so the sweep that would re-read both tensors for these sums is not needed. The kernel is vector-ALU bound:
+    //      g and g * (raw - mean) are formed once per element by the thread that staged it (dx piece and the dead g image
+    //      as LDS space), then summed per plane. One partial per tile and plane, like the weight gradient above. ----
+    if (BNIN && a.in_sums != nullptr) {
+        const int per = own * a.W;  // several planes per tile: whole planes, own == H
+        float* rl = gl;             // the host enables the sums only where the g image's space holds a dx piece
+        if (sums_fused) {
+#pragma unroll
+            for (int q = 0; q < kMaxQ; ++q) {
+                const int i = tid + q * 256;
+                if (i * 4 >= dcount) continue;
+                const float4 d = reinterpret_cast<const float4*>(dl)[i];
+                reinterpret_cast<float4*>(gdx)[i] = d;
+                const int j0 = (int)dwl_div((unsigned)(4 * i), a.hw_magic), j3 = (int)dwl_div((unsigned)(4 * i + 3), a.hw_magic);
+                const float m0 = wl[j0 * kConst + 16], m3 = wl[j3 * kConst + 16];
+                const int edge = (j0 + 1) * per - 4 * i;  // elements of the four that still belong to plane j0 (>= 1)
+                float4 g, t;
+                g.x = (in_pass_bits & (1u << (4 * q))) ? d.x : 0.f;
+                g.y = (in_pass_bits & (2u << (4 * q))) ? d.y : 0.f;
+                g.z = (in_pass_bits & (4u << (4 * q))) ? d.z : 0.f;
+                g.w = (in_pass_bits & (8u << (4 * q))) ? d.w : 0.f;
+                t.x = g.x * (xv[q].x - m0);
+                t.y = g.y * (xv[q].y - (edge > 1 ? m0 : m3));
+                t.z = g.z * (xv[q].z - (edge > 2 ? m0 : m3));
+                t.w = g.w * (xv[q].w - m3);
+                reinterpret_cast<float4*>(dl)[i] = g;
+                reinterpret_cast<float4*>(rl)[i] = t;
+            }
+        } else {
+            __syncthreads();  // the copy above has read every dx value
+            const int shift = (i0 - r0) * a.W;  // the staged piece starts one halo row above the own rows (not on the first band)
+            auto put = [&](int e, float r, unsigned pass) {
+                const int o = e - shift;
+                if (o < 0 || o >= dcount) return;
+                const int j = multi ? (int)dwl_div((unsigned)o, a.hw_magic) : 0;
+                const float g = pass ? dl[o] : 0.f;
+                dl[o] = g;
+                rl[o] = g * (r - wl[j * kConst + 16]);
+            };
+            if (xvec) {
+#pragma unroll
+                for (int q = 0; q < kMaxQ; ++q) {
+                    const int e = (tid + q * 256) * 4;
+                    if (e >= xcount) continue;
+                    put(e, xv[q].x, in_pass_bits & (1u << (4 * q)));
+                    put(e + 1, xv[q].y, in_pass_bits & (2u << (4 * q)));
+                    put(e + 2, xv[q].z, in_pass_bits & (4u << (4 * q)));
+                    put(e + 3, xv[q].w, in_pass_bits & (8u << (4 * q)));
+                }
+            } else {
+                int bit = 0;
+                for (int e = tid; e < xcount; e += 256, ++bit) put(e, gx[e], in_pass_bits & (1u << bit));
+            }
+        }
+        __syncthreads();
+        const bool rows = a.g.P >= 8;
+        const int jstep = multi ? (rows ? 16 : 4) : 1, jfirst = multi ? (rows ? wid * 4 + (lane >> 4) : wid) : 0;
+        const int ifirst = multi ? (rows ? (lane & 15) : lane) : tid, istep = multi ? (rows ? 16 : 64) : 256;
+        const int jend = (multi && rows) ? ((Pe + 15) & ~15) : Pe;
+        for (int j = jfirst; j < jend; j += jstep) {
+            float s1 = 0.f, s2 = 0.f;
+            if (j < Pe) {
+                const float* dj = dl + j * per;
+                const float* rj = rl + j * per;
+                for (int e = ifirst; e < per; e += istep) {
+                    s1 += dj[e];
+                    s2 += rj[e];
+                }
+            }
+            if (multi) {
+                s1 = rows ? row_sum_dpp(s1) : wave_sum_dpp(s1);
+                s2 = rows ? row_sum_dpp(s2) : wave_sum_dpp(s2);
+                if ((rows ? (lane & 15) == 0 : lane == 63) && j < Pe) {
+                    const int p = p0 + j, n = p / a.C, c = p - n * a.C;
+                    float* dst = a.in_sums + ((size_t)c * a.splits + n) * 2;
+                    dst[0] = s1;
+                    dst[1] = s2;
+                }
+            } else {
+                s1 = wave_sum_dpp(s1);
+                s2 = wave_sum_dpp(s2);
+                if (lane == 63) { red[wid][0] = s1; red[wid][1] = s2; }
+                __syncthreads();
+                if (tid < 2) {
+                    const int n = p0 / a.C, c = p0 - n * a.C;
+                    a.in_sums[((size_t)c * a.splits + (size_t)n * a.g.NB + band) * 2 + tid] =
+                        (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+                }
+            }
+        }
+    }
 }
 
 // dw[c][t] += sum over slots (double, fixed order); dbias[c] += the tenth column when `dbias`
@@ -773,9 +889,16 @@ bool depthwise_forward_lds(const float* x, const float* w, const float* bias, fl
     return true;
 }
 
+size_t depthwise_lds_in_sums_floats(const DwShape& s) {
+    if (!depthwise_lds_ok(s)) return 0;
+    const DwlGeom g = dwl_plan(s);
+    return (size_t)s.C * s.N * g.NB * 2;
+}
+
 bool depthwise_backward_lds(const float* x, const float* w, const float* y, float* dy, float* dx, float* dw, float* dbias,
                             const DwShape& s, int act, int overwrite, int write_back, const DwBnBwd* bn,
-                            const DwBnIn* in) {
+                            const DwBnIn* in, ConvStats* in_sums) {
+    if (in_sums) in_sums->splits = 0;
     if (!depthwise_lds_ok(s) || !act_bwd_is_cheap(act) || act == BCNN_HIP_ACT_PRELU || !dx) return false;
     if (in && (!in->mean || !act_is_cheap(in->act) || in->act == BCNN_HIP_ACT_PRELU)) return false;
     DwlBwdArgs a;
@@ -796,6 +919,7 @@ bool depthwise_backward_lds(const float* x, const float* w, const float* y, floa
     a.ow_magic = dwl_magic((unsigned)s.OW); a.oh_magic = dwl_magic((unsigned)s.OH);
     a.rg_magic = dwl_magic((unsigned)a.RG); a.rgx_magic = dwl_magic((unsigned)a.RGX);
     a.hw2_magic = dwl_magic((unsigned)((s.W + 1) >> 1));
+    a.hw_magic = dwl_magic((unsigned)(s.H * s.W));
     a.fM = (float)((long long)s.N * s.OH * s.OW);
     a.rfM = 1.0f / a.fM;  // host division: IEEE, round to nearest
     if (bn) a.bn = *bn;
@@ -803,6 +927,16 @@ bool depthwise_backward_lds(const float* x, const float* w, const float* y, floa
     const size_t lds = (size_t)(a.x_floats + a.g_floats + a.g.P * kConst) * sizeof(float);
     if (lds > 64 * 1024) return false;
     a.partials = reduce_scratch((size_t)s.C * a.splits * kPart);
+    a.in_sums = nullptr;
+    // the sums are of the COMPLETE gradient: only when this kernel is its sole writer
+    // (stride 1: the g image's LDS space then holds a copy of the tile's dx piece worth of the pre-normalisation values)
+    // and for producer activations whose derivative is 0 or 1 (noted as one bit per element while staging)
+    if (in && in_sums && in_sums->partials && overwrite && S == 1 && a.g_floats >= a.g.stage_floats &&
+        (in->act == BCNN_HIP_ACT_NONE || in->act == BCNN_HIP_ACT_RELU) &&
+        in_sums->capacity >= (size_t)s.C * a.splits * 2) {
+        a.in_sums = in_sums->partials;
+        in_sums->splits = a.splits;
+    }
     const unsigned tiles = (unsigned)ceil_div((long long)a.planes, a.g.P) * (unsigned)a.g.NB;
     hipStream_t st = current_stream();
     a.in = in ? *in : DwBnIn{nullptr, nullptr, nullptr, nullptr, 0};

@@ -264,6 +264,9 @@ typedef struct bcnn_conv_param {
     int dw_node;       /* index of the depthwise node that is this node's only consumer and normalises this node's
                         * pre-normalisation output while staging it (bcnn_link_conv_depthwise), -1: none */
     int apply_skipped; /* this node left its batch-norm apply sweep to its consumer in the running forward pass */
+    float *insums_gpu;   /* dw_node >= 0: partial backward sums of this node's batch-norm, left by that depthwise node's */
+    size_t insums_floats; /* backward kernel (bcnn_hip_depthwise_backward_bnin_sums) in the running backward pass */
+    int insums_splits;   /* > 0: insums_gpu holds them (partials per channel) */
     int data_pending;  /* the last forward pass did not write this node's output tensor (nobody inside a pass reads it):
                         * bcnn_materialize_data produces it from bn_workspace_gpu on demand */
 #endif

@@ -218,21 +218,27 @@ void bcnn_backward_conv_layer(bcnn_net *net, bcnn_node *node) {
                                         (size_t)ep->min_dim[0] * out->h * out->w);
         return;
     }
-    if (hctx(net)->in_pass == 2 && p->bnsums_node >= 0 && io.x->grad_data_gpu) {
-        /* the stand-alone batch-norm node that runs next in this pass gets the partial sums of the gradient this node's
-         * data-gradient kernel writes, straight from that kernel's epilogue */
-        bcnn_node *bn = &net->nodes[p->bnsums_node];
-        bcnn_batchnorm_param *bp = (bcnn_batchnorm_param *)bn->param;
-        const bcnn_tensor *bx = &net->tensors[bn->src[0]];
-        bp->bsums_splits = bcnn_hip_conv_backward_bnsums(
+    /* sums of this node's own batch-norm backward that the depthwise node behind it (which ran just before in this pass)
+     * left while writing this node's output gradient */
+    const int own_splits = hctx(net)->in_pass == 2 ? p->insums_splits : 0;
+    p->insums_splits = 0;
+    const int to_bn = hctx(net)->in_pass == 2 && p->bnsums_node >= 0 && io.x->grad_data_gpu;
+    if (to_bn || own_splits > 0) {
+        /* to_bn: the stand-alone batch-norm node that runs next in this pass gets the partial sums of the gradient this
+         * node's data-gradient kernel writes, straight from that kernel's epilogue */
+        bcnn_node *bn = to_bn ? &net->nodes[p->bnsums_node] : NULL;
+        bcnn_batchnorm_param *bp = bn ? (bcnn_batchnorm_param *)bn->param : NULL;
+        const int splits = bcnn_hip_conv_backward_presummed(
             io.x->data_gpu, io.w->data_gpu, io.b->data_gpu, io.y->data_gpu, io.y->grad_data_gpu, io.x->grad_data_gpu,
             io.w->grad_data_gpu, io.b->grad_data_gpu, io.x->n, io.x->c, io.x->h, io.x->w, p->num, p->size, p->stride, p->pad,
             p->num_groups, (int)p->activation, io.slopes ? io.slopes->data_gpu : NULL,
             io.slopes ? io.slopes->grad_data_gpu : NULL, p->batch_norm, io.scales ? io.scales->data_gpu : NULL,
             io.scales ? io.scales->grad_data_gpu : NULL, p->saved_mean.data_gpu, p->saved_variance.data_gpu,
             p->saved_mean.grad_data_gpu, p->saved_variance.grad_data_gpu, p->x_norm_gpu, p->bn_workspace_gpu,
-            p->conv_workspace_gpu, hctx(net)->workspace_size, bx->data_gpu, bp->saved_mean.data_gpu, bp->bsums_gpu,
-            bp->bsums_floats);
+            p->conv_workspace_gpu, hctx(net)->workspace_size, own_splits > 0 ? p->insums_gpu : NULL, own_splits,
+            bn ? net->tensors[bn->src[0]].data_gpu : NULL, bp ? bp->saved_mean.data_gpu : NULL, bp ? bp->bsums_gpu : NULL,
+            bp ? bp->bsums_floats : 0);
+        if (bp) bp->bsums_splits = splits;
         return;
     }
     bcnn_hip_conv_backward(io.x->data_gpu, io.w->data_gpu, io.b->data_gpu, io.y->data_gpu, io.y->grad_data_gpu,
@@ -278,6 +284,7 @@ void bcnn_release_param_conv_layer(bcnn_node *node) {
     bcnn_tensor_destroy(&p->saved_mean);
     bcnn_tensor_destroy(&p->saved_variance);
     bcnn_hip_free(p->bn_workspace_gpu);
+    bcnn_hip_free(p->insums_gpu);
     bcnn_hip_free(p->x_norm_gpu);
     bcnn_hip_free(p->adam_m_gpu);
     bcnn_hip_free(p->adam_v_gpu);
@@ -365,22 +372,24 @@ void bcnn_backward_depthwise_conv_layer(bcnn_net *net, bcnn_node *node) {
         bcnn_conv_param *cp = (bcnn_conv_param *)cn->param;
         const float *im = cp->saved_mean.data_gpu, *iv = cp->saved_variance.data_gpu;
         const float *is = net->tensors[cn->src[5]].data_gpu, *ib = net->tensors[cn->src[2]].data_gpu;
+        /* either way the kernel also leaves the sums the producer's batch-norm backward (which runs next) starts with */
+        const int want_sums = cp->insums_gpu != NULL && !BCNN_EXP_ENV("BCNN_NO_DW_INSUMS");
         if (p->bn_fused_bwd) {
             const bcnn_node *bn = &net->nodes[p->bn_node];
             const bcnn_batchnorm_param *bp = (const bcnn_batchnorm_param *)bn->param;
-            bcnn_hip_depthwise_backward_bn_bnin(cp->bn_workspace_gpu, w->data_gpu, y->data_gpu,
-                                                net->tensors[bn->dst[0]].grad_data_gpu, x->grad_data_gpu, w->grad_data_gpu,
-                                                b->grad_data_gpu, x->n, x->c, x->h, x->w, p->size, p->stride, p->pad,
-                                                (int)p->activation, bcnn_grad_sole_writer(net, node->src[0]),
-                                                bp->saved_mean.data_gpu, bp->saved_variance.data_gpu,
-                                                net->tensors[bn->src[3]].data_gpu, bp->saved_mean.grad_data_gpu,
-                                                bp->saved_variance.grad_data_gpu, im, iv, is, ib, (int)cp->activation);
+            cp->insums_splits = bcnn_hip_depthwise_backward_bnin_sums(
+                cp->bn_workspace_gpu, w->data_gpu, y->data_gpu, net->tensors[bn->dst[0]].grad_data_gpu, x->grad_data_gpu,
+                w->grad_data_gpu, b->grad_data_gpu, x->n, x->c, x->h, x->w, p->size, p->stride, p->pad, (int)p->activation,
+                bcnn_grad_sole_writer(net, node->src[0]), bp->saved_mean.data_gpu, bp->saved_variance.data_gpu,
+                net->tensors[bn->src[3]].data_gpu, bp->saved_mean.grad_data_gpu, bp->saved_variance.grad_data_gpu, im, iv, is,
+                ib, (int)cp->activation, want_sums ? cp->insums_gpu : NULL, want_sums ? cp->insums_floats : 0);
             p->grads_pending = 1;
         } else {
-            bcnn_hip_depthwise_backward_bnin(cp->bn_workspace_gpu, w->data_gpu, y->data_gpu, y->grad_data_gpu,
-                                             x->grad_data_gpu, w->grad_data_gpu, b->grad_data_gpu, x->n, x->c, x->h, x->w,
-                                             p->size, p->stride, p->pad, (int)p->activation,
-                                             bcnn_grad_sole_writer(net, node->src[0]), im, iv, is, ib, (int)cp->activation);
+            cp->insums_splits = bcnn_hip_depthwise_backward_bnin_sums(
+                cp->bn_workspace_gpu, w->data_gpu, y->data_gpu, y->grad_data_gpu, x->grad_data_gpu, w->grad_data_gpu,
+                b->grad_data_gpu, x->n, x->c, x->h, x->w, p->size, p->stride, p->pad, (int)p->activation,
+                bcnn_grad_sole_writer(net, node->src[0]), NULL, NULL, NULL, NULL, NULL, im, iv, is, ib, (int)cp->activation,
+                want_sums ? cp->insums_gpu : NULL, want_sums ? cp->insums_floats : 0);
         }
         return;
     }
@@ -594,7 +603,10 @@ void bcnn_link_conv_maxpool(bcnn_net *net) {
 void bcnn_link_conv_depthwise(bcnn_net *net) {
     for (int i = 0; i < net->num_nodes; ++i) {
         bcnn_node *nd = &net->nodes[i];
-        if (nd->type == BCNN_LAYER_CONV2D) ((bcnn_conv_param *)nd->param)->dw_node = -1;
+        if (nd->type == BCNN_LAYER_CONV2D) {
+            ((bcnn_conv_param *)nd->param)->dw_node = -1;
+            ((bcnn_conv_param *)nd->param)->insums_splits = 0;
+        }
         else if (nd->type == BCNN_LAYER_DEPTHWISE_CONV2D) {
             ((bcnn_depthwise_conv_param *)nd->param)->conv_node = -1;
             ((bcnn_depthwise_conv_param *)nd->param)->raw_input = 0;
@@ -621,6 +633,14 @@ void bcnn_link_conv_depthwise(bcnn_net *net) {
             continue;
         cp->dw_node = d;
         dp->conv_node = d - 1;
+        /* the depthwise node's backward kernel can leave the sums this node's batch-norm backward starts with */
+        const size_t need = bcnn_hip_depthwise_insums_size(x->n, x->c, x->h, x->w, dp->size, dp->stride, dp->pad);
+        if (need > cp->insums_floats) {
+            bcnn_hip_sync();
+            bcnn_hip_free(cp->insums_gpu);
+            cp->insums_gpu = bcnn_hip_malloc_f32(need);
+            cp->insums_floats = need;
+        }
     }
 }
 

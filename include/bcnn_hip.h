@@ -257,6 +257,30 @@ int bcnn_hip_conv_backward_bnsums(const float *x_d, const float *w_d, const floa
                                   const float *saved_var_d, float *dmean_d, float *dvar_d, const float *x_norm_d,
                                   const float *bn_workspace_d, float *workspace_d, size_t workspace_elems,
                                   const float *prev_y_d, const float *prev_mean_d, float *sums_d, size_t sums_floats);
+/* The other direction of the same idea, for a convolution node with batch-norm whose output feeds a depthwise node that
+ * reads its pre-normalisation tensor (bcnn_hip_depthwise_backward_bnin / _bn_bnin below): that depthwise kernel writes the
+ * gradient of the convolution node's OUTPUT and holds the pre-normalisation values it belongs to, so
+ * bcnn_hip_depthwise_backward_bnin_sums (bn_mean_d == NULL: no batch-norm node behind the depthwise node, dy_d is updated
+ * in place; else dy_d is that node's output gradient, read only) also leaves S1 = sum g, S2 = sum g * (raw - mean) with
+ * g = dx * act'(act(bn(raw))) per channel in in_sums_d (bcnn_hip_depthwise_insums_size floats) and returns the number of
+ * partials per channel (0: not emitted -- overwrite == 0, or the buffer is too small). bcnn_hip_conv_backward_presummed is
+ * bcnn_hip_conv_backward_bnsums (prev_* may be NULL) that takes those partials (own_sums_d, own_splits > 0) instead of
+ * sweeping (dy, pre-normalisation tensor) for them; with own_splits == 0 it is bcnn_hip_conv_backward_bnsums. */
+size_t bcnn_hip_depthwise_insums_size(int n, int c, int h, int w, int k, int stride, int pad);
+int bcnn_hip_depthwise_backward_bnin_sums(const float *x_raw_d, const float *w_d, const float *y_d, float *dy_d, float *dx_d,
+                                          float *dw_d, float *dbias_d, int n, int c, int h, int w, int k, int stride, int pad,
+                                          int act, int overwrite, const float *bn_mean_d, const float *bn_var_d,
+                                          const float *bn_scales_d, const float *bn_dmean_d, const float *bn_dvar_d,
+                                          const float *in_mean_d, const float *in_var_d, const float *in_scale_d,
+                                          const float *in_bias_d, int in_act, float *in_sums_d, size_t in_sums_floats);
+int bcnn_hip_conv_backward_presummed(const float *x_d, const float *w_d, const float *bias_d, const float *y_d, float *dy_d,
+                                     float *dx_d, float *dw_d, float *dbias_d, int n, int c, int h, int w, int f, int k,
+                                     int stride, int pad, int groups, int act, const float *slopes_d, float *dslopes_d,
+                                     int batch_norm, const float *scales_d, float *dscales_d, const float *saved_mean_d,
+                                     const float *saved_var_d, float *dmean_d, float *dvar_d, const float *x_norm_d,
+                                     const float *bn_workspace_d, float *workspace_d, size_t workspace_elems,
+                                     const float *own_sums_d, int own_splits, const float *prev_y_d,
+                                     const float *prev_mean_d, float *prev_sums_d, size_t prev_sums_floats);
 void bcnn_hip_batchnorm_backward_finalize(const float *sums_d, int splits, const float *scales_d, float *dscales_d,
                                           float *dbias_d, const float *saved_var_d, float *dmean_d, float *dvar_d, int c);
 

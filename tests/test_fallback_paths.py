@@ -114,7 +114,9 @@ def test_depthwise_batchnorm_backward_fusion_trains_bit_identically():
     shas = []
     # BCNN_NO_BN_CONV_FUSION: the batch-norm backward sums otherwise come from the 1x1 convolution's data-gradient epilogue
     # (one partial per 64 pixels): the same sums in another order again (tests/test_bn_sums_from_conv.py pins that path)
-    for extra in ({"BCNN_NO_DW_STATS": "1", "BCNN_NO_BN_CONV_FUSION": "1"}, {"BCNN_NO_NODE_FUSION": "1"}):
+    # BCNN_NO_DW_INSUMS: likewise the sums of a convolution node's batch-norm backward that the depthwise kernel behind it
+    # leaves (tests/test_dw_insums.py pins that path)
+    for extra in ({"BCNN_NO_DW_STATS": "1", "BCNN_NO_BN_CONV_FUSION": "1", "BCNN_NO_DW_INSUMS": "1"}, {"BCNN_NO_NODE_FUSION": "1"}):
         e = dict(os.environ); e.update(exp); e.update(extra)
         r = subprocess.run([sys.executable, "-c", _TRAIN_MB], cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
