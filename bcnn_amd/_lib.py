@@ -83,6 +83,10 @@ SIGNATURES = {
     "bcnn_hip_conv_backward_residual": (None, [vp] * 7 + [i] * 9 + [vp] * 7 + [vp, sz, vp, vp, i, vp, vp, sz]),
     "bcnn_hip_batchnorm_apply": (None, [vp] * 6 + [i, i, i, i]),
     "bcnn_hip_conv_prepack": (None, [vp, i, i]),
+    "bcnn_hip_maxpool_forward_bn_keep": (None, [vp, vp, vp] + [i] * 8 + [vp] * 4 + [i, vp]),
+    "bcnn_hip_maxpool_bn_backward_fusable": (i, [i] * 9 + [vp] * 4),
+    "bcnn_hip_maxpool_bn_backward": (None, [vp] * 5 + [i] * 8 + [vp] * 8 + [i]),
+    "bcnn_hip_conv_backward_bn_done": (None, [vp] * 5 + [i] * 9 + [vp, sz]),
     "bcnn_hip_depthwise_insums_size": (sz, [i] * 7),
     "bcnn_hip_depthwise_backward_bnin_sums": (i, [vp] * 7 + [i] * 9 + [vp] * 5 + [vp] * 4 + [i] + [vp, sz]),
     "bcnn_hip_conv_backward_presummed": (i, [vp] * 8 + [i] * 10 + [vp, vp, i] + [vp] * 8 + [vp, sz] + [vp, i] + [vp, vp, vp, sz]),

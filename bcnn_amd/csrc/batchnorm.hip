@@ -417,10 +417,11 @@ void bcnn_hip_batchnorm_forward_stats(const float* x, float* y, float* run_mean,
 
 namespace bcnn_hip {
 // S1 = sum g', S2 = sum g' (x - mean) per channel -> dbias, dscales, dmean, dvar (the first sweep of the backward pass)
-static void batchnorm_backward_sums(const float* dy, const float* y, int act, const float* scales, float* dscales,
-                                    float* dbias, const float* saved_mean, const float* saved_var, float* dmean,
-                                    float* dvar, const float* workspace, int n, int c, int hw, const float* fwd_bias,
-                                    const float* res = nullptr, unsigned res_count = 0) {
+// (also called by pool.hip: the stem's sums over the pooled tensors)
+void batchnorm_backward_sums(const float* dy, const float* y, int act, const float* scales, float* dscales,
+                             float* dbias, const float* saved_mean, const float* saved_var, float* dmean,
+                             float* dvar, const float* workspace, int n, int c, int hw, const float* fwd_bias,
+                             const float* res = nullptr, unsigned res_count = 0) {
     const long long M = (long long)n * hw;
     const int splits = chan_splits(c, M);
     float* part = reduce_scratch((size_t)c * splits * 2);

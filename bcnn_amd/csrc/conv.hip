@@ -363,7 +363,7 @@ static void conv_backward_impl(const float* x, const float* w, const float* bias
                                const float* saved_var, float* dmean, float* dvar, const float* x_norm,
                                const float* bn_workspace, float* workspace, size_t workspace_elems,
                                const ConvResidualBwd* rb, DxBnSums* bs = nullptr, const float* own_sums = nullptr,
-                               int own_splits = 0) {
+                               int own_splits = 0, bool bn_done = false) {
     const ConvShape s = make_conv_shape(n, c, h, wd, f, k, stride, pad, groups);
     const size_t ysize = (size_t)n * f * s.OHOW;
     if (rb) {
@@ -371,6 +371,8 @@ static void conv_backward_impl(const float* x, const float* w, const float* bias
         // in the two sweeps the latter takes alone
         batchnorm_backward_residual(rb->dout, rb->out, rb->act, rb->res, rb->dres, rb->res_count, dy, scales, dscales, dbias,
                                     bias, saved_mean, saved_var, dmean, dvar, bn_workspace, n, f, s.OHOW);
+    } else if (batch_norm && bn_done) {
+        // dy already is the gradient of the pre-normalisation output (bcnn_hip_maxpool_bn_backward wrote it)
     } else if (batch_norm) {
         int fused_act = act;
         if (act == BCNN_HIP_ACT_PRELU) {
@@ -463,6 +465,13 @@ int bcnn_hip_conv_backward_bnsums(const float* x, const float* w, const float* b
                        batch_norm, scales, dscales, saved_mean, saved_var, dmean, dvar, x_norm, bn_workspace, workspace,
                        workspace_elems, nullptr, (sums && prev_y && prev_mean) ? &bs : nullptr);
     return bs.splits;
+}
+
+void bcnn_hip_conv_backward_bn_done(const float* x, const float* w, float* dy, float* dx, float* dw, int n, int c, int h, int wd,
+                                    int f, int k, int stride, int pad, int groups, float* workspace, size_t workspace_elems) {
+    conv_backward_impl(x, w, nullptr, nullptr, dy, dx, dw, nullptr, n, c, h, wd, f, k, stride, pad, groups, BCNN_HIP_ACT_NONE,
+                       nullptr, nullptr, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, workspace,
+                       workspace_elems, nullptr, nullptr, nullptr, 0, /*bn_done=*/true);
 }
 
 int bcnn_hip_conv_backward_presummed(const float* x, const float* w, const float* bias, const float* y, float* dy, float* dx,

@@ -91,7 +91,8 @@ __global__ __launch_bounds__(256) void maxpool_fwd_s2_bn_kernel(const float* __r
                                                                 int* __restrict__ idx, int C, int H, int W, int OH, int OW,
                                                                 unsigned total_items, const float* __restrict__ mean,
                                                                 const float* __restrict__ var, const float* __restrict__ scale,
-                                                                const float* __restrict__ bias, int act) {
+                                                                const float* __restrict__ bias, int act,
+                                                                float* __restrict__ raw_at_max) {
     const unsigned t = blockIdx.x * 256u + threadIdx.x;
     if (t >= total_items) return;
     const unsigned ppr = (unsigned)(OW + 1) >> 1;       // output pairs per row
@@ -137,9 +138,13 @@ __global__ __launch_bounds__(256) void maxpool_fwd_s2_bn_kernel(const float* __r
         const unsigned out = (plane * (unsigned)OH + i0 + r) * (unsigned)OW + q * 2;
         y[out] = best[r][0];
         idx[out] = bi[r][0];
+        // the pre-normalisation value that won (this thread read its cache line a moment ago): what the backward pass needs
+        // of x at the only places where the pooled gradient lands (maxpool_bn_backward below)
+        if (raw_at_max) raw_at_max[out] = x[bi[r][0] >= 0 ? bi[r][0] : 0];
         if ((int)(q * 2 + 1) < OW) {
             y[out + 1] = best[r][1];
             idx[out + 1] = bi[r][1];
+            if (raw_at_max) raw_at_max[out + 1] = x[bi[r][1] >= 0 ? bi[r][1] : 0];
         }
     }
 }
@@ -307,6 +312,72 @@ __global__ __launch_bounds__(256) void maxpool_bwd_vec4_k3s2_pair_kernel(const f
     if (hit) *reinterpret_cast<float4*>(dx + s0) = v;
 }
 
+// The pair kernel for a pooling node behind a convolution node with batch-norm (the ResNet stem), with that node's
+// batch-norm backward apply step (bcnn_batchnorm_layer.c:292-296 behind the activation backward) on the four gradient
+// values while they are in registers: dx[s] = bn_bwd(sum of the pooled gradients that selected s) is written straight into
+// the convolution node's output-gradient tensor, which is then never written and re-read in its pooled-gradient form. The
+// coefficients (dmean, dvar) come from sums taken over the POOLED tensors (bcnn_hip_maxpool_bn_backward below).
+__global__ __launch_bounds__(256) void maxpool_bwd_pair_bn_kernel(const float* __restrict__ dy, const int* __restrict__ idx,
+                                                                  const float* __restrict__ raw, float* __restrict__ dx,
+                                                                  int C, int H, int W, int OH, int OW,
+                                                                  const float* __restrict__ mean, const float* __restrict__ var,
+                                                                  const float* __restrict__ scale, const float* __restrict__ bias,
+                                                                  const float* __restrict__ dmean, const float* __restrict__ dvar,
+                                                                  float fM, int act) {
+    const int W4 = W >> 2;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int plane = blockIdx.y;
+    const bool live = t < H * W4;
+    const int tt = live ? t : 0;
+    const int h = tt / W4, k = tt - h * W4, w0 = k * 4;
+    const int s0 = (plane * H + h) * W + w0;
+    const int i0 = h >= 2 ? (h - 1) >> 1 : 0;
+    int i1 = h >> 1; if (i1 > OH - 1) i1 = OH - 1;
+    const bool need_left = k > 0, fetch_left = need_left && (threadIdx.x & 63) == 0;
+    const float4 xv = *reinterpret_cast<const float4*>(raw + s0);
+    int id[2][3];
+    float g[2][3];
+    bool ok[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int i = i0 + a;
+        ok[a] = live && i <= i1;
+        const int o = (plane * OH + (i <= i1 ? i : i1)) * OW + 2 * k;
+        const int2 ip = *reinterpret_cast<const int2*>(idx + o);
+        const float2 gp = *reinterpret_cast<const float2*>(dy + o);
+        const int ie = idx[fetch_left ? o - 1 : o];
+        const float ge = dy[fetch_left ? o - 1 : o];
+        id[a][0] = __builtin_amdgcn_update_dpp(ie, ip.y, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+        g[a][0] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, ge), __builtin_bit_cast(int, gp.y),
+                                                                        0x138, 0xf, 0xf, false));
+        id[a][1] = ip.x; g[a][1] = gp.x;
+        id[a][2] = ip.y; g[a][2] = gp.y;
+    }
+    if (!live) return;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const unsigned d = (unsigned)(id[a][b] - s0);
+            if (ok[a] && (b > 0 || need_left) && d < 4u) {
+                const float gg = g[a][b];
+                if (d == 0) v.x += gg; else if (d == 1) v.y += gg; else if (d == 2) v.z += gg; else v.w += gg;
+            }
+        }
+    const int ch = plane % C;
+    const float m = mean[ch], sc = scale[ch], bb = bias[ch], vr = var[ch];
+    const BnDiv rs_fwd = bn_divisor(sqrtf(vr + 0.000001f)), rs = bn_divisor(sqrtf(vr + 0.00001f)), fMd = bn_divisor(fM);
+    const float dmm = __fdiv_rn(dmean[ch], fM), dv = dvar[ch];
+    float dummy;
+    float4 o;
+    o.x = bn_bwd_one(v.x, bn_one(xv.x, m, rs_fwd, sc, bb, 0, act, &dummy), xv.x, m, rs, sc, dmm, dv, fMd, act);
+    o.y = bn_bwd_one(v.y, bn_one(xv.y, m, rs_fwd, sc, bb, 0, act, &dummy), xv.y, m, rs, sc, dmm, dv, fMd, act);
+    o.z = bn_bwd_one(v.z, bn_one(xv.z, m, rs_fwd, sc, bb, 0, act, &dummy), xv.z, m, rs, sc, dmm, dv, fMd, act);
+    o.w = bn_bwd_one(v.w, bn_one(xv.w, m, rs_fwd, sc, bb, 0, act, &dummy), xv.w, m, rs, sc, dmm, dv, fMd, act);
+    *reinterpret_cast<float4*>(dx + s0) = o;
+}
+
 // Global average pooling: one wave64 per (n,c) plane, shuffle reduction, then / (H*W).
 __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                           int planes, int HW) {
@@ -330,6 +401,12 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restric
         dx[i] += dy[p] / (float)HW;  // dst.grad / (h*w), int divisor promoted (bcnn_avgpool_layer.c:118-120)
     }
 }
+
+// batchnorm.hip: sums + finalize of a batch-norm backward over (dy, x) with the forward output recomputed from x
+void batchnorm_backward_sums(const float* dy, const float* y, int act, const float* scales, float* dscales, float* dbias,
+                             const float* saved_mean, const float* saved_var, float* dmean, float* dvar,
+                             const float* workspace, int n, int c, int hw, const float* fwd_bias, const float* res,
+                             unsigned res_count);
 
 }  // namespace bcnn_hip
 
@@ -363,9 +440,9 @@ int bcnn_hip_maxpool_bn_fusable(int n, int c, int h, int w, int out_h, int out_w
            act != BCNN_HIP_ACT_PRELU;
 }
 
-void bcnn_hip_maxpool_forward_bn(const float* x, float* y, int* indexes, int n, int c, int h, int w, int out_h, int out_w,
-                                 int size, int stride, const float* scales, const float* bias, const float* mean,
-                                 const float* var, int act) {
+void bcnn_hip_maxpool_forward_bn_keep(const float* x, float* y, int* indexes, int n, int c, int h, int w, int out_h, int out_w,
+                                      int size, int stride, const float* scales, const float* bias, const float* mean,
+                                      const float* var, int act, float* raw_at_max) {
     const long long total = (long long)n * c * out_h * out_w;
     if (!total) return;
     if (!bcnn_hip_maxpool_bn_fusable(n, c, h, w, out_h, out_w, size, stride, act, x)) {
@@ -378,10 +455,53 @@ void bcnn_hip_maxpool_forward_bn(const float* x, float* y, int* indexes, int n, 
     const unsigned blocks = (unsigned)((items + 255) / 256);
     if (size == 2)
         maxpool_fwd_s2_bn_kernel<2, R><<<blocks, 256, 0, current_stream()>>>(x, y, indexes, c, h, w, out_h, out_w,
-                                                                             (unsigned)items, mean, var, scales, bias, act);
+                                                                             (unsigned)items, mean, var, scales, bias, act,
+                                                                             raw_at_max);
     else
         maxpool_fwd_s2_bn_kernel<3, R><<<blocks, 256, 0, current_stream()>>>(x, y, indexes, c, h, w, out_h, out_w,
-                                                                             (unsigned)items, mean, var, scales, bias, act);
+                                                                             (unsigned)items, mean, var, scales, bias, act,
+                                                                             raw_at_max);
+    KERNEL_CHECK();
+}
+
+void bcnn_hip_maxpool_forward_bn(const float* x, float* y, int* indexes, int n, int c, int h, int w, int out_h, int out_w,
+                                 int size, int stride, const float* scales, const float* bias, const float* mean,
+                                 const float* var, int act) {
+    bcnn_hip_maxpool_forward_bn_keep(x, y, indexes, n, c, h, w, out_h, out_w, size, stride, scales, bias, mean, var, act, nullptr);
+}
+
+int bcnn_hip_maxpool_bn_backward_fusable(int n, int c, int h, int w, int out_h, int out_w, int size, int stride, int act,
+                                         const float* raw, const float* dpool, const int* indexes, const float* dx) {
+    const uintptr_t p16 = reinterpret_cast<uintptr_t>(raw) | reinterpret_cast<uintptr_t>(dx);
+    const uintptr_t p8 = reinterpret_cast<uintptr_t>(dpool) | reinterpret_cast<uintptr_t>(indexes);
+    return size == 3 && stride == 2 && (w & 3) == 0 && out_w * 2 == w && out_h * out_w > 0 &&
+           (long long)n * c * h * w < 0x7fffffffLL && (long long)n * c <= 65535 && raw && dx && (p16 & 15) == 0 && (p8 & 7) == 0 &&
+           act_is_cheap(act) && act_bwd_is_cheap(act) && act != BCNN_HIP_ACT_PRELU;
+}
+
+void bcnn_hip_maxpool_bn_backward(const float* dpool, const int* indexes, const float* raw_at_max, const float* raw, float* dx,
+                                  int n, int c, int h, int w, int out_h, int out_w, int size, int stride, const float* scales,
+                                  float* dscales, const float* bias, float* dbias, const float* mean, const float* var,
+                                  float* dmean, float* dvar, int act) {
+    const long long total = (long long)n * c * h * w, ptotal = (long long)n * c * out_h * out_w;
+    if (!total) return;
+    if (!bcnn_hip_maxpool_bn_backward_fusable(n, c, h, w, out_h, out_w, size, stride, act, raw, dpool, indexes, dx) || !raw_at_max) {
+        fprintf(stderr, "[bcnn_hip] bcnn_hip_maxpool_bn_backward: not fusable (ask bcnn_hip_maxpool_bn_backward_fusable)\n");
+        exit(1);
+    }
+    // S1 = sum g act'(y), S2 = sum g act'(y) (x - mean) of the batch-norm backward: the gradient of the un-pooled tensor is
+    // zero except where a window's maximum sits, and there it is the sum of the pooled gradients that selected the place --
+    // so both sums are sums over the POOLED gradient against the pre-normalisation values that won (a quarter of the data;
+    // the divisor of dmean / M and of the dvar term stays the un-pooled element count)
+    {
+        KTimer kt(K_BN_BWD, 0.0, 4.0 * 2.0 * (double)ptotal);
+        batchnorm_backward_sums(dpool, nullptr, act, scales, dscales, dbias, mean, var, dmean, dvar, raw_at_max, n, c,
+                                out_h * out_w, act != BCNN_HIP_ACT_NONE ? bias : nullptr, nullptr, 0u);
+    }
+    KTimer kt(K_POOL, 0.0, 4.0 * (2.0 * (double)total + 2.0 * (double)ptotal));
+    dim3 grid((unsigned)ceil_div(h * (w / 4), 256), (unsigned)(n * c));
+    maxpool_bwd_pair_bn_kernel<<<grid, 256, 0, current_stream()>>>(dpool, indexes, raw, dx, c, h, w, out_h, out_w, mean, var, scales,
+                                                                   bias, dmean, dvar, (float)((long long)n * h * w), act);
     KERNEL_CHECK();
 }
 

@@ -264,6 +264,8 @@ typedef struct bcnn_conv_param {
     int dw_node;       /* index of the depthwise node that is this node's only consumer and normalises this node's
                         * pre-normalisation output while staging it (bcnn_link_conv_depthwise), -1: none */
     int apply_skipped; /* this node left its batch-norm apply sweep to its consumer in the running forward pass */
+    int pool_bwd_pending; /* pool_node >= 0, inside a backward pass: that node left its backward to this node's (one kernel
+                           * does the pooling backward and this node's batch-norm backward: bcnn_hip_maxpool_bn_backward) */
     float *insums_gpu;   /* dw_node >= 0: partial backward sums of this node's batch-norm, left by that depthwise node's */
     size_t insums_floats; /* backward kernel (bcnn_hip_depthwise_backward_bnin_sums) in the running backward pass */
     int insums_splits;   /* > 0: insums_gpu holds them (partials per channel) */
@@ -320,6 +322,9 @@ typedef struct bcnn_maxpool_param {
 #ifdef BCNN_USE_HIP
     int *indexes_gpu;
     int conv_node;  /* the convolution node whose batch-norm this node applies on the fly (see bcnn_conv_param), -1: none */
+    float *raw_at_max_gpu; /* conv_node >= 0: per pooled element the pre-normalisation value that won its window, kept by
+                            * the forward pass for bcnn_hip_maxpool_bn_backward (the output tensor's shape) */
+    int raw_fwd;    /* the running pass's forward took that route (raw_at_max_gpu is current) */
 #endif
 } bcnn_maxpool_param;
 

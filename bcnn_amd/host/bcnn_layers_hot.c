@@ -201,6 +201,22 @@ void bcnn_forward_conv_layer(bcnn_net *net, bcnn_node *node) {
 void bcnn_backward_conv_layer(bcnn_net *net, bcnn_node *node) {
     bcnn_conv_param *p = (bcnn_conv_param *)node->param;
     conv_io io = conv_tensors(net, node);
+    if (hctx(net)->in_pass == 2 && p->pool_bwd_pending) {
+        /* the max-pooling node (which ran just before in this pass) left its backward to this node */
+        bcnn_node *pn = &net->nodes[p->pool_node];
+        bcnn_maxpool_param *mp = (bcnn_maxpool_param *)pn->param;
+        const bcnn_tensor *py = &net->tensors[pn->dst[0]];
+        p->pool_bwd_pending = 0;
+        bcnn_hip_maxpool_bn_backward(py->grad_data_gpu, mp->indexes_gpu, mp->raw_at_max_gpu, p->bn_workspace_gpu,
+                                     io.y->grad_data_gpu, io.y->n, io.y->c, io.y->h, io.y->w, py->h, py->w, mp->size,
+                                     mp->stride, io.scales->data_gpu, io.scales->grad_data_gpu, io.b->data_gpu,
+                                     io.b->grad_data_gpu, p->saved_mean.data_gpu, p->saved_variance.data_gpu,
+                                     p->saved_mean.grad_data_gpu, p->saved_variance.grad_data_gpu, (int)p->activation);
+        bcnn_hip_conv_backward_bn_done(io.x->data_gpu, io.w->data_gpu, io.y->grad_data_gpu, io.x->grad_data_gpu,
+                                       io.w->grad_data_gpu, io.x->n, io.x->c, io.x->h, io.x->w, p->num, p->size, p->stride,
+                                       p->pad, p->num_groups, p->conv_workspace_gpu, hctx(net)->workspace_size);
+        return;
+    }
     if (hctx(net)->in_pass == 2 && p->elt_node >= 0 && ((bcnn_eltwise_param *)net->nodes[p->elt_node].param)->deferred) {
         /* the eltwise node (which ran just before in this pass) left its backward to this node's batch-norm sweeps */
         bcnn_node *en = &net->nodes[p->elt_node];
@@ -567,8 +583,10 @@ void bcnn_link_conv_maxpool(bcnn_net *net) {
         if (nd->type == BCNN_LAYER_CONV2D) {
             ((bcnn_conv_param *)nd->param)->pool_node = -1;
             ((bcnn_conv_param *)nd->param)->apply_skipped = 0;
+            ((bcnn_conv_param *)nd->param)->pool_bwd_pending = 0;
         } else if (nd->type == BCNN_LAYER_MAXPOOL) {
             ((bcnn_maxpool_param *)nd->param)->conv_node = -1;
+            ((bcnn_maxpool_param *)nd->param)->raw_fwd = 0;
         }
     }
     if (BCNN_EXP_ENV("BCNN_NO_NODE_FUSION") || net->mode != BCNN_MODE_TRAIN) return;
@@ -592,6 +610,7 @@ void bcnn_link_conv_maxpool(bcnn_net *net) {
             continue;
         cp->pool_node = m;
         mp->conv_node = m - 1;
+        if (!mp->raw_at_max_gpu) mp->raw_at_max_gpu = bcnn_hip_malloc_f32((size_t)bcnn_tensor_size(py));
     }
 }
 
@@ -871,15 +890,17 @@ bcnn_status bcnn_add_maxpool_layer(bcnn_net *net, int size, int stride, bcnn_pad
 void bcnn_forward_maxpool_layer(bcnn_net *net, bcnn_node *node) {
     bcnn_maxpool_param *p = (bcnn_maxpool_param *)node->param;
     bcnn_tensor *x = &net->tensors[node->src[0]], *y = &net->tensors[node->dst[0]];
+    p->raw_fwd = 0;
     if (hctx(net)->in_pass == 1 && p->conv_node >= 0) {
         bcnn_node *cn = &net->nodes[p->conv_node];
         bcnn_conv_param *cp = (bcnn_conv_param *)cn->param;
         if (cp->apply_skipped) { /* the convolution node before this one left its pre-normalisation output and statistics */
             cp->apply_skipped = 0;
-            bcnn_hip_maxpool_forward_bn(cp->bn_workspace_gpu, y->data_gpu, p->indexes_gpu, x->n, x->c, x->h, x->w, y->h, y->w,
-                                        p->size, p->stride, net->tensors[cn->src[5]].data_gpu,
-                                        net->tensors[cn->src[2]].data_gpu, cp->saved_mean.data_gpu,
-                                        cp->saved_variance.data_gpu, (int)cp->activation);
+            bcnn_hip_maxpool_forward_bn_keep(cp->bn_workspace_gpu, y->data_gpu, p->indexes_gpu, x->n, x->c, x->h, x->w, y->h,
+                                             y->w, p->size, p->stride, net->tensors[cn->src[5]].data_gpu,
+                                             net->tensors[cn->src[2]].data_gpu, cp->saved_mean.data_gpu,
+                                             cp->saved_variance.data_gpu, (int)cp->activation, p->raw_at_max_gpu);
+            p->raw_fwd = p->raw_at_max_gpu != NULL;
             return;
         }
     }
@@ -891,6 +912,17 @@ void bcnn_backward_maxpool_layer(bcnn_net *net, bcnn_node *node) {
     bcnn_maxpool_param *p = (bcnn_maxpool_param *)node->param;
     bcnn_tensor *x = &net->tensors[node->src[0]], *y = &net->tensors[node->dst[0]];
     if (!x->grad_data_gpu) return;
+    if (hctx(net)->in_pass == 2 && p->conv_node >= 0 && p->raw_fwd && !BCNN_EXP_ENV("BCNN_NO_POOL_BWD_FUSION") &&
+        bcnn_grad_sole_writer(net, node->src[0])) {
+        /* the convolution node that runs next in this pass: one kernel gathers this node's gradient and applies that node's
+         * batch-norm backward to it in registers; the sums it needs are taken over the pooled tensors */
+        bcnn_conv_param *cp = (bcnn_conv_param *)net->nodes[p->conv_node].param;
+        if (bcnn_hip_maxpool_bn_backward_fusable(x->n, x->c, x->h, x->w, y->h, y->w, p->size, p->stride, (int)cp->activation,
+                                                 cp->bn_workspace_gpu, y->grad_data_gpu, p->indexes_gpu, x->grad_data_gpu)) {
+            cp->pool_bwd_pending = 1;
+            return;
+        }
+    }
     bcnn_hip_maxpool_backward(y->grad_data_gpu, p->indexes_gpu, x->grad_data_gpu, x->n, x->c, x->h, x->w, y->h, y->w,
                               p->size, p->stride, bcnn_grad_sole_writer(net, node->src[0]));
 }
@@ -899,6 +931,7 @@ void bcnn_release_param_maxpool_layer(bcnn_node *node) {
     bcnn_maxpool_param *p = (bcnn_maxpool_param *)node->param;
     free(p->indexes);
     bcnn_hip_free(p->indexes_gpu);
+    bcnn_hip_free(p->raw_at_max_gpu);
 }
 
 bcnn_status bcnn_add_avgpool_layer(bcnn_net *net, const char *src_id, const char *dst_id) {

@@ -299,6 +299,30 @@ int bcnn_hip_maxpool_bn_fusable(int n, int c, int h, int w, int out_h, int out_w
 void bcnn_hip_maxpool_forward_bn(const float *x_d, float *y_d, int *indexes_d, int n, int c, int h, int w, int out_h,
                                  int out_w, int size, int stride, const float *scales_d, const float *bias_d,
                                  const float *saved_mean_d, const float *saved_var_d, int act);
+/* ... and its backward. bcnn_hip_maxpool_forward_bn_keep is bcnn_hip_maxpool_forward_bn that also keeps, per pooled
+ * element, the pre-normalisation value that won its window (raw_at_max_d, the pooled shape). With it
+ * bcnn_hip_maxpool_bn_backward does the pooling node's backward AND the convolution node's batch-norm backward in a sweep
+ * over the pooled tensors plus ONE sweep over the un-pooled ones: the sums S1, S2 of bcnn_batchnorm_layer.c:263-281 are
+ * taken over (dpool_d, raw_at_max_d) -- the un-pooled gradient is zero except at the winning places, where it is the sum
+ * of the pooled gradients that selected them -- into dscales_d / dbias_d (accumulated) and dmean_d / dvar_d (written),
+ * and one kernel then gathers each un-pooled gradient value like bcnn_hip_maxpool_backward (overwrite form) and applies
+ * :292-296 to it in registers, writing dx_d = the gradient of the convolution's PRE-NORMALISATION output (what
+ * bcnn_hip_conv_backward leaves in dy_d after its batch-norm step). bcnn_hip_conv_backward_bn_done is the rest of that
+ * node's backward: weight gradient and, if dx_d != NULL, data gradient from such a dy_d (no bias gradient: the bias of a
+ * batch-norm convolution is the batch-norm's). Ask bcnn_hip_maxpool_bn_backward_fusable (3x3 / stride 2, out_w == w / 2,
+ * cheap activation, aligned pointers; raw_d = the convolution's pre-normalisation output). */
+void bcnn_hip_maxpool_forward_bn_keep(const float *x_d, float *y_d, int *indexes_d, int n, int c, int h, int w, int out_h,
+                                      int out_w, int size, int stride, const float *scales_d, const float *bias_d,
+                                      const float *saved_mean_d, const float *saved_var_d, int act, float *raw_at_max_d);
+int bcnn_hip_maxpool_bn_backward_fusable(int n, int c, int h, int w, int out_h, int out_w, int size, int stride, int act,
+                                         const float *raw_d, const float *dpool_d, const int *indexes_d, const float *dx_d);
+void bcnn_hip_maxpool_bn_backward(const float *dpool_d, const int *indexes_d, const float *raw_at_max_d, const float *raw_d,
+                                  float *dx_d, int n, int c, int h, int w, int out_h, int out_w, int size, int stride,
+                                  const float *scales_d, float *dscales_d, const float *bias_d, float *dbias_d,
+                                  const float *saved_mean_d, const float *saved_var_d, float *dmean_d, float *dvar_d, int act);
+void bcnn_hip_conv_backward_bn_done(const float *x_d, const float *w_d, float *dy_d, float *dx_d, float *dw_d, int n, int c,
+                                    int h, int w, int f, int k, int stride, int pad, int groups, float *workspace_d,
+                                    size_t workspace_elems);
 void bcnn_hip_avgpool_forward(const float *x_d, float *y_d, int n, int c, int h, int w);
 void bcnn_hip_avgpool_backward(const float *dy_d, float *dx_d, int n, int c, int h, int w);
 

@@ -65,8 +65,11 @@ def test_experiment_host_runtime_with_every_gradient_fill_kept_trains_bit_identi
     # BCNN_NO_NODE_FUSION=1 on top: every worker runs alone, so the product run's convolution -> eltwise pairs (the add,
     # the activation and their backward riding on the convolution node's batch-norm sweeps, bcnn_link_conv_eltwise) are
     # pinned bit for bit against the separate workers as well
-    for env in ({}, {"BCNN_LIB": os.path.join(lib, "libbcnn_exp.so"), "BCNN_HIP_LIB": os.path.join(lib, "libbcnn_hip_exp.so"),
-                     "BCNN_KEEP_ALL_GRAD_FILLS": "1", "BCNN_NO_NODE_FUSION": "1"}):
+    # The stem's pooling backward folded into the convolution node's batch-norm backward takes that node's sums over the
+    # pooled tensors -- the same sums in another order (pinned by tests/test_pool_bn_backward.py) -- so the fused side of
+    # this bit-for-bit comparison runs without it (BCNN_NO_POOL_BWD_FUSION, experiment host runtime)
+    exp = {"BCNN_LIB": os.path.join(lib, "libbcnn_exp.so"), "BCNN_HIP_LIB": os.path.join(lib, "libbcnn_hip_exp.so")}
+    for env in (dict(exp, BCNN_NO_POOL_BWD_FUSION="1"), dict(exp, BCNN_KEEP_ALL_GRAD_FILLS="1", BCNN_NO_NODE_FUSION="1")):
         e = dict(os.environ); e.update(env)
         r = subprocess.run([sys.executable, "-c", _TRAIN], cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
