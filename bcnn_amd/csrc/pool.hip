@@ -104,21 +104,23 @@ __global__ __launch_bounds__(256) void maxpool_fwd_s2_bn_kernel(const float* __r
     const BnDiv rs = bn_divisor(sqrtf(var[ch] + 0.000001f));
     const int base = (int)plane * H * W;
     const int w0 = (int)q * 4;
-    float best[R][2];
+    float best[R][2], braw[R][2];
     int bi[R][2];
 #pragma unroll
-    for (int r = 0; r < R; ++r) { best[r][0] = best[r][1] = -FLT_MAX; bi[r][0] = bi[r][1] = -1; }
+    for (int r = 0; r < R; ++r) { best[r][0] = best[r][1] = -FLT_MAX; bi[r][0] = bi[r][1] = -1; braw[r][0] = braw[r][1] = 0.f; }
     float dummy;
     const bool tail = SIZE == 3 && w0 + 4 < W;
+    const bool keep = raw_at_max != nullptr;  // uniform
 #pragma unroll
     for (int rr = 0; rr < 2 * R + SIZE - 2; ++rr) {
         const int hh = (int)i0 * 2 + rr;
         if (hh >= H) continue;  // bottom padding: the row never wins
         const int rb = base + hh * W + w0;
         const float4 v4 = *reinterpret_cast<const float4*>(x + rb);
-        const float v[5] = {bn_one(v4.x, m, rs, sc, b, 0, act, &dummy), bn_one(v4.y, m, rs, sc, b, 0, act, &dummy),
-                            bn_one(v4.z, m, rs, sc, b, 0, act, &dummy), bn_one(v4.w, m, rs, sc, b, 0, act, &dummy),
-                            tail ? bn_one(x[rb + 4], m, rs, sc, b, 0, act, &dummy) : -FLT_MAX};
+        const float raw[5] = {v4.x, v4.y, v4.z, v4.w, tail ? x[rb + 4] : 0.f};
+        const float v[5] = {bn_one(raw[0], m, rs, sc, b, 0, act, &dummy), bn_one(raw[1], m, rs, sc, b, 0, act, &dummy),
+                            bn_one(raw[2], m, rs, sc, b, 0, act, &dummy), bn_one(raw[3], m, rs, sc, b, 0, act, &dummy),
+                            tail ? bn_one(raw[4], m, rs, sc, b, 0, act, &dummy) : -FLT_MAX};
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int k = rr - 2 * r;  // window row of output row i0 + r; ascending rr == ascending k: the scan order
@@ -128,7 +130,11 @@ __global__ __launch_bounds__(256) void maxpool_fwd_s2_bn_kernel(const float* __r
 #pragma unroll
                 for (int c = 0; c < SIZE; ++c) {
                     const float val = v[2 * o + c];
-                    if (val > best[r][o]) { best[r][o] = val; bi[r][o] = rb + 2 * o + c; }
+                    if (val > best[r][o]) {
+                        best[r][o] = val;
+                        bi[r][o] = rb + 2 * o + c;
+                        if (keep) braw[r][o] = raw[2 * o + c];
+                    }
                 }
         }
     }
@@ -138,13 +144,13 @@ __global__ __launch_bounds__(256) void maxpool_fwd_s2_bn_kernel(const float* __r
         const unsigned out = (plane * (unsigned)OH + i0 + r) * (unsigned)OW + q * 2;
         y[out] = best[r][0];
         idx[out] = bi[r][0];
-        // the pre-normalisation value that won (this thread read its cache line a moment ago): what the backward pass needs
-        // of x at the only places where the pooled gradient lands (maxpool_bn_backward below)
-        if (raw_at_max) raw_at_max[out] = x[bi[r][0] >= 0 ? bi[r][0] : 0];
+        // the pre-normalisation value that won: what the backward pass needs of x at the only places where the pooled
+        // gradient lands (bcnn_hip_maxpool_bn_backward)
+        if (keep) raw_at_max[out] = braw[r][0];
         if ((int)(q * 2 + 1) < OW) {
             y[out + 1] = best[r][1];
             idx[out + 1] = bi[r][1];
-            if (raw_at_max) raw_at_max[out + 1] = x[bi[r][1] >= 0 ? bi[r][1] : 0];
+            if (keep) raw_at_max[out + 1] = braw[r][1];
         }
     }
 }
