@@ -1221,20 +1221,34 @@ __global__ __launch_bounds__(512, 2) void wino_dw_fused_kernel(const WinoDwArgs 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[e][i][j][r] = 0.f;
 
+    // The vector ALU (transform) and the fp32 MFMAs do not overlap on a SIMD, but each SIMD hosts one wave of each half of
+    // the workgroup, and the halves transform at different times -- waves 0-3 at the head of a chunk, waves 4-7 between
+    // their second and third k-step -- so that while one wave waits for its loads, its LDS stores or the barrier, the other
+    // has MFMAs to issue (the arrangement of wino_fused_kernel). The items a wave transforms in chunk kc (for chunk kc + 1)
+    // were requested during chunk kc - 1, right after the previous transform freed the registers: a whole chunk of lead.
+    const bool early = wid < 4;
     if (nchunks > 0) {
         load_items();
         write_items(0);
+        if (nchunks > 1) {
+            advance();
+            load_items();
+        }
     }
     __syncthreads();
     for (int kc = 0; kc < nchunks; ++kc) {
         const int cur = kc & 1, nxt = cur ^ 1;
-        const bool more = kc + 1 < nchunks;
-        if (more) {
-            advance();
+        const bool more = kc + 1 < nchunks, more2 = kc + 2 < nchunks;
+        auto produce = [&]() {  // V / dM of chunk kc + 1 from the registers, then the requests of chunk kc + 2 into them
 #ifndef WD_ABL_NOXFORM
-            load_items();
+            if (more) write_items(nxt);
+            if (more2) {
+                advance();
+                load_items();
+            }
 #endif
-        }
+        };
+        if (early) produce();
         __builtin_amdgcn_sched_barrier(0);  // requests first, then the MFMAs they fly under
         const float* ms = lds + cur * 2 * WD_OP + (2 * wid) * 64 * WD_ROW + l31 * WD_ROW + lhi;
         const float* vs = ms + WD_OP;
@@ -1260,11 +1274,13 @@ __global__ __launch_bounds__(512, 2) void wino_dw_fused_kernel(const WinoDwArgs 
                         acc[e][i][j][0] += af[e][i] * bf[e][j];
 #endif
                     }
+            if (ks == WD_KT / 4 - 1 && !early) {  // uniform per wave
+                __builtin_amdgcn_sched_barrier(0);
+                produce();
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
-#ifndef WD_ABL_NOXFORM
-        if (more) write_items(nxt);
-#endif
         __syncthreads();
     }
     // ---- publish the partial block: [sp][ob][xi][f][c] -----------------------------------------------------
