@@ -353,7 +353,8 @@ void batchnorm_forward_impl(const float* x, float* y, float* run_mean, float* ru
     if (!total) return;
     const bool have_pre = pre && pre->splits > 0 && mode == BCNN_HIP_MODE_TRAIN;
     // read x twice (statistics, apply) + write y; one read less with fused statistics
-    KTimer kt(K_BN_FWD, 0.0, 4.0 * (have_pre ? 2.0 : 3.0) * (double)total);
+    // (stats_only: no apply sweep -- with fused statistics only the partials are read)
+    KTimer kt(K_BN_FWD, 0.0, 4.0 * ((have_pre ? 0.0 : 1.0) + (stats_only ? 0.0 : 2.0)) * (double)total);
     const int want_act = act;
     if (!act_is_cheap(act)) act = BCNN_HIP_ACT_NONE;  // tanh/softplus/logistic: separate pass below
     BnApplyArgs a;

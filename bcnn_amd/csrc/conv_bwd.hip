@@ -160,31 +160,34 @@ __global__ __launch_bounds__(256) void conv_dw_kernel(const ConvDwArgs a) {
 }
 
 // dW[g][f][k] += sum_p partials[p][g][f][k]; column K (if bias_col) goes to dbias[g*Mg + f].
-// 16 outputs x 16 interleaved sub-sums per workgroup, combined in a fixed order (deterministic): the split
-// counts run into the hundreds for small GEMMs, a single thread per output would be a serial latency chain.
+// OUTS outputs x (256 / OUTS) interleaved sub-sums per workgroup, combined in a fixed order (deterministic): the split
+// counts run into the hundreds for small GEMMs, a single thread per output would be a serial latency chain -- and with
+// ~1000 partials (the RGB layer of MobileNet: 864 outputs) even 16 sub-sums are one (79 us; 4 outputs x 64 sub-sums: 12 us).
+template <int OUTS>
 __global__ __launch_bounds__(256) void conv_dw_finalize_kernel(const float* __restrict__ partials, int nparts,
                                                                int groups, int Mg, int K, int MP, int NP,
                                                                int bias_col, float* __restrict__ dw,
                                                                float* __restrict__ dbias) {
-    __shared__ float red[16][17];
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    constexpr int SUBS = 256 / OUTS;
+    __shared__ float red[SUBS][OUTS + 1];
+    const int tx = threadIdx.x % OUTS, ty = threadIdx.x / OUTS;
     const int kcols = K + (bias_col ? 1 : 0);
     const long long total = (long long)groups * Mg * kcols;
-    const long long i = (long long)blockIdx.x * 16 + tx;
+    const long long i = (long long)blockIdx.x * OUTS + tx;
     int k = 0, f = 0, g = 0;
     float sum = 0.f;
     if (i < total) {
         k = (int)(i % kcols);
         const long long t = i / kcols;
         f = (int)(t % Mg); g = (int)(t / Mg);
-        for (int p = ty; p < nparts; p += 16) sum += partials[(((long long)p * groups + g) * MP + f) * NP + k];
+        for (int p = ty; p < nparts; p += SUBS) sum += partials[(((long long)p * groups + g) * MP + f) * NP + k];
     }
     red[ty][tx] = sum;
     __syncthreads();
     if (ty == 0 && i < total) {
         float tot = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) tot += red[r][tx];
+        for (int r = 0; r < SUBS; ++r) tot += red[r][tx];
         if (k < K) dw[((long long)g * Mg + f) * K + k] += tot;
         else dbias[g * Mg + f] += tot;
     }
@@ -241,9 +244,12 @@ bool conv_backward_weights(const float* x, const float* dy, float* dw, float* db
     else conv_dw_kernel<2, 2><<<grid, 256, 0, current_stream()>>>(a);
     KERNEL_CHECK();
     const long long total = (long long)s.groups * s.Mg * (s.K + p.bias_col);
-    conv_dw_finalize_kernel<<<(unsigned)((total + 15) / 16), 256, 0, current_stream()>>>(
-        workspace, p.qsplits * 4, s.groups, s.Mg, s.K, p.mtiles * p.TM * 32, p.ntiles * p.TN * 32, p.bias_col,
-        dw, dbias);
+    if (p.qsplits * 4 >= 256)
+        conv_dw_finalize_kernel<4><<<(unsigned)((total + 3) / 4), 256, 0, current_stream()>>>(
+            workspace, p.qsplits * 4, s.groups, s.Mg, s.K, p.mtiles * p.TM * 32, p.ntiles * p.TN * 32, p.bias_col, dw, dbias);
+    else
+        conv_dw_finalize_kernel<16><<<(unsigned)((total + 15) / 16), 256, 0, current_stream()>>>(
+            workspace, p.qsplits * 4, s.groups, s.Mg, s.K, p.mtiles * p.TM * 32, p.ntiles * p.TN * 32, p.bias_col, dw, dbias);
     KERNEL_CHECK();
     return p.bias_col != 0;
 }

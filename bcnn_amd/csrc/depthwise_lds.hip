@@ -704,7 +704,44 @@ __global__ __launch_bounds__(256) void dwl_bwd_kernel(const DwlBwdArgs a) {
     //      as LDS space), then summed per plane. One partial per tile and plane, like the weight gradient above. ----
     if (BNIN && a.in_sums != nullptr) {
         const int per = own * a.W;  // several planes per tile: whole planes, own == H
-        float* rl = gl;             // the host enables the sums only where the g image's space holds a dx piece
+        float* rl = gl;             // several planes per tile: the host made the g image's space hold a dx piece
+        if (!multi) {
+            // one plane per tile: every element a thread staged belongs to it -- sums in registers, no LDS arrays
+            const int shift = (i0 - r0) * a.W;  // the staged piece starts one halo row above the own rows (not on the first band)
+            const float mean = wl[16];
+            float s1 = 0.f, s2 = 0.f;
+            auto add = [&](int e, float r, unsigned pass) {
+                const int o = e - shift;
+                if (o < 0 || o >= dcount) return;
+                const float g = pass ? dl[o] : 0.f;
+                s1 += g;
+                s2 += g * (r - mean);
+            };
+            if (xvec) {
+#pragma unroll
+                for (int q = 0; q < kMaxQ; ++q) {
+                    const int e = (tid + q * 256) * 4;
+                    if (e >= xcount) continue;
+                    add(e, xv[q].x, in_pass_bits & (1u << (4 * q)));
+                    add(e + 1, xv[q].y, in_pass_bits & (2u << (4 * q)));
+                    add(e + 2, xv[q].z, in_pass_bits & (4u << (4 * q)));
+                    add(e + 3, xv[q].w, in_pass_bits & (8u << (4 * q)));
+                }
+            } else {
+                int bit = 0;
+                for (int e = tid; e < xcount; e += 256, ++bit) add(e, gx[e], in_pass_bits & (1u << bit));
+            }
+            s1 = wave_sum_dpp(s1);
+            s2 = wave_sum_dpp(s2);
+            if (lane == 63) { red[wid][0] = s1; red[wid][1] = s2; }
+            __syncthreads();
+            if (tid < 2) {
+                const int n = p0 / a.C, c = p0 - n * a.C;
+                a.in_sums[((size_t)c * a.splits + (size_t)n * a.g.NB + band) * 2 + tid] =
+                    (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+            }
+            return;
+        }
         if (sums_fused) {
 #pragma unroll
             for (int q = 0; q < kMaxQ; ++q) {
@@ -924,16 +961,21 @@ bool depthwise_backward_lds(const float* x, const float* w, const float* y, floa
     a.rfM = 1.0f / a.fM;  // host division: IEEE, round to nearest
     if (bn) a.bn = *bn;
     else a.bn = DwBnBwd{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    // the sums of the producer's batch-norm backward are of the COMPLETE gradient: only when this kernel is its sole writer;
+    // for producer activations whose derivative is 0 or 1 (noted as one bit per element while staging); tiles of several
+    // planes form g and g * (raw - mean) in LDS -- the dx piece and the g image's space, which then must hold a dx piece
+    bool want_sums = in && in_sums && in_sums->partials && overwrite &&
+                     (in->act == BCNN_HIP_ACT_NONE || in->act == BCNN_HIP_ACT_RELU) &&
+                     in_sums->capacity >= (size_t)s.C * a.splits * 2;
+    if (want_sums && a.g.P > 1 && a.g_floats < a.g.stage_floats) {  // stride 2
+        if ((size_t)(a.x_floats + a.g.stage_floats + a.g.P * kConst) * sizeof(float) <= 64 * 1024) a.g_floats = a.g.stage_floats;
+        else want_sums = false;
+    }
     const size_t lds = (size_t)(a.x_floats + a.g_floats + a.g.P * kConst) * sizeof(float);
     if (lds > 64 * 1024) return false;
     a.partials = reduce_scratch((size_t)s.C * a.splits * kPart);
     a.in_sums = nullptr;
-    // the sums are of the COMPLETE gradient: only when this kernel is its sole writer
-    // (stride 1: the g image's LDS space then holds a copy of the tile's dx piece worth of the pre-normalisation values)
-    // and for producer activations whose derivative is 0 or 1 (noted as one bit per element while staging)
-    if (in && in_sums && in_sums->partials && overwrite && S == 1 && a.g_floats >= a.g.stage_floats &&
-        (in->act == BCNN_HIP_ACT_NONE || in->act == BCNN_HIP_ACT_RELU) &&
-        in_sums->capacity >= (size_t)s.C * a.splits * 2) {
+    if (want_sums) {
         a.in_sums = in_sums->partials;
         in_sums->splits = a.splits;
     }

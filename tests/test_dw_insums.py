@@ -63,7 +63,7 @@ def test_sums_from_the_depthwise_kernel_match_the_separate_sweep(case):
             sums = torch.full((L.bcnn_hip_depthwise_insums_size(n, c, hw, hw, 3, st, 1),), float("nan"), device=DEV)
             splits = L.bcnn_hip_depthwise_backward_bnin_sums(P(raw), P(wd), P(y2), P(dy), P(dx), P(dwd), P(dbd), n, c, hw, hw,
                                                              3, st, 1, RELU, 1, *bnp, *inp, P(sums), sums.numel())
-            assert (splits > 0) == (st == 1) and sums.numel() >= c * splits * 2  # stride 2: the kernel leaves them to the sweep
+            assert splits > 0 and sums.numel() >= c * splits * 2
         elif with_bn:
             L.bcnn_hip_depthwise_backward_bn_bnin(P(raw), P(wd), P(y2), P(dy), P(dx), P(dwd), P(dbd), n, c, hw, hw, 3, st, 1,
                                                   RELU, 1, *bnp, *inp)
