@@ -45,6 +45,15 @@ struct WinoFusedArgs {
     int nunits;
     int act, add_bias;
     unsigned src_bytes, upk_bytes, dst_bytes, stats_bytes;
+    // K-split tail (EPI == 0 kernels, tail_units > 0): units [nunits, nunits + tail_units) -- the blocks a last, partly
+    // filled round would hold -- are not run as units. Their chunks, flattened (unit-major), are dealt out evenly:
+    // workgroup i takes chunks [i * tail_q, (i + 1) * tail_q) as one or two PIECES (a piece = a chunk range of one unit) and
+    // writes each piece's raw 2 x 2 outputs -- a partial sum over its input channels; the output transform is linear --
+    // to tail_scr[2 * i + piece][channel 0..63][tile 0..63][4]. wino_tail_fixup_kernel adds a unit's pieces in channel
+    // order and stores / takes the statistics like the epilogue here does.
+    float* tail_scr;
+    int tail_q, tail_units;
+    unsigned tail_scr_bytes;
 };
 
 #ifndef WF_LATE_AFTER
@@ -91,11 +100,15 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
     const rsrc_i4 rs_u = make_rsrc(a.upk, a.upk_bytes);
     const rsrc_i4 rs_dst = make_rsrc(a.dst, a.dst_bytes);
     const rsrc_i4 rs_stats = make_rsrc(a.stats, STATS ? a.stats_bytes : 0u);
+    const rsrc_i4 rs_scr = make_rsrc(a.tail_scr, EPI == 0 ? a.tail_scr_bytes : 0u);
     const unsigned lds0 = lds_offset(&lds[0]);
     // LDS-DMA of U: 4 rows (k) x 64 floats per instruction; lane -> row lane / 16, floats 4 * (lane % 16) ..
     const unsigned u_voff = ((unsigned)(lane >> 4) * (unsigned)a.Mpad + (unsigned)(lane & 15) * 4u) * 4u;
     const unsigned per_img = (unsigned)(a.TH * a.TW);
-    const int nchunks = a.Jpad / WF_KC;
+    const int nchunks_full = a.Jpad / WF_KC;
+    // the piece being multiplied (and, from the end of its K loop on, the NEXT one): a whole unit is the piece
+    // [0, nchunks_full) with slot < 0; kb = its first chunk, nchunks = how many
+    int kb = 0, nchunks = nchunks_full, slot = -1;
 
     // ---- per-unit state: of the unit being multiplied and, from the end of its K loop on, of the NEXT unit ----------
     // Work units: whole blocks first; when the last round would leave most CUs idle, its blocks are split into
@@ -138,7 +151,7 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
     // d[i][1..2] = the pair, d[i][0] = the neighbour column fetched by lanes 0 / 63 (0.0 in all other lanes)
     float d[4][4];
     auto load_patch = [&](int kc) {  // channel kc*8 + wid of this lane's tile
-        const unsigned soff = (unsigned)(kc * WF_KC + wid) * (unsigned)HW * 4u;
+        const unsigned soff = (unsigned)((kb + kc) * WF_KC + wid) * (unsigned)HW * 4u;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const buf_f32x2 m = buffer_load_f32x2(rs_src, (int)voff[i], (int)soff, 0);
@@ -153,7 +166,7 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int xi = 2 * wid + (q >> 1), r0 = (q & 1) * 4;
-            const unsigned soff = (((unsigned)xi * (unsigned)a.Jpad + (unsigned)(kc * WF_KC + r0)) * (unsigned)a.Mpad + (unsigned)m0) * 4u;
+            const unsigned soff = (((unsigned)xi * (unsigned)a.Jpad + (unsigned)((kb + kc) * WF_KC + r0)) * (unsigned)a.Mpad + (unsigned)m0) * 4u;
             dma_row_x4(rs_u, lds0 + (unsigned)((stage * WF_STAGE + (xi * WF_KC + r0) * WF_BF) * 4), u_voff, soff);
         }
     };
@@ -195,7 +208,25 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
     };
     // chunk 0 of a unit: U and V into stage 0, the patches of chunk 1 into the registers. The first unit's is issued
     // here, every later unit's during the previous unit's epilogue (which keeps its S in stage 1 only).
-    auto start_unit = [&](int unit) {
+    // this workgroup's work list: its whole units, then (K-split tail) one or two pieces
+    const int nreg = (int)blockIdx.x < a.nunits ? (a.nunits - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    int npieces = 0, pa_unit = 0, pa_k0 = 0, pa_n = 0, pb_n = 0;
+    if (EPI == 0 && a.tail_units > 0) {
+        const int c0 = (int)blockIdx.x * a.tail_q, c1 = min(c0 + a.tail_q, a.tail_units * nchunks_full);
+        if (c0 < c1) {
+            pa_unit = a.nunits + c0 / nchunks_full;
+            pa_k0 = c0 % nchunks_full;
+            pa_n = min(c1 - c0, nchunks_full - pa_k0);
+            pb_n = (c1 - c0) - pa_n;  // > 0: the range runs on into the next unit
+            npieces = pb_n > 0 ? 2 : 1;
+        }
+    }
+    const int nitems = nreg + npieces;
+    auto start_unit = [&](int it) {  // item `it` of the list becomes the piece being loaded
+        int unit;
+        if (it < nreg) { unit = (int)blockIdx.x + it * (int)gridDim.x; kb = 0; nchunks = nchunks_full; slot = -1; }
+        else if (it == nreg) { unit = pa_unit; kb = pa_k0; nchunks = pa_n; slot = 2 * (int)blockIdx.x; }
+        else { unit = pa_unit + 1; kb = 0; nchunks = pb_n; slot = 2 * (int)blockIdx.x + 1; }
         decode(unit);
         dma_u(0, 0);
 #ifndef WF_ABL_NOXFORM
@@ -209,11 +240,12 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
 #endif
     };
 
-    start_unit(blockIdx.x);
+    if (nitems == 0) return;
+    start_unit(0);
     finish_start();
-    for (int unit = blockIdx.x; unit < a.nunits; unit += gridDim.x) {
+    for (int it = 0; it < nitems; ++it) {
 #ifdef WF_ABL_CLOCK
-        const bool stamp_on = blockIdx.x == 37 && unit == (int)blockIdx.x + (int)gridDim.x;
+        const bool stamp_on = blockIdx.x == 37 && it == 1;
 #endif
         WF_STAMP(0);
         WF_STAMP(1);
@@ -338,10 +370,10 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
         // ---- epilogue, with the next unit's chunk 0 started underneath it ---------------------------------
         WF_STAMP(28);
         const bool e_whole = whole, e_tile_ok = tile_ok;
-        const int e_m0 = m0, e_tb = tb, e_half = half, oh = 2 * th, ow = 2 * tw;
+        const int e_m0 = m0, e_tb = tb, e_half = half, oh = 2 * th, ow = 2 * tw, e_slot = slot;
         const unsigned e_n = n;
-        const bool has_next = unit + (int)gridDim.x < a.nunits;
-        if (has_next) start_unit(unit + (int)gridDim.x);  // both stages are free: the K loop ended with a barrier
+        const bool has_next = it + 1 < nitems;
+        if (has_next) start_unit(it + 1);  // both stages are free: the K loop ended with a barrier
 #ifdef WF_ABL_NOEPI
         {
             float sum = 0.f;
@@ -423,6 +455,12 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
                 }
                 const int soff = f_ok ? f * HW * 4 : 0;  // wave-uniform; soffset is not range-checked,
                 const unsigned kill = f_ok ? 0u : kOOB;  // ... the voffset is: channels past M are dropped through it
+                if (EPI == 0 && e_slot >= 0) {  // uniform: a piece of a K-split unit -- raw partial outputs to its scratch slot
+                    const unsigned so = (unsigned)(((e_slot * 64 + ph * 32 + fl) * 64 + lane) * 16);
+                    buffer_store_f32x2(buf_f32x2{o[0][0], o[0][1]}, rs_scr, (int)so, 0, 0);
+                    buffer_store_f32x2(buf_f32x2{o[1][0], o[1][1]}, rs_scr, (int)(so + 8u), 0, 0);
+                    continue;
+                }
 #ifndef WF_ABL_NOSTORE
                 if (!odd_w) {  // uniform; rows start 8-byte aligned and ow is even
                     buffer_store_f32x2(buf_f32x2{o[0][0], o[0][1]}, rs_dst, (int)(o00 | kill), soff, 0);
@@ -450,6 +488,57 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
             if (ph == 0 && has_next) finish_start();
         }
         WF_STAMP(31);
+    }
+}
+
+// K-split tail of wino_fused_kernel<0, .>: the pieces of tail unit u (unit index nunits + u) sit in the scratch slots of the
+// workgroups whose chunk ranges met it -- workgroup i's range starts at chunk i * tail_q of the flattened tail; a range that
+// started in the previous unit left its SECOND piece here (slot 2 i + 1), every other one its first (slot 2 i). They are
+// added in channel order (ascending i), then stored and counted into the batch-norm statistics exactly like the epilogue of
+// the main kernel does for a whole unit. One wave per (unit, channel): lane = tile.
+template <bool STATS>
+__global__ __launch_bounds__(256) void wino_tail_fixup_kernel(const WinoFusedArgs a) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int u = blockIdx.x >> 4, fl = (blockIdx.x & 15) * 4 + wid;
+    const int NC = a.Jpad / WF_KC;
+    const int blk = a.nunits + u;
+    const int mb = blk % a.mblocks, tb = blk / a.mblocks;
+    const int f = mb * WF_BF + fl;
+    const bool f_ok = f < a.M;
+    const unsigned t = (unsigned)tb * WF_BT + (unsigned)lane;
+    const bool tile_ok = t < a.T;
+    const unsigned per_img = (unsigned)(a.TH * a.TW);
+    const unsigned n = tile_ok ? t / per_img : 0u;
+    const unsigned rr = tile_ok ? t - n * per_img : 0u;
+    const int th = (int)(rr / (unsigned)a.TW), tw = (int)(rr - (unsigned)th * (unsigned)a.TW);
+    const int c0 = u * NC, c1 = c0 + NC;
+    const int i0 = c0 / a.tail_q, i1 = (c1 - 1) / a.tail_q;
+    float o00 = 0.f, o01 = 0.f, o10 = 0.f, o11 = 0.f;
+    for (int i = i0; i <= i1; ++i) {
+        const int slot = 2 * i + (i * a.tail_q < c0 ? 1 : 0);
+        const float4 v = *reinterpret_cast<const float4*>(a.tail_scr + ((size_t)(slot * 64 + fl) * 64 + lane) * 4);
+        o00 += v.x; o01 += v.y; o10 += v.z; o11 += v.w;
+    }
+    const int HW = a.H * a.W, oh = 2 * th, ow = 2 * tw;
+    const bool two_cols = ow + 1 < a.W, two_rows = oh + 1 < a.H;
+    if (tile_ok && f_ok) {
+        float* d = a.dst + ((size_t)n * a.M + f) * HW + (size_t)oh * a.W + ow;
+        d[0] = o00;
+        if (two_cols) d[1] = o01;
+        if (two_rows) {
+            d[a.W] = o10;
+            if (two_cols) d[a.W + 1] = o11;
+        }
+    }
+    if (STATS) {  // the epilogue's masked sums, in its order
+        const float w00 = tile_ok ? 1.f : 0.f, w10 = (tile_ok && two_rows) ? 1.f : 0.f, w01 = two_cols ? 1.f : 0.f;
+        const float sv0 = (o00 + o01 * w01) * w00, sv1 = (o10 + o11 * w01) * w10;
+        const float sq0 = (o00 * o00 + o01 * o01 * w01) * w00, sq1 = (o10 * o10 + o11 * o11 * w01) * w10;
+        const float sv = wave_sum_dpp(sv0 + sv1), sq = wave_sum_dpp(sq0 + sq1);
+        if (lane == 63 && f_ok) {  // a whole block owns both half-block slots and zeroes the second
+            float* st = a.stats + ((size_t)f * (2 * a.tblocks) + 2 * tb) * 2;
+            st[0] = sv; st[1] = sq; st[2] = 0.f; st[3] = 0.f;
+        }
     }
 }
 
@@ -897,6 +986,25 @@ static float* wf_scratch(size_t floats) {
     return sc.p;
 }
 
+// the piece outputs of a K-split tail (33.5 MB: two slots of 64 x 64 x 4 floats per CU); separate from the U scratch, which
+// the running kernel reads
+static thread_local WfScratch g_wf_tail_scratch;
+static float* wf_tail_scratch(size_t floats) {
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    WfScratch& sc = g_wf_tail_scratch;
+    if (sc.p == nullptr || sc.cap < floats || sc.dev != dev) {
+        if (sc.p && sc.dev == dev) {
+            HIP_CHECK(hipStreamSynchronize(current_stream()));
+            HIP_CHECK(hipFree(sc.p));
+        }
+        HIP_CHECK(hipMalloc((void**)&sc.p, floats * sizeof(float)));
+        sc.cap = floats;
+        sc.dev = dev;
+    }
+    return sc.p;
+}
+
 // Split-bf16 form (wino_bf16_kernel): which layers and how many parts. BCNN_HIP_WINOGRAD_BF16 = 0 / 2 / 3 forces it in the
 // experiment build.
 static int g_wb_parts = -1;
@@ -977,6 +1085,26 @@ static void wino_fused_run(const float* src, const float* w, float* dst, const C
     a.nfull = (rem > 0 && 2 * rem <= (int)grid && nblocks > (int)grid) ? nblocks - rem : nblocks;
     a.nunits = a.nfull + 2 * (nblocks - a.nfull);
     const bool plain = !a.add_bias && a.act == BCNN_HIP_ACT_NONE;
+    // ... or, for the raw-output kernels, that round's chunks dealt out evenly over all CUs (K-split tail): a CU then does
+    // ceil(R * chunks / CUs) chunks in one or two pieces instead of a whole (or half) unit. Priced in chunk times with ~1.5
+    // per epilogue; the fix-up pass over the tail's outputs is a few microseconds.
+    a.tail_scr = nullptr; a.tail_q = 0; a.tail_units = 0; a.tail_scr_bytes = 0;
+    static const int ksplit_on = BCNN_EXP_ENV("BCNN_HIP_NO_WINO_KSPLIT") ? 0 : 1;  // A/B switch of the experiment build
+    if (ksplit_on && plain && !parts && rem > 0 && nblocks > (int)grid) {
+        const int NC = a.Jpad / WF_KC;
+        const int q = (int)ceil_div((long long)rem * NC, (long long)grid);
+        // (+2: the fix-up launch, 5-8 us -- on the 64-channel 56 x 56 layers the two ways then cost the same: not split)
+        const double ep = 1.5, now = (a.nfull < nblocks ? 0.5 * NC : (double)NC) + ep, split = q + 2 * ep + 2.0;
+        if (q >= 1 && q <= NC && split < now) {
+            a.nfull = nblocks;         // every block is a whole unit ...
+            a.nunits = nblocks - rem;  // ... and the last `rem` of them are the tail
+            a.tail_units = rem;
+            a.tail_q = q;
+            const size_t scr_floats = (size_t)2 * grid * 64 * 64 * 4;
+            a.tail_scr = wf_tail_scratch(scr_floats);
+            a.tail_scr_bytes = (unsigned)(scr_floats * sizeof(float));
+        }
+    }
     a.stats_bytes = a.stats ? (unsigned)((size_t)a.M * 2 * a.tblocks * 2 * sizeof(float)) : 0u;
     if (a.stats && (size_t)a.stats_bytes > stats->capacity * sizeof(float)) {
         fprintf(stderr, "[bcnn_hip] fused Winograd: statistics need %u bytes, the caller's buffer holds %zu\n",
@@ -994,6 +1122,11 @@ static void wino_fused_run(const float* src, const float* w, float* dst, const C
     else if (a.act == BCNN_HIP_ACT_RELU) wino_fused_kernel<1, false><<<grid, 512, 0, current_stream()>>>(a);
     else wino_fused_kernel<2, false><<<grid, 512, 0, current_stream()>>>(a);
     KERNEL_CHECK();
+    if (a.tail_units > 0) {
+        if (a.stats) wino_tail_fixup_kernel<true><<<(unsigned)(a.tail_units * 16), 256, 0, current_stream()>>>(a);
+        else wino_tail_fixup_kernel<false><<<(unsigned)(a.tail_units * 16), 256, 0, current_stream()>>>(a);
+        KERNEL_CHECK();
+    }
     if (stats) stats->splits = a.stats ? 2 * a.tblocks : 0;
 }
 
