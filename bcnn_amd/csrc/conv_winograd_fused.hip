@@ -1258,21 +1258,25 @@ __global__ __launch_bounds__(512, 2) void wino_dw_fused_kernel(const WinoDwArgs 
         if (odd_w) pair_y_ok = 2 * tw + 1 < a.W;
         const bool el = x_ok && is_l && has_l, er = x_ok && is_r && has_r;
         const unsigned up = xo - W4;
+        // the scalar offsets ARE wave-uniform, but when the compiler keeps W4 in a vector register (it runs out of scalar
+        // ones here) it wraps every such load in a waterfall loop over the distinct values: four loops of ~10 instructions
+        // per chunk. readfirstlane tells it.
+        const int s1 = __builtin_amdgcn_readfirstlane((int)W4), s2 = __builtin_amdgcn_readfirstlane((int)(2u * W4));
         xm[0] = buffer_load_f32x2(rs_x, (int)((x_ok && r0) ? up : kOOB), 0, 0);
         xm[1] = buffer_load_f32x2(rs_x, (int)(x_ok ? xo : kOOB), 0, 0);
-        xm[2] = buffer_load_f32x2(rs_x, (int)((x_ok && r2) ? xo : kOOB), (int)W4, 0);
-        xm[3] = buffer_load_f32x2(rs_x, (int)((x_ok && r3) ? xo : kOOB), (int)(2u * W4), 0);
+        xm[2] = buffer_load_f32x2(rs_x, (int)((x_ok && r2) ? xo : kOOB), s1, 0);
+        xm[3] = buffer_load_f32x2(rs_x, (int)((x_ok && r3) ? xo : kOOB), s2, 0);
         xl[0] = buffer_load_f32(rs_x, (int)((el && r0) ? up - 4u : kOOB), 0, 0);
         xl[1] = buffer_load_f32(rs_x, (int)(el ? xo - 4u : kOOB), 0, 0);
-        xl[2] = buffer_load_f32(rs_x, (int)((el && r2) ? xo - 4u : kOOB), (int)W4, 0);
-        xl[3] = buffer_load_f32(rs_x, (int)((el && r3) ? xo - 4u : kOOB), (int)(2u * W4), 0);
+        xl[2] = buffer_load_f32(rs_x, (int)((el && r2) ? xo - 4u : kOOB), s1, 0);
+        xl[3] = buffer_load_f32(rs_x, (int)((el && r3) ? xo - 4u : kOOB), s2, 0);
         xr[0] = buffer_load_f32(rs_x, (int)((er && r0) ? up + 8u : kOOB), 0, 0);
         xr[1] = buffer_load_f32(rs_x, (int)(er ? xo + 8u : kOOB), 0, 0);
-        xr[2] = buffer_load_f32(rs_x, (int)((er && r2) ? xo + 8u : kOOB), (int)W4, 0);
-        xr[3] = buffer_load_f32(rs_x, (int)((er && r3) ? xo + 8u : kOOB), (int)(2u * W4), 0);
+        xr[2] = buffer_load_f32(rs_x, (int)((er && r2) ? xo + 8u : kOOB), s1, 0);
+        xr[3] = buffer_load_f32(rs_x, (int)((er && r3) ? xo + 8u : kOOB), s2, 0);
         // dy block: rows 2th, 2th+1, columns 2tw, 2tw+1 of channel f0 + ch
         gy[0] = buffer_load_f32x2(rs_y, (int)(y_ok ? yo : kOOB), 0, 0);
-        gy[1] = buffer_load_f32x2(rs_y, (int)((y_ok && r2) ? yo : kOOB), (int)W4, 0);
+        gy[1] = buffer_load_f32x2(rs_y, (int)((y_ok && r2) ? yo : kOOB), s1, 0);
     };
     auto advance = [&]() {  // 8 tiles on: at most two row carries (TW >= 4) and one image carry (TH >= 2)
         t += WD_KT;
