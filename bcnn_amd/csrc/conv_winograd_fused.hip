@@ -1297,8 +1297,10 @@ __global__ __launch_bounds__(512, 2) void wino_dw_fused_kernel(const WinoDwArgs 
         for (int i = 0; i < 4; ++i) {
             float m0 = xm[i][0], m1 = xm[i][1];
             if (odd_w) m1 = pair_y_ok ? m1 : 0.f;
-            const float fromleft = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m1), 0x111 /* row_shr:1 */, 0xf, 0xf, false));
-            const float fromright = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m0), 0x101 /* row_shl:1 */, 0xf, 0xf, false));
+            // (bound_ctrl: a row's first / last lane reads 0 -- those lanes take xl / xr below anyway -- and the move needs no
+            // initialised destination, i.e. no v_mov in front of it)
+            const float fromleft = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, m1), 0x111 /* row_shr:1 */, 0xf, 0xf, true));
+            const float fromright = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, m0), 0x101 /* row_shl:1 */, 0xf, 0xf, true));
             d[i][0] = sel_l ? fromleft : xl[i];
             d[i][1] = m0;
             d[i][2] = m1;
