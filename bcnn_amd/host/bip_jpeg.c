@@ -419,6 +419,11 @@ static int read_frame(jdec *d) {
         if (c->h > d->hmax) d->hmax = c->h;
         if (c->v > d->vmax) d->vmax = c->v;
     }
+    /* every component must divide the largest sampling factor: the upsampler replicates by the integer ratio
+     * hmax / h, and with a truncated ratio (h = 3 under hmax = 4) a plane row is shorter than the image row the colour
+     * conversion reads from it (heap over-read). No encoder writes such frames. */
+    for (int i = 0; i < d->ncomp; ++i)
+        if (d->hmax % d->comp[i].h != 0 || d->vmax % d->comp[i].v != 0) return 0;
     d->mcus_x = (d->width + 8 * d->hmax - 1) / (8 * d->hmax);
     d->mcus_y = (d->height + 8 * d->vmax - 1) / (8 * d->vmax);
     for (int i = 0; i < d->ncomp; ++i) {

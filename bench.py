@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- images/s forward+backward of bcnn's conv hot path on MI355X, one process per GPU.
 
-Contract: `python bench.py --gpus N --steps K --warmup W` (for N > 1 launched under
-torch.distributed.run, one rank per GPU, RCCL all-reduce of the weight-gradient arena after backward).
+Contract: `python bench.py --gpus N --steps K --warmup W`: one rank per GPU, RCCL all-reduce of the weight-gradient
+arena after backward. For N > 1 either a launcher starts the ranks (`python -m torch.distributed.run --nproc-per-node N
+bench.py --gpus N ...`: WORLD_SIZE is set and must equal N) or, run bare, bench.py starts that launcher itself as a
+child process before anything touches the GPU and relays rank 0's line (launch_ranks below); fewer than N visible
+GPUs is an error, never a smaller run under the asked-for label.
 Rank 0 prints ONE JSON line: whole-job throughput, the roofline of the dominant kernel class (durations
 measured live with HIP events on the launch stream, inside the timed region: every 4th timed step carries the
 per-class event timers -- `profiled_steps` in the output -- because ~200 event records per step cost 4 % of a
@@ -365,6 +368,56 @@ class Workload:
         self.step = None
 
 
+def visible_gpus():
+    """number of GPUs a rank would see, counted by a short-lived child so that THIS process never initialises HIP"""
+    import subprocess
+    r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                       capture_output=True, text=True, timeout=600)
+    try:
+        return int(r.stdout.strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        return 0
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start N ranks (one per GPU, the reference's
+    one-device-per-process model, /root/reference/src/cli/bcnn_cl.c:281-285) under torch.distributed.run as a CHILD
+    process, relay rank 0's single JSON line and return the child's exit code. The parent imports neither torch nor
+    the HIP library: a process that has initialised the GPU must not start or become another program."""
+    import socket
+    import subprocess
+    if os.environ.get("BENCH_TEST_SAME_DEVICE") != "1":
+        have = visible_gpus()
+        if have < n:
+            print("bench.py: --gpus %d asked for, %d visible on this node: refusing to print a %d-GPU number under "
+                  "another label" % (n, have, have), file=sys.stderr, flush=True)
+            return 2
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL's intra-node transport needs it on this driver
+    env.pop("MASTER_PORT", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    out, _ = child.communicate()
+    result = None
+    for ln in out.splitlines():
+        if ln.startswith("{") and result is None:
+            result = ln
+        elif ln.strip():
+            print(ln, file=sys.stderr)
+    if child.returncode == 0 and result is None:
+        print("bench.py: the ranks finished without a result line", file=sys.stderr, flush=True)
+        return 4
+    if result is not None:
+        print(result, flush=True)
+    return child.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -385,6 +438,13 @@ def main():
         ap.error("--steps must be at least 1 (the timed region runs exactly that many steps)")
     if args.warmup < 0:
         ap.error("--warmup must not be negative")
+    if args.gpus < 1:
+        ap.error("--gpus must be at least 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            sys.exit(launch_ranks(args.gpus))   # parent of N ranks: never touches the GPU itself
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks" % (args.gpus, os.environ["WORLD_SIZE"]))
 
     # stdout carries exactly one line, the result: everything else that writes to file descriptor 1 while the job
     # runs (RCCL's version banner comes through C stdio, from whichever rank initialises first) goes to stderr
@@ -405,6 +465,8 @@ def main():
         local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
+    if local_rank >= torch.cuda.device_count():
+        sys.exit("bench.py: rank %d wants GPU %d, %d visible" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     L = _lib.load()
     L.bcnn_hip_set_device(local_rank)

@@ -45,6 +45,19 @@ def test_mutated_image_files_never_trip_the_sanitizers(tmp_path):
         p = str(tmp_path / ("p%d.png" % i))
         img.save(p)
         seeds.append(p)
+    # hostile seeds no encoder writes: sampling factors that do not divide the largest one (3x1 under 4x1; the
+    # upsampler's integer ratio truncates and a plane row ends before the image row does -- ADVICE round 3), on a
+    # tall narrow frame where the last row sits at the end of the plane's allocation
+    for j, (w, h) in enumerate(((1024, 8), (16, 200))):
+        p = str(tmp_path / ("odd%d.jpg" % j))
+        Image.fromarray(rs.randint(0, 256, (h, w, 3)).astype(np.uint8)).save(p, "JPEG", quality=60, subsampling=0)
+        raw = bytearray(open(p, "rb").read())
+        sof = raw.find(b"\xff\xc0")
+        assert sof > 0 and raw[sof + 9] == 3
+        for k, hv in enumerate((0x31, 0x41, 0x41) if j == 0 else (0x13, 0x14, 0x12)):
+            raw[sof + 10 + 3 * k + 1] = hv
+        open(p, "wb").write(bytes(raw))
+        seeds.append(p)
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
     r = subprocess.run([exe] + seeds, capture_output=True, text=True, env=env, timeout=600)
     tail = "\n".join(ln for ln in (r.stdout + r.stderr).splitlines() if not ln.startswith("[ERROR]"))[-3000:]

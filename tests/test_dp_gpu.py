@@ -113,20 +113,30 @@ def test_gradient_ready_ranges_tile_the_arena():
     assert len(seen) == 2 * n_first
 
 
-def _run_bench_two_ranks(extra, port):
+def _run_bench_two_ranks(extra, port, self_launch):
+    """self_launch: `python bench.py --gpus 2` bare (bench.py starts its own ranks, the form the round-end driver may
+    use); otherwise under torch.distributed.run the way the driver's multi-GPU contract spells it"""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, BENCH_TEST_SAME_DEVICE="1", BENCH_TEST_CHECKSUM="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--batch", "8", "--no-cpu-baseline"] + extra
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    tail = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "8",
+            "--no-cpu-baseline"] + extra
+    if self_launch:
+        cmd = [sys.executable] + tail
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(port)] + tail
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-    return json.loads(line)
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    if self_launch:
+        assert len(lines) == 1, r.stdout[-2000:]     # the parent relays rank 0's line and nothing else
+    return json.loads([ln for ln in lines if ln.startswith("{")][-1])
 
 
 def test_bench_two_ranks_overlapped_allreduce_equals_blocking_allreduce():
@@ -139,9 +149,10 @@ def test_bench_two_ranks_overlapped_allreduce_equals_blocking_allreduce():
         with socket.socket() as s:
             s.bind(("127.0.0.1", 0))
             ports.append(s.getsockname()[1])
-    a = _run_bench_two_ranks([], ports[0])
-    b = _run_bench_two_ranks(["--no-overlap"], ports[1])
-    assert a["n_gpus"] == 2 and a["config"]["global_batch"] == 16
+    a = _run_bench_two_ranks([], ports[0], self_launch=True)
+    b = _run_bench_two_ranks(["--no-overlap"], ports[1], self_launch=False)
+    for d in (a, b):
+        assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp2"
     assert a["param_checksum"] == b["param_checksum"], (a["param_checksum"], b["param_checksum"])
 
 
@@ -175,3 +186,15 @@ def test_bench_rccl_path_on_one_gpu_prints_one_line_and_leaves_the_same_paramete
     blocking = run({"BENCH_FORCE_DP": "1", "BENCH_NO_OVERLAP": "1"})
     assert forced["param_checksum"] == plain["param_checksum"]
     assert blocking["param_checksum"] == plain["param_checksum"]
+
+
+def test_bench_refuses_more_gpus_than_the_node_has():
+    """`bench.py --gpus 64` on this box: non-zero exit and a message, never a smaller run under that label"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "BENCH_TEST_SAME_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64", "--steps", "1", "--warmup", "0"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and not r.stdout.strip() and "64" in r.stderr

@@ -1,5 +1,5 @@
 /* tools/fuzz_bip.c -- mutation fuzzer for libbip's image decoders (JPEG, PNG, PNM, BMP): every seed file given on the
- * command line is decoded 400 times with 1..8 random byte / bit / truncation mutations. Built with
+ * command line is decoded once as it is and 400 times with 1..8 random byte / bit / truncation mutations. Built with
  * -fsanitize=address,undefined by tests/test_bip_fuzz.py (sanitizers run on the CPU build only). */
 #include <stdio.h>
 #include <stdlib.h>
@@ -13,9 +13,9 @@ int main(int argc, char **argv) {
         FILE *f = fopen(argv[a], "rb"); if (!f) continue;
         fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
         uint8_t *base = malloc(n); if (fread(base, 1, n, f) != (size_t)n) n = 0; fclose(f); if (n == 0) { free(base); continue; }
-        for (int it = 0; it < 400; ++it) {
+        for (int it = 0; it <= 400; ++it) {
             uint8_t *buf = malloc(n); memcpy(buf, base, n);
-            int flips = 1 + (rand_r(&seed) % 8);
+            int flips = it == 0 ? 0 : 1 + (rand_r(&seed) % 8); /* it 0: the seed itself (hand-made hostile seeds) */
             long len = n;
             for (int k = 0; k < flips; ++k) {
                 long pos = rand_r(&seed) % n;
