@@ -47,4 +47,14 @@ bool depthwise_backward_lds(const float* x, const float* w, const float* y, floa
                             const DwShape& s, int act, int overwrite, int write_back, const DwBnBwd* bn,
                             const DwBnIn* in = nullptr, ConvStats* in_sums = nullptr);
 
+// depthwise_march.hip: the same contracts for rows of whole 16-byte groups (W % 4 == 0, W <= 256), tried first by the two
+// entry points above; slots per channel of their statistics / sums / partials (0: not their shape)
+bool depthwise_march_ok(const DwShape& s);
+size_t depthwise_march_splits(const DwShape& s);
+bool depthwise_forward_march(const float* x, const float* w, const float* bias, float* y, const DwShape& s, int act,
+                             ConvStats* stats, const DwBnIn* in);
+bool depthwise_backward_march(const float* x, const float* w, const float* y, float* dy, float* dx, float* dw, float* dbias,
+                              const DwShape& s, int act, int overwrite, int write_back, const DwBnBwd* bn, const DwBnIn* in,
+                              ConvStats* in_sums);
+
 }  // namespace bcnn_hip

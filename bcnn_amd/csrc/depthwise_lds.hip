@@ -23,6 +23,8 @@
 #include "depthwise.h"
 #include "lds_dma.h"
 
+#include <algorithm>
+
 namespace bcnn_hip {
 
 namespace {
@@ -865,6 +867,11 @@ constexpr int kVR1 = 4, kVR2 = 2;  // output rows per thread, stride 1 / 2
 
 }  // namespace
 
+void dwl_finalize_launch(const float* partials, int splits, int C, float* dw, float* dbias, hipStream_t st) {
+    dwl_finalize_kernel<<<C, 256, 0, st>>>(partials, splits, dw, dbias);
+    KERNEL_CHECK();
+}
+
 bool depthwise_lds_ok(const DwShape& s) {
     static const int on = BCNN_EXP_ENV("BCNN_HIP_NO_DW_LDS") ? 0 : 1;  // A/B switch (experiment build only)
     if (!on) return false;
@@ -879,19 +886,21 @@ bool depthwise_lds_ok(const DwShape& s) {
 size_t depthwise_lds_stats_floats(const DwShape& s) {
     if (!depthwise_lds_ok(s)) return 0;
     const DwlGeom g = dwl_plan(s);
-    return (size_t)s.C * s.N * g.NB * 2;
+    const size_t march = (size_t)s.C * depthwise_march_splits(s) * 2;  // the marching kernels' slots, where they take the shape
+    return std::max((size_t)s.C * s.N * g.NB * 2, march);
 }
 
 size_t depthwise_lds_partial_floats(const DwShape& s) {
     if (!depthwise_lds_ok(s)) return 0;
     const DwlGeom g = dwl_plan(s);
-    return (size_t)s.C * s.N * g.NB * kPart;
+    return std::max((size_t)s.C * s.N * g.NB * kPart, (size_t)s.C * depthwise_march_splits(s) * kPart);
 }
 
 bool depthwise_forward_lds(const float* x, const float* w, const float* bias, float* y, const DwShape& s, int act,
                            ConvStats* stats, const DwBnIn* in) {
     if (!depthwise_lds_ok(s) || !act_is_cheap(act) || act == BCNN_HIP_ACT_PRELU) return false;
     if (in && (!in->mean || !act_is_cheap(in->act) || in->act == BCNN_HIP_ACT_PRELU)) return false;
+    if (depthwise_forward_march(x, w, bias, y, s, act, stats, in)) return true;  // rows of whole 16-byte groups
     DwlFwdArgs a;
     a.g = dwl_plan(s);
     const int VR = s.stride == 1 ? kVR1 : kVR2;
@@ -929,7 +938,7 @@ bool depthwise_forward_lds(const float* x, const float* w, const float* bias, fl
 size_t depthwise_lds_in_sums_floats(const DwShape& s) {
     if (!depthwise_lds_ok(s)) return 0;
     const DwlGeom g = dwl_plan(s);
-    return (size_t)s.C * s.N * g.NB * 2;
+    return std::max((size_t)s.C * s.N * g.NB * 2, (size_t)s.C * depthwise_march_splits(s) * 2);
 }
 
 bool depthwise_backward_lds(const float* x, const float* w, const float* y, float* dy, float* dx, float* dw, float* dbias,
@@ -938,6 +947,15 @@ bool depthwise_backward_lds(const float* x, const float* w, const float* y, floa
     if (in_sums) in_sums->splits = 0;
     if (!depthwise_lds_ok(s) || !act_bwd_is_cheap(act) || act == BCNN_HIP_ACT_PRELU || !dx) return false;
     if (in && (!in->mean || !act_is_cheap(in->act) || in->act == BCNN_HIP_ACT_PRELU)) return false;
+    if (!bn && write_back && act != BCNN_HIP_ACT_NONE && act != BCNN_HIP_ACT_RELU && act != BCNN_HIP_ACT_CLAMP) {
+        // g = dy * act'(y) is written back over dy by the band that owns the row, while the neighbouring band reads the same
+        // row as its halo: harmless when applying the derivative twice changes nothing (a factor 0 or 1), a race otherwise
+        // (leaky ReLU: 0.01 instead of 0.1 on a band's edge row, whenever the owner happened to run first). Those
+        // activations get their own in-place pass first.
+        bcnn_hip_activation_backward(y, dy, (size_t)s.N * s.C * s.OH * s.OW, act, nullptr, nullptr, s.OH * s.OW, s.C);
+        act = BCNN_HIP_ACT_NONE;
+    }
+    if (depthwise_backward_march(x, w, y, dy, dx, dw, dbias, s, act, overwrite, write_back, bn, in, in_sums)) return true;
     DwlBwdArgs a;
     a.g = dwl_plan(s);
     const int S = s.stride, VR = S == 1 ? kVR1 : kVR2;

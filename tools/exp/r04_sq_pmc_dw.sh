@@ -21,11 +21,11 @@ def key(r):
     return "%s grid %s wg %s" % (r["Kernel_Name"][:60], r["Grid_Size_X"] if "Grid_Size_X" in r else r.get("Grid_Size", "?"), r["Workgroup_Size_X"] if "Workgroup_Size_X" in r else r.get("Workgroup_Size", "?"))
 for f in glob.glob("$O/*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "dwl_" in r["Kernel_Name"] or "dw3_" in r["Kernel_Name"]:
+        if "dwl_" in r["Kernel_Name"] or "dw3_" in r["Kernel_Name"] or "dwm_" in r["Kernel_Name"]:
             acc[key(r)][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for f in glob.glob("$O/*/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "dwl_" in r["Kernel_Name"] or "dw3_" in r["Kernel_Name"]:
+        if "dwl_" in r["Kernel_Name"] or "dw3_" in r["Kernel_Name"] or "dwm_" in r["Kernel_Name"]:
             dur[key(r)].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 for k in sorted(acc):
     m = {c: sum(v) / len(v) for c, v in acc[k].items()}
