@@ -47,7 +47,7 @@ bool depthwise_backward_lds(const float* x, const float* w, const float* y, floa
                             const DwShape& s, int act, int overwrite, int write_back, const DwBnBwd* bn,
                             const DwBnIn* in = nullptr, ConvStats* in_sums = nullptr);
 
-// depthwise_march.hip: the same contracts for rows of whole 16-byte groups (W % 4 == 0, W <= 256), tried first by the two
+// depthwise_march.hip: the same contracts for rows of at most 64 column groups of 4 / 2 / 1 floats, tried first by the two
 // entry points above; slots per channel of their statistics / sums / partials (0: not their shape)
 bool depthwise_march_ok(const DwShape& s);
 size_t depthwise_march_splits(const DwShape& s);
