@@ -34,6 +34,10 @@ float* reduce_scratch(size_t floats);                                           
 
 namespace {
 
+#ifndef DWM_BWD_WAVES
+#define DWM_BWD_WAVES 3  // waves per SIMD the backward kernels are compiled for (register budget 512 / that; at 4 the
+                         // 112 x 112 instance spills inside its loop and takes twice the time)
+#endif
 #ifndef DWM_ROWS
 #define DWM_ROWS 14  // rows a band marches (target; the plan evens bands out)
 #endif
@@ -170,7 +174,7 @@ __device__ __forceinline__ Row<V> dwm_row(const Vals<V>& x, const DwmLane& m) {
 struct DwmBnInC {
     float mean, sc, b;
     BnDiv rs;
-    bool sc0;
+    bool sc0, any_sc0;
 };
 __device__ __forceinline__ DwmBnInC dwm_bnin_consts(const DwBnIn& in, int c) {
     DwmBnInC k;
@@ -179,6 +183,7 @@ __device__ __forceinline__ DwmBnInC dwm_bnin_consts(const DwBnIn& in, int c) {
     k.b = in.bias[c];
     if (k.b == 0.0f || k.b == 1.0f) k.b = -0.0f;
     k.sc0 = k.sc == 0.0f;
+    k.any_sc0 = __builtin_amdgcn_ballot_w64(k.sc0) != 0;
     k.rs.d = sqrtf(in.var[c] + 0.000001f);
     k.rs.r = __fdiv_rn(1.0f, k.rs.d);
     return k;
@@ -186,7 +191,7 @@ __device__ __forceinline__ DwmBnInC dwm_bnin_consts(const DwBnIn& in, int c) {
 __device__ __forceinline__ float dwm_bnin(float x, const DwmBnInC& k, int act) {
     float v = bn_div(__fsub_rn(x, k.mean), k.rs);
     v = __fmul_rn(v, k.sc);
-    if (k.sc0) v = 0.f;
+    if (k.any_sc0 && k.sc0) v = 0.f;  // wave-uniform first: no channel of a trained net has a scale of exactly 0
     v = __fadd_rn(v, k.b);
     return act_fwd_cheap(v, act, 0.f);
 }
@@ -232,9 +237,12 @@ struct DwmFwdArgs {
     DwmGeom g;
 };
 
-template <int S, int V, bool BNIN, int PF>
+// RELU: this layer's activation (and with BNIN the producer's) is ReLU, compiled in: the activation switch on a kernel
+// argument costs a scalar jump table per element otherwise. Other cheap activations take the generic instance.
+template <int S, int V, bool BNIN, int PF, bool RELU>
 __global__ __launch_bounds__(256) void dwm_fwd_kernel(const DwmFwdArgs a) {
     __shared__ float red[4][2 * kSlab];
+    const int act = RELU ? BCNN_HIP_ACT_RELU : a.act, in_act = RELU ? BCNN_HIP_ACT_RELU : a.in.act;
     constexpr int OV = S == 1 ? V : V / 2;  // outputs per lane and row
     const DwmLane m = dwm_lane(a.g.L, a.g.G, a.g.BPP, a.C, (unsigned)a.g.bands);
     float w[9];
@@ -252,10 +260,10 @@ __global__ __launch_bounds__(256) void dwm_fwd_kernel(const DwmFwdArgs a) {
     auto in_row = [&](int r) -> bool { return m.on && r >= 0 && r < a.H; };
     auto fetch = [&](int r) -> Vals<V> { return dwm_ld<V>(a.x, xbase + (unsigned)r * xrow, in_row(r)); };
     auto prep = [&](Vals<V> v, int r) -> Row<V> {
-        if (BNIN && in_row(r)) v = dwm_bnin_v<V>(v, kin, a.in.act);
+        if (BNIN && in_row(r)) v = dwm_bnin_v<V>(v, kin, in_act);
         return dwm_row<V, true, S == 1>(v, m);
     };
-    auto finish = [&](float v) -> float { return act_fwd_cheap(__fadd_rn(v, b), a.act, 0.f); };
+    auto finish = [&](float v) -> float { return act_fwd_cheap(__fadd_rn(v, b), act, 0.f); };
     auto emit = [&](const Row<V>& A, const Row<V>& B, const Row<V>& Cr, bool valid) {
         Vals<OV> o;
 #pragma unroll
@@ -356,12 +364,13 @@ struct DwmBwdArgs {
 struct DwmBnC {
     float mean, sc, dm_m, dv2;
     BnDiv rs;
-    bool sc0;
+    bool sc0, any_sc0;
 };
 
-template <int S, int V, bool BN, bool BNIN>
-__global__ __launch_bounds__(256) void dwm_bwd_kernel(const DwmBwdArgs a) {
+template <int S, int V, bool BN, bool BNIN, bool RELU>
+__global__ __launch_bounds__(256, DWM_BWD_WAVES) void dwm_bwd_kernel(const DwmBwdArgs a) {
     __shared__ float red[4][kDwmPart * kSlab];
+    const int act = RELU ? BCNN_HIP_ACT_RELU : a.act, in_act = RELU ? BCNN_HIP_ACT_RELU : a.in.act;
     constexpr int GV = S == 1 ? V : V / 2;  // gradient values per lane and row
     const DwmLane m = dwm_lane(a.g.L, a.g.G, a.g.BPP, a.C, (unsigned)a.g.bands);
     float w[9];
@@ -374,6 +383,7 @@ __global__ __launch_bounds__(256) void dwm_bwd_kernel(const DwmBwdArgs a) {
         kb.rs.r = __fdiv_rn(1.0f, kb.rs.d);
         kb.sc = a.bn.scale[m.c];
         kb.sc0 = kb.sc == 0.0f;
+        kb.any_sc0 = __builtin_amdgcn_ballot_w64(kb.sc0) != 0;
         kb.dm_m = __fdiv_rn(a.bn.dmean[m.c], a.fM);
         kb.dv2 = __fmul_rn(a.bn.dvar[m.c], 2.0f);
     }
@@ -384,8 +394,8 @@ __global__ __launch_bounds__(256) void dwm_bwd_kernel(const DwmBwdArgs a) {
     const unsigned xrow = (unsigned)a.W * 4u, grow = (unsigned)a.OW * 4u;  // bytes per row
     const unsigned xbase = ((unsigned)m.p * a.H * a.W + m.cg * V) * 4u, gbase = ((unsigned)m.p * a.OH * a.OW + m.cg * GV) * 4u;
     const float* gsrc = BN ? a.bn.dz : a.dy;
-    const bool need_y = BN || a.act != BCNN_HIP_ACT_NONE;
-    const bool wb = !BN && a.write_back && a.act != BCNN_HIP_ACT_NONE;
+    const bool need_y = BN || act != BCNN_HIP_ACT_NONE;
+    const bool wb = !BN && a.write_back && act != BCNN_HIP_ACT_NONE;
     // gradient rows [r0, r1) are the band's own; stride 1: the same rows of x / dx, stride 2: x / dx rows [2 r0, min(2 r1, H))
     const int r0 = m.bi * a.g.len, r1 = m.on ? min(r0 + a.g.len, a.OH) : r0;
     float acc[kDwmPart];
@@ -398,16 +408,16 @@ __global__ __launch_bounds__(256) void dwm_bwd_kernel(const DwmBwdArgs a) {
         float g = gin;
         if (BN) {
             g = __fmul_rn(g, kb.sc);
-            if (kb.sc0) g = 0.f;
+            if (kb.any_sc0 && kb.sc0) g = 0.f;
             const float t1 = bn_div(g, kb.rs);
             const float t2 = bn_div(__fmul_rn(kb.dv2, __fsub_rn(yv, kb.mean)), fM);
             g = __fadd_rn(__fadd_rn(t1, t2), kb.dm_m);
         }
-        if (a.act != BCNN_HIP_ACT_NONE) g *= act_bwd_cheap(yv, a.act, 0.f);
+        if (act != BCNN_HIP_ACT_NONE) g *= act_bwd_cheap(yv, act, 0.f);
         return g;
     };
     // the producer's activation passes this element (its derivative is 0 or 1: none / ReLU)
-    auto passes = [&](float y_in) -> bool { return act_bwd_cheap(y_in, a.in.act, 0.f) != 0.f; };
+    auto passes = [&](float y_in) -> bool { return act_bwd_cheap(y_in, in_act, 0.f) != 0.f; };
     struct Raw {
         Vals<GV> g, y;
     };
@@ -455,7 +465,7 @@ __global__ __launch_bounds__(256) void dwm_bwd_kernel(const DwmBwdArgs a) {
             const Row<V> Cr = make_g(gc, r + 1 <= r1 ? r + 1 : -1);
             if (valid) {
                 Vals<V> xv = xraw;
-                if (BNIN) xv = dwm_bnin_v<V>(xraw, kin, a.in.act);
+                if (BNIN) xv = dwm_bnin_v<V>(xraw, kin, in_act);
                 // weight gradient from the rows of x this band owns: x[r][j] meets g[r - kh + 1][j - kw + 1]
 #pragma unroll
                 for (int c = 0; c < V; ++c) {
@@ -505,8 +515,8 @@ __global__ __launch_bounds__(256) void dwm_bwd_kernel(const DwmBwdArgs a) {
             const Row<GV> Cg = make_g(gc, r + 1 <= r1 ? r + 1 : -1);
             if (valid) {
                 Vals<V> x0 = xr0, x1 = xr1;
-                if (BNIN) x0 = dwm_bnin_v<V>(xr0, kin, a.in.act);
-                if (BNIN && odd_ok) x1 = dwm_bnin_v<V>(xr1, kin, a.in.act);
+                if (BNIN) x0 = dwm_bnin_v<V>(xr0, kin, in_act);
+                if (BNIN && odd_ok) x1 = dwm_bnin_v<V>(xr1, kin, in_act);
                 Vals<V> d0 = dwm_ld<V>(a.dx, xo, !a.overwrite), d1 = dwm_ld<V>(a.dx, xo + xrow, !a.overwrite && odd_ok);
 #pragma unroll
                 for (int j = 0; j < GV; ++j) {
@@ -603,12 +613,24 @@ bool depthwise_forward_march(const float* x, const float* w, const float* bias, 
 #ifdef BCNN_HIP_EXPERIMENT
     if (const char* e = getenv("BCNN_HIP_DWM_PF")) pf = atoi(e);
 #endif
-#define DWM_FWD_PF(SV, VV, BV)                                                           \
-    do {                                                                                 \
-        if (pf <= 1) dwm_fwd_kernel<SV, VV, BV, 1><<<blocks, 256, 0, st>>>(a);           \
-        else if (pf == 2) dwm_fwd_kernel<SV, VV, BV, 2><<<blocks, 256, 0, st>>>(a);      \
-        else dwm_fwd_kernel<SV, VV, BV, 4><<<blocks, 256, 0, st>>>(a);                   \
+    bool relu = act == BCNN_HIP_ACT_RELU && (!in || in->act == BCNN_HIP_ACT_RELU);
+    if (BCNN_EXP_ENV("BCNN_HIP_DWM_NORELU")) relu = false;  // A/B switch (experiment build only)
+#ifdef BCNN_HIP_EXPERIMENT
+#define DWM_FWD_PF(SV, VV, BV)                                                                      \
+    do {                                                                                            \
+        if (!relu) dwm_fwd_kernel<SV, VV, BV, 2, false><<<blocks, 256, 0, st>>>(a);                 \
+        else if (pf <= 1) dwm_fwd_kernel<SV, VV, BV, 1, true><<<blocks, 256, 0, st>>>(a);           \
+        else if (pf == 2) dwm_fwd_kernel<SV, VV, BV, 2, true><<<blocks, 256, 0, st>>>(a);           \
+        else dwm_fwd_kernel<SV, VV, BV, 4, true><<<blocks, 256, 0, st>>>(a);                        \
     } while (0)
+#else
+#define DWM_FWD_PF(SV, VV, BV)                                                                      \
+    do {                                                                                            \
+        if (!relu) dwm_fwd_kernel<SV, VV, BV, 2, false><<<blocks, 256, 0, st>>>(a);                 \
+        else dwm_fwd_kernel<SV, VV, BV, 2, true><<<blocks, 256, 0, st>>>(a);                        \
+    } while (0)
+    (void)pf;
+#endif
 #define DWM_FWD(SV, VV)                      \
     do {                                     \
         if (in) DWM_FWD_PF(SV, VV, true);    \
@@ -656,12 +678,19 @@ bool depthwise_backward_march(const float* x, const float* w, const float* y, fl
     }
     const unsigned waves = (unsigned)ceil_div(a.g.bands, a.g.G), blocks = (waves + 3) / 4;
     hipStream_t st = current_stream();
-#define DWM_LAUNCH(SV, VV)                                                                   \
-    do {                                                                                     \
-        if (bn && in) dwm_bwd_kernel<SV, VV, true, true><<<blocks, 256, 0, st>>>(a);         \
-        else if (bn) dwm_bwd_kernel<SV, VV, true, false><<<blocks, 256, 0, st>>>(a);         \
-        else if (in) dwm_bwd_kernel<SV, VV, false, true><<<blocks, 256, 0, st>>>(a);         \
-        else dwm_bwd_kernel<SV, VV, false, false><<<blocks, 256, 0, st>>>(a);                \
+    bool relu = act == BCNN_HIP_ACT_RELU && (!in || in->act == BCNN_HIP_ACT_RELU);
+    if (BCNN_EXP_ENV("BCNN_HIP_DWM_NORELU")) relu = false;  // A/B switch (experiment build only)
+#define DWM_LAUNCH_R(SV, VV, RV)                                                                 \
+    do {                                                                                         \
+        if (bn && in) dwm_bwd_kernel<SV, VV, true, true, RV><<<blocks, 256, 0, st>>>(a);         \
+        else if (bn) dwm_bwd_kernel<SV, VV, true, false, RV><<<blocks, 256, 0, st>>>(a);         \
+        else if (in) dwm_bwd_kernel<SV, VV, false, true, RV><<<blocks, 256, 0, st>>>(a);         \
+        else dwm_bwd_kernel<SV, VV, false, false, RV><<<blocks, 256, 0, st>>>(a);                \
+    } while (0)
+#define DWM_LAUNCH(SV, VV)                     \
+    do {                                       \
+        if (relu) DWM_LAUNCH_R(SV, VV, true);  \
+        else DWM_LAUNCH_R(SV, VV, false);      \
     } while (0)
     if (s.stride == 1) {
         if (a.g.V == 4) DWM_LAUNCH(1, 4);
@@ -672,6 +701,7 @@ bool depthwise_backward_march(const float* x, const float* w, const float* y, fl
         else DWM_LAUNCH(2, 2);
     }
 #undef DWM_LAUNCH
+#undef DWM_LAUNCH_R
     KERNEL_CHECK();
     dwl_finalize_launch(a.partials, splits, s.C, dw, dbias, st);
     return true;
