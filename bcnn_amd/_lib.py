@@ -91,6 +91,7 @@ SIGNATURES = {
     "bcnn_hip_depthwise_backward_bnin_sums": (i, [vp] * 7 + [i] * 9 + [vp] * 5 + [vp] * 4 + [i] + [vp, sz]),
     "bcnn_hip_conv_backward_presummed": (i, [vp] * 8 + [i] * 10 + [vp, vp, i] + [vp] * 8 + [vp, sz] + [vp, i] + [vp, vp, vp, sz]),
     "bcnn_hip_conv_prepack_reset": (None, []),
+    "bcnn_hip_conv_prepack_discard": (None, []),
     "bcnn_hip_maxpool_bn_fusable": (i, [i] * 9 + [vp]),
     "bcnn_hip_conv_forward_stats_only": (None, [vp, vp, vp] + [i] * 9 + [vp] * 6),
     "bcnn_hip_maxpool_forward_bn": (None, [vp, vp, vp] + [i] * 8 + [vp] * 4 + [i]),

@@ -244,6 +244,8 @@ void bcnn_hip_conv_prepack(const bcnn_hip_conv_desc* layers, int count, int data
     }
 }
 
+void bcnn_hip_conv_prepack_discard(void) { ++g_prepack.epoch; }
+
 void bcnn_hip_conv_prepack_reset(void) {
     PrepackStore& st = g_prepack;
     if (st.dev < 0) return;

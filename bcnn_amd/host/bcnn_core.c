@@ -179,19 +179,28 @@ static void invalidate_sgd_table(bcnn_net *net) {
     hc->num_fill_chunks = -1; /* not built */
 }
 
+static void relink_graph(bcnn_net *net);
+
 bcnn_status bcnn_net_add_node(bcnn_net *net, bcnn_node node) {
+    bcnn_hip_context *hc = hctx(net);
+    /* A compiled net carries node-to-node links that were proven on the OLD graph (a convolution node that stops after its
+     * statistics because the eltwise / pooling / depthwise node behind it is its only reader, fused backward pairs, ...).
+     * The new node may read one of those unwritten tensors or be a second writer of a gradient. Values a fused pass left
+     * pending are produced now, under the old links; the links are re-derived below on the graph with the node in it. */
+    if (hc && hc->compiled) {
+        bcnn_materialize_data(net, -1);
+        bcnn_materialize_gradients(net, -1);
+    }
     bcnn_node *p = (bcnn_node *)realloc(net->nodes, (size_t)(net->num_nodes + 1) * sizeof(bcnn_node));
     if (!p) return BCNN_FAILED_ALLOC;
     net->nodes = p;
     net->nodes[net->num_nodes++] = node;
     invalidate_sgd_table(net); /* the new node's parameters are not in the cached one-launch table */
-    if (hctx(net)) { /* per-node arena offsets are rebuilt by the next bcnn_compile_net; until then one final range */
-        free(hctx(net)->node_grad_first);
-        hctx(net)->node_grad_first = NULL;
-        /* the dead-fill / sole-writer marks were proven on the OLD graph: the new node may be a second writer of a
-         * gradient whose fill was elided (its contribution would be overwritten by the `0 + sum` assignment of the
-         * former sole writer). Until the next compile every fill is live and nobody is a sole writer. */
-        hctx(net)->grad_fill_count = 0;
+    if (hc) { /* per-node arena offsets are rebuilt by the next bcnn_compile_net; until then one final range */
+        free(hc->node_grad_first);
+        hc->node_grad_first = NULL;
+        if (hc->compiled) relink_graph(net); /* dead-fill / sole-writer marks and fusion links: functions of the graph */
+        else hc->grad_fill_count = 0;
     }
     return BCNN_SUCCESS;
 }
@@ -448,6 +457,15 @@ bcnn_status bcnn_compile_net(bcnn_net *net) {
         if (hc->grad_ready_fn) bcnn_set_gradient_ready_callback(net, hc->grad_ready_fn, hc->grad_ready_user);
         comm_sync_parameters(net); /* communicator installed before the arena existed / new parameters appeared */
     }
+    relink_graph(net);
+    bcnn_hip_sync();
+    return BCNN_SUCCESS;
+}
+
+/* everything bcnn_compile_net derives from the graph alone: which gradient fills are dead, who is a sole writer, and the
+ * node-to-node fusion links (each link pass starts from "no link"). Also run by bcnn_net_add_node on a compiled net. */
+static void relink_graph(bcnn_net *net) {
+    bcnn_hip_context *hc = hctx(net);
     mark_dead_grad_fills(net);
     bcnn_link_depthwise_batchnorm(net);
     bcnn_link_conv_eltwise(net);
@@ -460,8 +478,6 @@ bcnn_status bcnn_compile_net(bcnn_net *net) {
         hc->fill_chunks_gpu = NULL;
     }
     hc->num_fill_chunks = -1;
-    bcnn_hip_sync();
-    return BCNN_SUCCESS;
 }
 
 bcnn_status bcnn_set_mode(bcnn_net *net, bcnn_mode mode) {
@@ -522,6 +538,7 @@ void bcnn_forward(bcnn_net *net) {
     hc->in_pass = 1;
     for (int i = 0; i < net->num_nodes; ++i) net->nodes[i].forward(net, &net->nodes[i]);
     hc->in_pass = 0;
+    bcnn_hip_conv_prepack_discard(); /* a copy no node of this pass consumed must not meet later (rewritten) weights */
 }
 
 /* in-library data parallelism: the gradient-ready callback of bcnn_set_data_parallel_comm */
@@ -553,6 +570,7 @@ void bcnn_backward(bcnn_net *net) {
         }
     }
     hc->in_pass = 0;
+    bcnn_hip_conv_prepack_discard(); /* before bcnn_update rewrites the weights an unused copy was made from */
     if (hc->grad_ready_fn && ready_from > 0 && hc->arena_size > 0)  /* members no node claims (none today) */
         hc->grad_ready_fn(0, ready_from, hc->grad_ready_user);
     if (hc->comm_active) {
@@ -724,8 +742,18 @@ static float current_loss(bcnn_net *net) {
     return n ? loss / n : 0.f;
 }
 
+/* forward / backward / update return nothing (reference bcnn_net.c:455-488); a batch that could not be read is fatal in the
+ * reference's convention for unrecoverable errors (print and exit, bcnn_utils.h:174-195), not a step on stale tensors */
+static void next_batch_or_die(bcnn_net *net) {
+    const bcnn_status st = bcnn_loader_next(net);
+    if (st != BCNN_SUCCESS) {
+        fprintf(stderr, "[bcnn] the data loader could not fill a batch (status %d)\n", (int)st);
+        exit(1);
+    }
+}
+
 float bcnn_train_on_batch(bcnn_net *net) {
-    bcnn_loader_next(net);
+    next_batch_or_die(net);
     bcnn_forward(net);
     bcnn_backward(net);
     bcnn_update(net);
@@ -733,7 +761,7 @@ float bcnn_train_on_batch(bcnn_net *net) {
 }
 
 float bcnn_predict_on_batch(bcnn_net *net, bcnn_tensor **out) {
-    bcnn_loader_next(net);
+    next_batch_or_die(net);
     bcnn_forward(net);
     const bcnn_node *last = &net->nodes[net->num_nodes - 1];
     const int out_id = (last->type == BCNN_LAYER_COST) ? last->src[0] : last->dst[0];

@@ -18,8 +18,9 @@
  *   - bcnn_augment_data_with_distortion stores `distortion`, not `max_distortion`: it enables nothing;
  *   - a shifted or rotated sample is composed over a buffer filled with 128 / 0 respectively;
  *   - the readers wrap around at end of file, and switching to VALID / PREDICT mode rewinds the test streams.
- * Not built: Perlin distortion and random spotlights (INI keys max_distortion / max_spots). Their parameter draws still
- * consume rand() like the reference so that the other augmentations stay aligned; the image is left untouched.
+ * Not built: Perlin distortion and random spotlights (INI keys max_distortion / max_spots). Their draws still consume
+ * rand() call for call like the reference (parameters, the distortion's own seed, four values per spot), so that the other
+ * augmentations stay aligned; the image is left untouched and a warning is printed once.
  */
 #include <string.h>
 
@@ -120,12 +121,28 @@ bcnn_status bcnn_apply_data_augmentation(unsigned char *img, int width, int heig
                           : (p->brightness = (int)rand_span((float)p->min_brightness, (float)p->max_brightness));
         bip_image_brightness(img, stride, width, height, depth, img, stride, b);
     }
-    if (p->max_distortion > 0.0f && !p->use_precomputed) { /* not built: keep the generator aligned */
-        p->distortion_kx = ((float)rand() - RAND_MAX / 2) / RAND_MAX;
-        p->distortion_ky = ((float)rand() - RAND_MAX / 2) / RAND_MAX;
-        p->distortion = ((float)rand() / RAND_MAX) * p->max_distortion;
+    /* Not built: Perlin distortion and random spotlights. Their draws are consumed exactly as the reference consumes them,
+     * so that the samples behind this one see the generator in the reference's state: three parameters (when not
+     * precomputed) plus the seed bip_image_perlin_distortion draws for itself on every call (bip.c:212); the spot count
+     * plus four values per spot (mu_x, mu_y, sigma_x, sigma_y: bip.c:294-298). */
+    if (p->max_distortion > 0.0f) {
+        if (!p->use_precomputed) {
+            p->distortion_kx = ((float)rand() - RAND_MAX / 2) / RAND_MAX;
+            p->distortion_ky = ((float)rand() - RAND_MAX / 2) / RAND_MAX;
+            p->distortion = ((float)rand() / RAND_MAX) * p->max_distortion;
+        }
+        (void)rand();
     }
-    if (p->max_random_spots > 0) (void)rand_between(0, p->max_random_spots); /* not built */
+    if (p->max_random_spots > 0) {
+        const int spots = rand_between(0, p->max_random_spots);
+        for (int i = 0; i < 4 * spots; ++i) (void)rand();
+    }
+    static int warned = 0;
+    if ((p->max_distortion > 0.0f || p->max_random_spots > 0) && !warned) {
+        warned = 1;
+        fprintf(stderr, "[bcnn] max_distortion / max_spots: Perlin distortion and random spotlights are not built; samples keep "
+                        "their pixels (the random stream stays aligned with the reference)\n");
+    }
     return BCNN_SUCCESS;
 }
 
@@ -243,6 +260,14 @@ static bcnn_status mnist_header(bcnn_net *net, bcnn_loader *it) {
     const uint32_t images = be32(h + 4);
     it->input_height = (int)be32(h + 8);
     it->input_width = (int)be32(h + 12);
+    /* the sample buffer is sized from these two and the network input is cut out of it: neither can be empty or absurd, and
+     * the input cannot be larger than the stored sample (the reference reads past the sample there) */
+    if (it->input_height < 1 || it->input_width < 1 || it->input_height > 4096 || it->input_width > 4096 ||
+        net->tensors[0].h > it->input_height || net->tensors[0].w > it->input_width) {
+        bcnn_log(net->log_ctx, BCNN_LOG_ERROR, "Mnist header: %d x %d samples do not fit the %d x %d network input\n",
+                 it->input_width, it->input_height, net->tensors[0].w, net->tensors[0].h);
+        return BCNN_INVALID_DATA;
+    }
     if (fread(h, 1, 8, it->f_current_extra) != 8) goto corrupt;
     if (images != be32(h + 4)) {
         bcnn_log(net->log_ctx, BCNN_LOG_ERROR,
@@ -466,11 +491,14 @@ bcnn_status bcnn_set_data_loader(bcnn_net *net, bcnn_loader_type type, const cha
     if (!it) return BCNN_FAILED_ALLOC;
     it->type = type;
     net->data_loader = it;
+    bcnn_status st;
     switch (type) {
-        case BCNN_LOAD_MNIST: return mnist_init(it, net, train_path_data, train_path_extra, test_path_data, test_path_extra);
-        case BCNN_LOAD_CIFAR10: return cifar10_init(it, net, train_path_data, train_path_extra, test_path_data, test_path_extra);
-        default: return list_init(it, net, train_path_data, train_path_extra, test_path_data, test_path_extra);
+        case BCNN_LOAD_MNIST: st = mnist_init(it, net, train_path_data, train_path_extra, test_path_data, test_path_extra); break;
+        case BCNN_LOAD_CIFAR10: st = cifar10_init(it, net, train_path_data, train_path_extra, test_path_data, test_path_extra); break;
+        default: st = list_init(it, net, train_path_data, train_path_extra, test_path_data, test_path_extra); break;
     }
+    if (st != BCNN_SUCCESS) bcnn_destroy_data_loader(net); /* no half-opened loader for a later bcnn_loader_next to trip over */
+    return st;
 }
 
 /* One batch: samples on the host, then the reference's host -> device hook (bcnn_data.c:398-427). A sample that cannot be

@@ -272,11 +272,12 @@ void bcnn_backward_conv_layer(bcnn_net *net, bcnn_node *node) {
  * (the nodes' own calls would each pack right before their kernel: ~40 launches of ~5 us per ResNet-18 step).
  * data_gradient = 0: forward forms; 1: data-gradient forms, of the nodes whose source carries a gradient. */
 void bcnn_prepack_conv_weights(bcnn_net *net, int data_gradient) {
-    enum { MAXL = 256 };
-    bcnn_hip_conv_desc d[MAXL];
     int n = 0;
     if (BCNN_EXP_ENV("BCNN_NO_PREPACK")) return; /* A/B switch of the experiment build: every node packs for itself */
-    for (int i = 0; i < net->num_nodes && n < MAXL; ++i) {
+    if (net->num_nodes < 1) return;
+    bcnn_hip_conv_desc *d = (bcnn_hip_conv_desc *)malloc((size_t)net->num_nodes * sizeof(*d));
+    if (!d) return; /* every node then packs for itself */
+    for (int i = 0; i < net->num_nodes; ++i) {
         bcnn_node *node = &net->nodes[i];
         if (node->type != BCNN_LAYER_CONV2D) continue;
         const bcnn_conv_param *p = (const bcnn_conv_param *)node->param;
@@ -288,6 +289,7 @@ void bcnn_prepack_conv_weights(bcnn_net *net, int data_gradient) {
         ++n;
     }
     if (n > 0) bcnn_hip_conv_prepack(d, n, data_gradient);
+    free(d);
 }
 
 void bcnn_update_conv_layer(bcnn_net *net, bcnn_node *node) { /* reference bcnn_conv_layer.c:810-855 */

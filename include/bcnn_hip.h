@@ -225,6 +225,8 @@ typedef struct {
 } bcnn_hip_conv_desc;
 void bcnn_hip_conv_prepack(const bcnn_hip_conv_desc *layers, int count, int data_gradient);
 void bcnn_hip_conv_prepack_reset(void);
+/* every copy made so far and not consumed is stale from here on (end of a pass: the weights may be rewritten next) */
+void bcnn_hip_conv_prepack_discard(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Pooling.  Replaces bcnn_forward/backward_maxpool_layer_gpu (bcnn_maxpool_layer.cu:28-166) and

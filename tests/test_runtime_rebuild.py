@@ -236,3 +236,55 @@ def test_second_consumer_added_after_compile_keeps_its_gradient_without_a_recomp
     assert np.abs(a).max() > 0
     assert np.array_equal(a, b)
     whole.close(); grown.close()
+
+
+def test_reader_of_a_fused_away_tensor_added_after_compile_sees_its_values():
+    """the fusion links of the last compile outlived bcnn_net_add_node. conv(+batch-norm, ReLU) -> maxpool
+    links the pair in a TRAIN net: the convolution stops after its batch statistics, the pooling kernel normalises on the
+    fly and the convolution's output tensor is never written. A global avg-pool over that tensor appended afterwards read
+    stale memory until the next compile. add_node now re-derives the links on the graph with the new node in it: the
+    un-recompiled net equals the net built in one go, forward and backward, over two passes."""
+    from bcnn_amd import capi
+
+    def head(net):
+        net.conv(8, 3, 1, 1, 1, 1, capi.ACT_RELU, "input", "c1")   # fused batch-norm: the conv -> maxpool link applies
+        net.maxpool(2, 2, capi.PADDING_SAME, "c1", "p1")
+
+    def tail(net):
+        net.avgpool("c1", "gap")
+
+    def run(net, x, seed):
+        rs = np.random.RandomState(seed)
+        net.data(0)[...] = x; net.upload(0)
+        net.forward()
+        out = {}
+        for name in ("p1", "gap"):
+            i = net.index(name)
+            net.download(i)
+            out[name] = net.data(i).copy()
+            net.grad(i)[...] = rs.uniform(-1, 1, net.shape(i)).astype(np.float32)
+            net.upload(i, with_grad=True)
+        net.backward(); net.sync()
+        i = net.index("input_w")
+        net.download(i, with_grad=True)
+        out["dw"] = net.grad(i).copy()
+        return out
+
+    shp = dict(w=12, h=12, c=3, n=2)
+    C.CDLL(None).srand(5)
+    whole = capi.Net(mode=capi.MODE_TRAIN, **shp)
+    head(whole); tail(whole); whole.compile()
+    C.CDLL(None).srand(5)
+    grown = capi.Net(mode=capi.MODE_TRAIN, **shp)
+    head(grown); grown.compile()
+    x0 = np.random.RandomState(0).uniform(-1, 1, (2, 3, 12, 12)).astype(np.float32)
+    grown.data(0)[...] = x0; grown.upload(0)
+    grown.forward(); grown.sync()                      # one linked pass: c1 is pending, not written
+    tail(grown)                                        # NOT recompiled
+    for seed in (1, 2):
+        x = np.random.RandomState(seed).uniform(-1, 1, (2, 3, 12, 12)).astype(np.float32)
+        a, b = run(whole, x, seed), run(grown, x, seed)
+        assert np.abs(a["gap"]).max() > 0 and np.abs(a["dw"]).max() > 0
+        for k in a:
+            assert np.array_equal(a[k], b[k]), (seed, k)
+    whole.close(); grown.close()
