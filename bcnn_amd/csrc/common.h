@@ -42,7 +42,8 @@ enum KClass { K_CONV_FWD = 0, K_CONV_DW, K_CONV_DX, K_BN_FWD, K_BN_BWD, K_POOL, 
               K_NUM };
 struct KTimer {
     int idx;
-    KTimer(int cls, double flops, double bytes);
+    // useful_flops: the part of `flops` that is not padding (Winograd tiles hanging over an odd-sized plane); < 0: all of it
+    KTimer(int cls, double flops, double bytes, double useful_flops = -1.0);
     ~KTimer();
 };
 

@@ -352,6 +352,8 @@ static double wino_flops(const ConvShape& s) {
     const double T = (double)s.N * ((s.H + 1) / 2) * ((s.W + 1) / 2);
     return 2.0 * 16.0 * T * s.C * s.F;
 }
+// the same without the tiles' overhang on odd-sized planes (7 x 7: 16 tiles cover 8 x 8)
+static double wino_useful_flops(const ConvShape& s) { return 2.0 * 16.0 * ((double)s.N * s.H * s.W / 4.0) * s.C * s.F; }
 static double wino_bytes(const ConvShape& s) {
     return 4.0 * ((double)s.N * s.C * s.HW + (double)s.F * s.K + (double)s.N * s.F * s.OHOW);
 }
@@ -362,7 +364,7 @@ bool conv_winograd_unfused_takes(const ConvShape& s) { return wino_applicable(s)
 bool conv_forward_winograd(const float* x, const float* w, const float* bias, const float* slopes, float* y,
                            const ConvShape& s, int act, int raw, ConvStats* stats) {
     if (!wino_applicable(s) || !wino_profitable(s)) return false;
-    KTimer kt(K_CONV_FWD_WINO, wino_flops(s), wino_bytes(s));
+    KTimer kt(K_CONV_FWD_WINO, wino_flops(s), wino_bytes(s), wino_useful_flops(s));
     const bool plain = raw || (bias == nullptr && act == BCNN_HIP_ACT_NONE);
     // raw output for a fused batch-norm: the output transform also emits the per-channel statistics partials
     // (ceil(T / 256) <= ceil(N*OH*OW / 64) entries per channel: inside the buffer conv.hip sized)
@@ -375,7 +377,7 @@ bool conv_backward_data_winograd(const float* w, const float* dy, float* dx, con
     if (!wino_applicable(s) || !wino_profitable(s)) return false;
     // dX is itself a 3x3 / s1 / p1 convolution of dy [N][F][H][W] with F and C swapped
     if (s.F < 16 || s.C < 64) return false;
-    KTimer kt(K_CONV_DX_WINO, wino_flops(s), wino_bytes(s));
+    KTimer kt(K_CONV_DX_WINO, wino_flops(s), wino_bytes(s), wino_useful_flops(s));
     wino_run(dy, w, dx, s, /*dx_mode=*/1, nullptr, nullptr, BCNN_HIP_ACT_NONE, true);
     return true;
 }
@@ -402,7 +404,7 @@ bool conv_backward_weights_winograd(const float* x, const float* dy, float* dw, 
     const ConvShape gs = wino_dw_gemm_shape(s);
     const size_t need = conv_dw_dma_workspace_floats(gs);
     if (need == 0) return false;
-    KTimer kt(K_CONV_DW_WINO, wino_flops(s), wino_bytes(s));
+    KTimer kt(K_CONV_DW_WINO, wino_flops(s), wino_bytes(s), wino_useful_flops(s));
     WinoGeom g;
     g.N = s.N; g.C = s.C; g.H = s.H; g.W = s.W;
     g.TH = (s.H + 1) / 2; g.TW = (s.W + 1) / 2;

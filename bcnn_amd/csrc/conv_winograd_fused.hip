@@ -1153,6 +1153,8 @@ static double wf_flops(const ConvShape& s) {
     const double T = (double)s.N * ((s.H + 1) / 2) * ((s.W + 1) / 2);
     return 2.0 * 16.0 * T * s.C * s.F;
 }
+// the same without the tiles' overhang on odd-sized planes (7 x 7: 16 tiles cover 8 x 8)
+static double wf_useful_flops(const ConvShape& s) { return 2.0 * 16.0 * ((double)s.N * s.H * s.W / 4.0) * s.C * s.F; }
 static double wf_bytes(const ConvShape& s) {
     return 4.0 * ((double)s.N * s.C * s.HW + (double)s.F * s.K + (double)s.N * s.F * s.OHOW);
 }
@@ -1160,7 +1162,7 @@ static double wf_bytes(const ConvShape& s) {
 bool conv_forward_winograd_fused(const float* x, const float* w, const float* bias, const float* slopes, float* y,
                                  const ConvShape& s, int act, int raw, ConvStats* stats) {
     if (!wino_fused_wanted(s, s.C, s.F)) return false;
-    KTimer kt(K_CONV_FWD_WINO, wf_flops(s), wf_bytes(s));
+    KTimer kt(K_CONV_FWD_WINO, wf_flops(s), wf_bytes(s), wf_useful_flops(s));
     if (stats && !raw) stats->splits = 0;
     wino_fused_run(x, w, y, s, 0, bias, slopes, raw ? BCNN_HIP_ACT_NONE : act, raw ? 0 : (bias != nullptr), raw ? stats : nullptr);
     return true;
@@ -1168,7 +1170,7 @@ bool conv_forward_winograd_fused(const float* x, const float* w, const float* bi
 
 bool conv_backward_data_winograd_fused(const float* w, const float* dy, float* dx, const ConvShape& s) {
     if (!wino_fused_wanted(s, s.F, s.C)) return false;
-    KTimer kt(K_CONV_DX_WINO, wf_flops(s), wf_bytes(s));
+    KTimer kt(K_CONV_DX_WINO, wf_flops(s), wf_bytes(s), wf_useful_flops(s));
     wino_fused_run(dy, w, dx, s, 1, nullptr, nullptr, BCNN_HIP_ACT_NONE, 0, nullptr);
     return true;
 }
@@ -1528,7 +1530,7 @@ bool conv_backward_weights_winograd_fused(const float* x, const float* dy, float
                 p.partial_floats);
         exit(1);
     }
-    KTimer kt(K_CONV_DW_WINO, wf_flops(s), wf_bytes(s));
+    KTimer kt(K_CONV_DW_WINO, wf_flops(s), wf_bytes(s), wf_useful_flops(s));
     WinoDwArgs a;
     a.x = x; a.dy = dy; a.partials = workspace;
     a.N = s.N; a.C = s.C; a.F = s.F; a.H = s.H; a.W = s.W; a.TH = (s.H + 1) / 2; a.TW = (s.W + 1) / 2;

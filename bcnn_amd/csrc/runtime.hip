@@ -12,7 +12,7 @@ hipStream_t current_stream() { return g_stream; }
 void set_current_stream(hipStream_t st) { g_stream = st; }  // internal: side-stream sections (conv.hip)
 
 // ---- per-kernel-class event timing ---------------------------------------------------------------
-struct KRecord { int cls; hipEvent_t a, b; double flops, bytes; };
+struct KRecord { int cls; hipEvent_t a, b; double flops, bytes, useful; };
 static thread_local bool g_prof_on = false;
 static thread_local std::vector<KRecord>* g_records = nullptr;
 static thread_local std::vector<hipEvent_t>* g_event_pool = nullptr;
@@ -23,10 +23,10 @@ static hipEvent_t pool_event() {
     HIP_CHECK(hipEventCreate(&e));
     return e;
 }
-KTimer::KTimer(int cls, double flops, double bytes) : idx(-1) {
+KTimer::KTimer(int cls, double flops, double bytes, double useful_flops) : idx(-1) {
     if (!g_prof_on) return;
     if (!g_records) g_records = new std::vector<KRecord>();
-    KRecord r{cls, pool_event(), pool_event(), flops, bytes};
+    KRecord r{cls, pool_event(), pool_event(), flops, bytes, useful_flops < 0 ? flops : useful_flops};
     HIP_CHECK(hipEventRecord(r.a, g_stream));
     idx = (int)g_records->size();
     g_records->push_back(r);
@@ -231,6 +231,14 @@ void bcnn_hip_profile_read(int cls, double* ms, long long* launches, double* flo
     if (launches) *launches = n;
     if (flops) *flops = f;
     if (bytes) *bytes = b;
+}
+
+double bcnn_hip_profile_read_useful_flops(int cls) {
+    double u = 0;
+    if (g_records)
+        for (auto& r : *g_records)
+            if (r.cls == cls) u += r.useful;
+    return u;
 }
 
 }  // extern "C"

@@ -94,7 +94,7 @@ def cpu_baseline(workload, sample_n):
     import numpy as np
     from oracle import ref_bind as rb
     if not rb.available():
-        return {"value": None, "unit": "images/s", "cores": 0, "kind": "reference",
+        return {"value": None, "unit": "images/s", "cores": 0, "host_cores": os.cpu_count(), "kind": "reference",
                 "sample": "oracle/_ref/libbcnn_ref.so not present on this host"}
     rs = np.random.RandomState(0)
     best = None
@@ -116,9 +116,10 @@ def cpu_baseline(workload, sample_n):
         if best is None or t < best[0]:
             best = (t, threads)
     t, threads = best
-    return {"value": round(sample_n / t, 2), "unit": "images/s", "cores": int(threads), "kind": "reference",
+    return {"value": round(sample_n / t, 2), "unit": "images/s", "cores": int(threads), "host_cores": ncpu, "kind": "reference",
             "sample": "unmodified reference (oracle/_ref, AVX2+OpenMP, in-tree gemm), same %s graph at N=%d, "
-                      "bcnn_forward+bcnn_backward, best of 2 after 1 warm-up, best OpenMP team of {8,16,32}"
+                      "bcnn_forward+bcnn_backward, best of 2 after 1 warm-up, best OpenMP team of {8,16,32} "
+                      "(`cores` = that team, `host_cores` = os.cpu_count())"
                       % (workload, sample_n)}
 
 
@@ -129,7 +130,8 @@ def read_profile(L):
         L.bcnn_hip_profile_read(cls, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by))
         if n.value:
             out[L.bcnn_hip_profile_class_name(cls).decode()] = dict(ms=ms.value, launches=n.value, flops=fl.value,
-                                                                    bytes=by.value)
+                                                                    bytes=by.value,
+                                                                    useful_flops=L.bcnn_hip_profile_read_useful_flops(cls))
     return out
 
 
@@ -191,7 +193,7 @@ def roofline_of(prof, workload, traffic_ok):
     fw, dx = prof.pop("conv_fwd_winograd", None), prof.pop("conv_dx_winograd", None)
     if fw or dx:
         parts = [p for p in (fw, dx) if p]
-        prof["conv_fwd_dx_winograd"] = {k: sum(p[k] for p in parts) for k in ("ms", "launches", "flops", "bytes")}
+        prof["conv_fwd_dx_winograd"] = {k: sum(p[k] for p in parts) for k in ("ms", "launches", "flops", "bytes", "useful_flops")}
     name, d = max(prof.items(), key=lambda kv: kv[1]["ms"])
     avg_ms = d["ms"] / d["launches"]
     tf = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["flops"] else 0.0
@@ -211,6 +213,9 @@ def roofline_of(prof, workload, traffic_ok):
         # multiplies per 2x2 outputs: DESIGN.md section 4.8); the direct-convolution count of the same layers is 2.25x that
         roof["flops_counted"] = "executed (Winograd transformed domain); direct-equivalent rate = 2.25 x achieved"
         roof["direct_equivalent_tflops"] = round(2.25 * tf, 2)
+        # `frac` counts what the MFMAs execute, tile padding included (7 x 7 planes: 16 tiles cover 8 x 8);
+        # frac_unpadded counts only the multiplies of tiles' cells that exist
+        roof["frac_unpadded"] = round(d.get("useful_flops", d["flops"]) / (d["ms"] * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4)
     roof.update({"traffic": traffic, "traffic_source": source, "launches": d["launches"], "avg_ms": round(avg_ms, 4),
                  "algorithmic_flops_per_launch": d["flops"] / d["launches"],
                  "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],

@@ -70,6 +70,8 @@ void bcnn_hip_profile_reset(void);
 int bcnn_hip_profile_num_classes(void);
 const char *bcnn_hip_profile_class_name(int cls);
 void bcnn_hip_profile_read(int cls, double *ms, long long *launches, double *flops, double *bytes);
+/* the part of the class's `flops` that is not tile padding (Winograd classes on odd-sized planes; otherwise == flops) */
+double bcnn_hip_profile_read_useful_flops(int cls);
 
 /* ---------------------------------------------------------------------------------------------
  * BLAS-1 / per-channel helpers.  Replaces bcnn_cuda_axpy/scal/copy (bcnn_mat.cu:44-100),

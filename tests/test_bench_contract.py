@@ -39,3 +39,6 @@ def test_bench_prints_the_contract_line(workload):
         assert "workloads" not in d
     cpu = d["cpu_baseline"]
     assert cpu["kind"] in ("reference", "port") and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["sample"]
+    assert cpu["host_cores"] == os.cpu_count()
+    if "winograd" in roof["kernel"]:
+        assert 0 < roof["frac_unpadded"] <= roof["frac"]
