@@ -248,3 +248,39 @@ def test_plain_c_program_trains_data_parallel_world2(tmp_path):
     assert all(p.returncode == 0 for p in procs), outs
     sums = sorted(ln.split("checksum")[-1] for o in outs for ln in o[0].splitlines() if ln.startswith("rank "))
     assert len(sums) == 2 and sums[0] == sums[1], outs
+
+
+@pytest.mark.gpu
+def test_plain_c_program_world2_on_one_gpu_over_a_test_double_of_rccl(tmp_path):
+    """World size 2 of the library's OWN collective path (bcnn_amd/csrc/comm.hip) where only one GPU exists: two processes
+    of tools/dp_train.c share the device, and `librccl.so.1` resolves to tests/fake_rccl (a test double that stages the
+    buffers through the host and exchanges them as files, sums in rank order). What runs for the first time before it meets
+    eight GPUs: the non-zero rank's poll for the id record (started FIRST here, so it really waits), rank 0's publish +
+    unlink after the collective ncclCommInitRank, the parameter broadcast, bucketed all-reduces from inside bcnn_backward
+    ordered against the compute stream, and the momentum carry / weight decay split over two ranks. The ranks see
+    different shards; identical parameter checksums at the end mean every gradient range was exchanged exactly once."""
+    fake = tmp_path / "fake"
+    fake.mkdir()
+    r = subprocess.run(["gcc", "-shared", "-fPIC", "-O1", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                        os.path.join(ROOT, "tests", "fake_rccl", "fake_rccl.c"), "-o", str(fake / "librccl.so.1"),
+                        "-L/opt/rocm/lib", "-lamdhip64"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    exe = _build_example(tmp_path)
+    idf = tmp_path / "w2.id"
+    env = dict(os.environ, BCNN_HIP_JOB_NONCE="fake-w2-%d" % os.getpid(), FAKE_RCCL_DIR=str(tmp_path),
+               LD_LIBRARY_PATH=str(fake) + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    import time
+    p1 = subprocess.Popen([exe, "1", "2", str(idf), "5"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    time.sleep(1.0)            # rank 1 is polling for a record that does not exist yet
+    p0 = subprocess.Popen([exe, "0", "2", str(idf), "5"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    outs = [p.communicate(timeout=600) for p in (p0, p1)]
+    assert p0.returncode == 0 and p1.returncode == 0, outs
+    lines = sorted(ln for o in outs for ln in o[0].splitlines() if ln.startswith("rank "))
+    assert len(lines) == 2 and lines[0].startswith("rank 0/2") and lines[1].startswith("rank 1/2"), outs
+    sums = [ln.split("checksum")[-1] for ln in lines]
+    assert sums[0] == sums[1] and "nan" not in sums[0], lines
+    assert not idf.exists()    # rank 0 removed the record once the communicator stood
+    # and the exchange mattered: one rank alone on its own shard ends somewhere else
+    solo = subprocess.run([exe, "0", "1", "-", "5", "nocomm"], capture_output=True, text=True, timeout=600)
+    assert solo.returncode == 0
+    assert solo.stdout.split("checksum")[-1].strip() != sums[0].strip()
