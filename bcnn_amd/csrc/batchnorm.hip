@@ -13,6 +13,49 @@
 
 namespace bcnn_hip {
 
+// ---- per-channel constants of an apply sweep ---------------------------------------------------------------------
+// The apply bodies need, per channel, sqrt(var + eps), its correctly rounded reciprocal, dmean / M ...: two square roots
+// and up to four IEEE divisions. Evaluated inside the map kernels (once per 16 bytes in the flat kernel, whose lanes
+// change channel every step) that was more vector-ALU work than the sweep's own arithmetic. The finalize kernel that
+// runs right before the sweep -- one thread per channel has mean, var, dmean, dvar in hand -- now leaves them in a small
+// table (same operations, same roundings: bit-identical results), and the bodies load three float4 per call.
+//   forward  [2c]   = {mean, rs6, 1 / rs6, scale}   [2c + 1] = {bias, -, -, -}                  rs6 = sqrt(var + 1e-6)
+//   backward [3c]   = {mean, scale, rs5, 1 / rs5}   [3c + 1] = {rs6, 1 / rs6, fwd bias, dmean / M}   [3c + 2] = {dvar, -, -, -}
+struct ConstScratch {
+    float4* p = nullptr;
+    size_t cap = 0;
+    int dev = -1;
+};
+static thread_local ConstScratch g_bn_consts;
+static float4* bn_consts_scratch(int channels) {  // grow-only, per host thread (= per stream): finalize -> apply only
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    const size_t need = (size_t)channels * 3;
+    if (g_bn_consts.p == nullptr || g_bn_consts.cap < need || g_bn_consts.dev != dev) {
+        if (g_bn_consts.p && g_bn_consts.dev == dev) HIP_CHECK(hipFree(g_bn_consts.p));  // hipFree syncs the device
+        const size_t cap = need < 4096 ? 4096 : need * 2;
+        HIP_CHECK(hipMalloc((void**)&g_bn_consts.p, cap * sizeof(float4)));
+        g_bn_consts.cap = cap;
+        g_bn_consts.dev = dev;
+    }
+    return g_bn_consts.p;
+}
+__device__ __forceinline__ void bn_fwd_consts_store(float4* consts, int c, float mean, float var, const float* scale,
+                                                    const float* bias) {
+    if (!consts) return;
+    const BnDiv rs = bn_divisor(sqrtf(var + 0.000001f));
+    consts[2 * c] = make_float4(mean, rs.d, rs.r, scale[c]);
+    consts[2 * c + 1] = make_float4(bias[c], 0.f, 0.f, 0.f);
+}
+__device__ __forceinline__ void bn_bwd_consts_store(float4* consts, int c, const float* mean, float var, float sc,
+                                                    const float* fwd_bias, float dmean, float dvar, float fM) {
+    if (!consts) return;
+    const BnDiv rs5 = bn_divisor(sqrtf(var + 0.00001f)), rs6 = bn_divisor(sqrtf(var + 0.000001f));
+    consts[3 * c] = make_float4(mean[c], sc, rs5.d, rs5.r);
+    consts[3 * c + 1] = make_float4(rs6.d, rs6.r, fwd_bias ? fwd_bias[c] : 0.f, __fdiv_rn(dmean, fM));
+    consts[3 * c + 2] = make_float4(dvar, 0.f, 0.f, 0.f);
+}
+
 // ---- forward statistics --------------------------------------------------------------------------
 struct StatsF {
     const float* x;
@@ -30,7 +73,9 @@ struct StatsF {
 
 __global__ void bn_stats_finalize_kernel(const float* __restrict__ partials, int C, int splits, int M,
                                          float* __restrict__ saved_mean, float* __restrict__ saved_var,
-                                         float* __restrict__ run_mean, float* __restrict__ run_var) {
+                                         float* __restrict__ run_mean, float* __restrict__ run_var,
+                                         float4* __restrict__ consts, const float* __restrict__ scale,
+                                         const float* __restrict__ bias) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double s = 0.0, ss = 0.0;
@@ -45,6 +90,7 @@ __global__ void bn_stats_finalize_kernel(const float* __restrict__ partials, int
     saved_var[c] = var;
     run_mean[c] = __fadd_rn(__fmul_rn(mean, 0.1f), __fmul_rn(run_mean[c], 0.9f));        // scal 0.9, axpy 0.1
     run_var[c] = __fadd_rn(__fmul_rn(var, 0.1f), __fmul_rn(run_var[c], 0.9f));
+    bn_fwd_consts_store(consts, c, mean, var, scale, bias);
 }
 
 // Same result for MANY partials per channel (the convolution epilogue emits one per column tile, up to a
@@ -53,7 +99,8 @@ __global__ void bn_stats_finalize_kernel(const float* __restrict__ partials, int
 constexpr int kFinalizeThreads = 1024;
 __global__ __launch_bounds__(kFinalizeThreads) void bn_stats_finalize_wide_kernel(
     const float* __restrict__ partials, int C, int splits, int M, float* __restrict__ saved_mean,
-    float* __restrict__ saved_var, float* __restrict__ run_mean, float* __restrict__ run_var) {
+    float* __restrict__ saved_var, float* __restrict__ run_mean, float* __restrict__ run_var,
+    float4* __restrict__ consts, const float* __restrict__ scale, const float* __restrict__ bias) {
     constexpr int NW = kFinalizeThreads / 64;
     __shared__ double red[NW][2];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -88,6 +135,7 @@ __global__ __launch_bounds__(kFinalizeThreads) void bn_stats_finalize_wide_kerne
     saved_var[c] = var;
     run_mean[c] = __fadd_rn(__fmul_rn(mean, 0.1f), __fmul_rn(run_mean[c], 0.9f));
     run_var[c] = __fadd_rn(__fmul_rn(var, 0.1f), __fmul_rn(run_var[c], 0.9f));
+    bn_fwd_consts_store(consts, c, mean, var, scale, bias);
 }
 
 // ---- forward apply ---------------------------------------------------------------------------------
@@ -109,15 +157,23 @@ struct BnApplyArgs {
     const float* res;
     unsigned res_count;
     int act2;
+    const float4* consts;  // per-channel constants left by the statistics finalize kernel (TRAIN), or NULL
 };
 
 struct BnApplyBody {
     BnApplyArgs a;
     bool al;
     __device__ void operator()(unsigned off, int c, int cnt) const {
-        const float mean = a.predict ? 0.f : a.mean[c];
-        const BnDiv rs = bn_divisor(a.predict ? 1.f : sqrtf(a.var[c] + 0.000001f));
-        const float sc = a.scale[c], b = a.bias[c];
+        float mean, sc, b;
+        BnDiv rs;
+        if (a.consts) {
+            const float4 k0 = a.consts[2 * c], k1 = a.consts[2 * c + 1];
+            mean = k0.x; rs.d = k0.y; rs.r = k0.z; sc = k0.w; b = k1.x;
+        } else {
+            mean = a.predict ? 0.f : a.mean[c];
+            rs = bn_divisor(a.predict ? 1.f : sqrtf(a.var[c] + 0.000001f));
+            sc = a.scale[c]; b = a.bias[c];
+        }
         const bool side_ws = a.ws && a.ws != a.x, side_xn = a.xn && !a.predict;
         if (cnt == 4 && al && (off & 3u) == 0) {
             const float4 xv = *reinterpret_cast<const float4*>(a.x + off);
@@ -223,7 +279,9 @@ struct BwdSumsF {
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int C, int splits,
                                        const float* __restrict__ scale, const float* __restrict__ var,
                                        float* __restrict__ dbias, float* __restrict__ dscales,
-                                       float* __restrict__ dmean, float* __restrict__ dvar) {
+                                       float* __restrict__ dmean, float* __restrict__ dvar,
+                                       float4* __restrict__ consts, const float* __restrict__ mean,
+                                       const float* __restrict__ fwd_bias, float fM) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double s1 = 0.0, s2 = 0.0;
@@ -240,6 +298,7 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int C
     vd *= -0.5f / (v * sqrtf(v) + 0.00001f);
     dmean[c] = md;
     dvar[c] = vd;
+    bn_bwd_consts_store(consts, c, mean, v, sc, fwd_bias, md, vd, fM);
 }
 
 // The same for MANY partials per channel (a 1x1 convolution's data-gradient epilogue emits one per 64 pixels): one workgroup
@@ -248,7 +307,9 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_wide_kernel(const float*
                                                                    const float* __restrict__ scale,
                                                                    const float* __restrict__ var, float* __restrict__ dbias,
                                                                    float* __restrict__ dscales, float* __restrict__ dmean,
-                                                                   float* __restrict__ dvar) {
+                                                                   float* __restrict__ dvar, float4* __restrict__ consts,
+                                                                   const float* __restrict__ mean,
+                                                                   const float* __restrict__ fwd_bias, float fM) {
     __shared__ double red[16][2];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, c = blockIdx.x;
     const float2* p = reinterpret_cast<const float2*>(partials) + (long long)c * splits;
@@ -281,6 +342,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_wide_kernel(const float*
     vd *= -0.5f / (v * sqrtf(v) + 0.00001f);
     dmean[c] = md;
     dvar[c] = vd;
+    bn_bwd_consts_store(consts, c, mean, v, sc, fwd_bias, md, vd, fM);
 }
 
 struct BnBwdApplyArgs {
@@ -299,19 +361,29 @@ struct BnBwdApplyArgs {
     int keep_dy;            // dy is only read; the result goes to dx alone
     const float* res;       // folded eltwise node (with fwd_bias), see bn_recompute_y
     unsigned res_count;
+    const float4* consts;   // per-channel constants left by the backward finalize kernel, or NULL
+    float rM;               // 1 / M, correctly rounded (host division)
 };
 
 struct BnBwdApplyBody {
     BnBwdApplyArgs a;
     bool al;
     __device__ void operator()(unsigned off, int c, int cnt) const {
-        const BnDiv fM = bn_divisor((float)a.M);
+        const BnDiv fM{(float)a.M, a.rM};
         const bool use_act = a.act != BCNN_HIP_ACT_NONE, use_y = use_act && a.fwd_bias == nullptr;
-        const float mean = a.mean[c], sc = a.scale[c];
-        const BnDiv rs = bn_divisor(sqrtf(a.var[c] + 0.00001f));
-        const BnDiv rs_fwd = bn_divisor(use_act && !use_y ? sqrtf(a.var[c] + 0.000001f) : 1.0f);
-        const float fb = a.fwd_bias ? a.fwd_bias[c] : 0.f;
-        const float dmm = __fdiv_rn(a.dmean[c], fM.d), dv = a.dvar[c];
+        float mean, sc, fb, dmm, dv;
+        BnDiv rs, rs_fwd;
+        if (a.consts) {
+            const float4 k0 = a.consts[3 * c], k1 = a.consts[3 * c + 1], k2 = a.consts[3 * c + 2];
+            mean = k0.x; sc = k0.y; rs.d = k0.z; rs.r = k0.w;
+            rs_fwd.d = k1.x; rs_fwd.r = k1.y; fb = k1.z; dmm = k1.w; dv = k2.x;
+        } else {
+            mean = a.mean[c]; sc = a.scale[c];
+            rs = bn_divisor(sqrtf(a.var[c] + 0.00001f));
+            rs_fwd = bn_divisor(use_act && !use_y ? sqrtf(a.var[c] + 0.000001f) : 1.0f);
+            fb = a.fwd_bias ? a.fwd_bias[c] : 0.f;
+            dmm = __fdiv_rn(a.dmean[c], fM.d); dv = a.dvar[c];
+        }
         if (cnt == 4 && al && (off & 3u) == 0) {
             const float4 g = *reinterpret_cast<const float4*>(a.dy + off);
             const float4 xv = *reinterpret_cast<const float4*>(a.x + off);
@@ -368,21 +440,23 @@ void batchnorm_forward_impl(const float* x, float* y, float* run_mean, float* ru
     }
     a.predict = (mode == BCNN_HIP_MODE_PREDICT);
     a.mean = run_mean; a.var = run_var;
+    a.consts = nullptr;
+    float4* consts = (mode == BCNN_HIP_MODE_TRAIN && !stats_only) ? bn_consts_scratch(c) : nullptr;
     if (mode == BCNN_HIP_MODE_PREDICT) a.ws = nullptr;  // the reference keeps no copy in PREDICT mode
     if (mode == BCNN_HIP_MODE_VALID) a.xn = nullptr;    // x_norm is only written in TRAIN mode (:230)
     if (have_pre) {
         bn_stats_finalize_wide_kernel<<<c, kFinalizeThreads, 0, current_stream()>>>(
-            pre->partials, c, pre->splits, (int)M, saved_mean, saved_var, run_mean, run_var);
+            pre->partials, c, pre->splits, (int)M, saved_mean, saved_var, run_mean, run_var, consts, scales, bias);
         KERNEL_CHECK();
-        a.mean = saved_mean; a.var = saved_var;
+        a.mean = saved_mean; a.var = saved_var; a.consts = consts;
     } else if (mode == BCNN_HIP_MODE_TRAIN) {
         const int splits = chan_splits(c, M);
         float* part = reduce_scratch((size_t)c * splits * 2);
         launch_chan_reduce<2>(StatsF{x}, c, hw, M, splits, part);
         bn_stats_finalize_kernel<<<ceil_div(c, 256), 256, 0, current_stream()>>>(
-            part, c, splits, (int)M, saved_mean, saved_var, run_mean, run_var);
+            part, c, splits, (int)M, saved_mean, saved_var, run_mean, run_var, consts, scales, bias);
         KERNEL_CHECK();
-        a.mean = saved_mean; a.var = saved_var;
+        a.mean = saved_mean; a.var = saved_var; a.consts = consts;
     }
     if (stats_only) return;  // the consumer normalises on the fly (bcnn_hip_maxpool_forward_bn)
     auto al16 = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
@@ -422,7 +496,7 @@ namespace bcnn_hip {
 void batchnorm_backward_sums(const float* dy, const float* y, int act, const float* scales, float* dscales,
                              float* dbias, const float* saved_mean, const float* saved_var, float* dmean,
                              float* dvar, const float* workspace, int n, int c, int hw, const float* fwd_bias,
-                             const float* res = nullptr, unsigned res_count = 0) {
+                             const float* res = nullptr, unsigned res_count = 0, float4* consts = nullptr) {
     const long long M = (long long)n * hw;
     const int splits = chan_splits(c, M);
     float* part = reduce_scratch((size_t)c * splits * 2);
@@ -431,7 +505,8 @@ void batchnorm_backward_sums(const float* dy, const float* y, int act, const flo
     f.fwd_bias = fwd_bias; f.var = saved_var; f.scale = scales; f.res = res; f.res_count = res_count;
     launch_chan_reduce<2>(f, c, hw, M, splits, part);
     bn_bwd_finalize_kernel<<<ceil_div(c, 256), 256, 0, current_stream()>>>(part, c, splits, scales, saved_var,
-                                                                          dbias, dscales, dmean, dvar);
+                                                                          dbias, dscales, dmean, dvar, consts, saved_mean,
+                                                                          fwd_bias, (float)M);
     KERNEL_CHECK();
 }
 
@@ -440,9 +515,11 @@ static void batchnorm_backward_apply(float* dy, float* dx, const float* y, int a
                                      const float* saved_mean, const float* saved_var, const float* dmean,
                                      const float* dvar, const float* workspace, int n, int c, int hw,
                                      const float* fwd_bias, int keep_dy = 0, const float* res = nullptr,
-                                     unsigned res_count = 0) {
+                                     unsigned res_count = 0, const float4* consts = nullptr) {
     const long long M = (long long)n * hw, total = M * c;
     BnBwdApplyArgs a;
+    a.consts = consts;
+    a.rM = 1.0f / (float)M;  // IEEE, round to nearest: what __fdiv_rn(1.0f, M) gives on the device
     a.dy = dy; a.dx = (dx && dx != dy) ? dx : nullptr; a.y = y; a.x = workspace;
     a.mean = saved_mean; a.var = saved_var; a.scale = scales; a.dmean = dmean; a.dvar = dvar;
     a.C = c; a.HW = hw; a.act = act; a.M = (int)M; a.total = total; a.fwd_bias = fwd_bias;
@@ -465,9 +542,11 @@ void batchnorm_backward_impl(float* dy, float* dx, const float* y, int act, cons
         bcnn_hip_activation_backward(y, dy, (size_t)total, act, nullptr, nullptr, hw, c);
         act = BCNN_HIP_ACT_NONE;
     }
+    float4* consts = bn_consts_scratch(c);
     batchnorm_backward_sums(dy, y, act, scales, dscales, dbias, saved_mean, saved_var, dmean, dvar, workspace, n, c, hw,
-                            fwd_bias);
-    batchnorm_backward_apply(dy, dx, y, act, scales, saved_mean, saved_var, dmean, dvar, workspace, n, c, hw, fwd_bias);
+                            fwd_bias, nullptr, 0, consts);
+    batchnorm_backward_apply(dy, dx, y, act, scales, saved_mean, saved_var, dmean, dvar, workspace, n, c, hw, fwd_bias, 0,
+                             nullptr, 0, consts);
 }
 // batchnorm_backward_impl whose sums a producer of dy already left as partials[(channel * splits + i) * 2 + {S1, S2}]
 // (the depthwise kernel that wrote dy: depthwise_lds.hip): finalize + the apply sweep, no read-only sweep
@@ -479,10 +558,12 @@ void batchnorm_backward_presummed(float* dy, const float* y, int act, const floa
     if (!total) return;
     if (act == BCNN_HIP_ACT_NONE) fwd_bias = nullptr;
     KTimer kt(K_BN_BWD, 0.0, 4.0 * ((act != BCNN_HIP_ACT_NONE && !fwd_bias) ? 4.0 : 3.0) * (double)total);
+    float4* consts = bn_consts_scratch(c);
     bn_bwd_finalize_wide_kernel<<<c, 1024, 0, current_stream()>>>(sums, c, splits, scales, saved_var, dbias, dscales, dmean,
-                                                                  dvar);
+                                                                  dvar, consts, saved_mean, fwd_bias, (float)M);
     KERNEL_CHECK();
-    batchnorm_backward_apply(dy, nullptr, y, act, scales, saved_mean, saved_var, dmean, dvar, workspace, n, c, hw, fwd_bias);
+    batchnorm_backward_apply(dy, nullptr, y, act, scales, saved_mean, saved_var, dmean, dvar, workspace, n, c, hw, fwd_bias, 0,
+                             nullptr, 0, consts);
 }
 // d(res)[i] += dout[i] * act'(out[i]) for the first `count` elements (the partial operand of the folded eltwise node)
 __global__ __launch_bounds__(256) void bn_residual_grad_kernel(const float* __restrict__ out, const float* __restrict__ dout,
@@ -508,10 +589,11 @@ void batchnorm_backward_residual(const float* dout, const float* out, int act_re
         bn_residual_grad_kernel<<<stream_grid(cnt, 256), 256, 0, current_stream()>>>(out, dout, dres, cnt, act_res);
         KERNEL_CHECK();
     }
+    float4* consts = bn_consts_scratch(c);
     batchnorm_backward_sums(dout, out, act_res, scales, dscales, dbias, saved_mean, saved_var, dmean, dvar, workspace, n, c,
-                            hw, fwd_bias, res, cnt);
+                            hw, fwd_bias, res, cnt, consts);
     batchnorm_backward_apply(const_cast<float*>(dout), dx, out, act_res, scales, saved_mean, saved_var, dmean, dvar,
-                             workspace, n, c, hw, fwd_bias, /*keep_dy=*/1, res, cnt);
+                             workspace, n, c, hw, fwd_bias, /*keep_dy=*/1, res, cnt, consts);
 }
 
 }  // namespace bcnn_hip
@@ -525,7 +607,7 @@ void bcnn_hip_batchnorm_apply(const float* x, float* y, const float* scales, con
     BnApplyArgs a;
     a.x = x; a.y = y; a.ws = nullptr; a.xn = nullptr; a.scale = scales; a.bias = bias; a.mean = saved_mean; a.var = saved_var;
     a.C = c; a.HW = hw; a.act = act_is_cheap(act) ? act : BCNN_HIP_ACT_NONE; a.total = total; a.predict = 0;
-    a.res = nullptr; a.res_count = 0; a.act2 = BCNN_HIP_ACT_NONE;
+    a.res = nullptr; a.res_count = 0; a.act2 = BCNN_HIP_ACT_NONE; a.consts = nullptr;
     auto al16 = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     launch_chan_map(BnApplyBody{a, al16(x) && al16(y)}, n, c, hw);
     if (a.act != act) bcnn_hip_activation_forward(y, (size_t)total, act, nullptr, hw, c);
@@ -535,7 +617,7 @@ void bcnn_hip_batchnorm_backward_finalize(const float* sums, int splits, const f
                                           const float* saved_var, float* dmean, float* dvar, int c) {
     if (c <= 0 || splits <= 0) return;
     bn_bwd_finalize_wide_kernel<<<c, 1024, 0, current_stream()>>>(sums, c, splits, scales, saved_var, dbias, dscales, dmean,
-                                                                  dvar);
+                                                                  dvar, nullptr, nullptr, nullptr, 1.0f);
     KERNEL_CHECK();
 }
 

@@ -111,19 +111,33 @@ __global__ __launch_bounds__(256) void plane_map_kernel(const Body body, int C, 
         if (i < HW) body(base + i, c, (HW - i) >= 4 ? 4 : (HW - i));
     }
 }
+// The running element's (offset in plane, channel) are carried along instead of divided out per step: the grid stride is
+// step_planes whole planes + step_in elements (host), so one step is two adds, two compares and two conditional
+// subtracts -- the two 32-bit divisions per float4 this loop used to do cost more vector-ALU time than the map bodies
+// (rocprofv3 SQ counters, profiles/r04_sq_step_resnet18.txt: the batch-norm maps on 28 x 28 planes were 40-60 % VALU-busy).
 template <class Body>
-__global__ __launch_bounds__(256) void flat_map_kernel(const Body body, int C, int HW, unsigned total) {
+__global__ __launch_bounds__(256) void flat_map_kernel(const Body body, int C, int HW, unsigned total, unsigned step_in,
+                                                       unsigned step_c) {
     const unsigned stride = gridDim.x * blockDim.x * 4u;
-    for (unsigned i = (blockIdx.x * blockDim.x + threadIdx.x) * 4u; i < total; i += stride) {
-        const unsigned plane = i / (unsigned)HW, in = i - plane * (unsigned)HW;
-        const int c = (int)(plane % (unsigned)C);
+    unsigned i = (blockIdx.x * blockDim.x + threadIdx.x) * 4u;
+    if (i >= total) return;
+    const unsigned plane0 = i / (unsigned)HW;
+    unsigned in = i - plane0 * (unsigned)HW, c = plane0 % (unsigned)C;
+    for (; i < total; i += stride) {
         const int cnt = (total - i) >= 4u ? 4 : (int)(total - i);
-        if (in + (unsigned)cnt <= (unsigned)HW) { body(i, c, cnt); continue; }
-        // the 4 elements straddle a plane boundary: one at a time
-        for (int k = 0; k < cnt; ++k) {
-            const unsigned pl = (i + k) / (unsigned)HW;
-            body(i + k, (int)(pl % (unsigned)C), 1);
+        if (in + (unsigned)cnt <= (unsigned)HW) {
+            body(i, (int)c, cnt);
+        } else {  // the 4 elements straddle one or more plane boundaries: one at a time
+            unsigned ik = in, ck = c;
+            for (int k = 0; k < cnt; ++k) {
+                body(i + k, (int)ck, 1);
+                if (++ik == (unsigned)HW) { ik = 0; ck = ck + 1 == (unsigned)C ? 0 : ck + 1; }
+            }
         }
+        in += step_in;
+        c += step_c;
+        if (in >= (unsigned)HW) { in -= (unsigned)HW; ++c; }
+        if (c >= (unsigned)C) c -= (unsigned)C;
     }
 }
 template <class Body>
@@ -134,8 +148,11 @@ inline void launch_chan_map(const Body& body, int N, int C, int HW) {
         const int chunks = (HW + 4095) / 4096;
         plane_map_kernel<Body><<<(unsigned)(N * C * chunks), 256, 0, current_stream()>>>(body, C, HW, chunks);
     } else {
-        flat_map_kernel<Body><<<stream_grid((size_t)(total / 4 + 1), 256), 256, 0, current_stream()>>>(
-            body, C, HW, (unsigned)total);
+        const int blocks = stream_grid((size_t)(total / 4 + 1), 256);
+        const unsigned stride = (unsigned)blocks * 256u * 4u;  // = step_planes * HW + step_in
+        const unsigned step_planes = stride / (unsigned)HW;
+        flat_map_kernel<Body><<<blocks, 256, 0, current_stream()>>>(body, C, HW, (unsigned)total,
+                                                                    stride - step_planes * (unsigned)HW, step_planes % (unsigned)C);
     }
     KERNEL_CHECK();
 }

@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restric
 void batchnorm_backward_sums(const float* dy, const float* y, int act, const float* scales, float* dscales, float* dbias,
                              const float* saved_mean, const float* saved_var, float* dmean, float* dvar,
                              const float* workspace, int n, int c, int hw, const float* fwd_bias, const float* res,
-                             unsigned res_count);
+                             unsigned res_count, float4* consts = nullptr);
 
 }  // namespace bcnn_hip
 
