@@ -1187,7 +1187,15 @@ bool conv_backward_data_winograd_fused(const float* w, const float* dy, float* d
 // dw in a fixed order (deterministic; keeps the `+=` onto the momentum carry, bcnn_conv_layer.c:547-553).
 // =============================================================================================================
 constexpr int WD_KT = 8;                 // tiles per chunk
-constexpr int WD_ROW = WD_KT + 1;        // padded LDS row
+// LDS rows are the 8 tiles of a chunk, unpadded, with the tile index XOR-swizzled by the channel: element (xi, ch, t)
+// sits at (xi * 64 + ch) * 8 + (t ^ 2 * ((ch >> 3) & 3)). Both access shapes then touch 64 different banks: the transform's
+// writes (a wave's lanes = 8 tiles x 8 consecutive channels: the swizzle is wave-uniform, ch * 8 + t covers 64 floats) and
+// the MFMA fragment reads (lanes = 32 consecutive channels x 2 tiles 2 ks, 2 ks + 1: the four channels that share
+// ch mod 8 differ in (ch >> 3) & 3 and so in bits 1-2 of their swizzled tile). The padded 9-float rows of round 3 were
+// conflict-free for the reads of ONE half-wave only: 25 of the 32 lane pairs (l, l + 32) met in a bank (9 (k - j) = 1 mod 64
+// has the solution k = j - 7), which rocprofv3 counted as bank conflicts in 33 % of the LDS-active cycles; and they took
+// 147 KB where this takes 128.
+constexpr int WD_ROW = WD_KT;            // LDS row: the chunk's 8 tiles
 constexpr int WD_OP = 16 * 64 * WD_ROW;  // floats per operand and stage
 
 
@@ -1203,7 +1211,7 @@ struct WinoDwArgs {
 
 template <bool ODDW>
 __global__ __launch_bounds__(512, 2) void wino_dw_fused_kernel(const WinoDwArgs a) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * 2 * WD_OP];  // two stages of (dM, V): 147 KB
+    __shared__ __attribute__((aligned(16))) float lds[2 * 2 * WD_OP];  // two stages of (dM, V): 128 KB
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lhi = lane >> 5;
@@ -1316,7 +1324,7 @@ __global__ __launch_bounds__(512, 2) void wino_dw_fused_kernel(const WinoDwArgs 
     };
     auto write_items = [&](int stage) {
         assemble();
-        float* pm = lds + stage * 2 * WD_OP + ch * WD_ROW + tl;
+        float* pm = lds + stage * 2 * WD_OP + ch * WD_ROW + (tl ^ (2 * (wid & 3)));  // (ch >> 3) & 3 == wid & 3
         float* pv = pm + WD_OP;
         // dM = A g A^T, A = [1 0; 1 1; 1 -1; 0 -1]
         float q[4][2];
@@ -1368,6 +1376,7 @@ __global__ __launch_bounds__(512, 2) void wino_dw_fused_kernel(const WinoDwArgs 
     // has MFMAs to issue (the arrangement of wino_fused_kernel). The items a wave transforms in chunk kc (for chunk kc + 1)
     // were requested during chunk kc - 1, right after the previous transform freed the registers: a whole chunk of lead.
     const bool early = wid < 4;
+    const unsigned rd0 = (unsigned)(((2 * wid) * 64 + l31) * WD_ROW + lhi + 2 * ((l31 >> 3) & 3));  // fragment reads, see WD_ROW
     if (nchunks > 0) {
         load_items();
         write_items(0);
@@ -1391,17 +1400,19 @@ __global__ __launch_bounds__(512, 2) void wino_dw_fused_kernel(const WinoDwArgs 
         };
         if (early) produce();
         __builtin_amdgcn_sched_barrier(0);  // requests first, then the MFMAs they fly under
-        const float* ms = lds + cur * 2 * WD_OP + (2 * wid) * 64 * WD_ROW + l31 * WD_ROW + lhi;
-        const float* vs = ms + WD_OP;
+        const float* stage_base = lds + cur * 2 * WD_OP;
 #pragma unroll
         for (int ks = 0; ks < WD_KT / 2; ++ks) {
             float af[2][2], bf[2][2];
+            // tile 2 ks + lhi of channel l31 (+ 32 i) of position 2 wid + e: the swizzled index is rd0 ^ 2 ks
+            const float* ms = stage_base + (rd0 ^ (unsigned)(2 * ks));
+            const float* vs = ms + WD_OP;
 #pragma unroll
             for (int e = 0; e < 2; ++e)
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    af[e][i] = ms[(e * 64 + i * 32) * WD_ROW + 2 * ks];
-                    bf[e][i] = vs[(e * 64 + i * 32) * WD_ROW + 2 * ks];
+                    af[e][i] = ms[(e * 64 + i * 32) * WD_ROW];
+                    bf[e][i] = vs[(e * 64 + i * 32) * WD_ROW];
                 }
 #pragma unroll
             for (int e = 0; e < 2; ++e)
@@ -1506,7 +1517,7 @@ static WinoDwPlan wino_dw_fused_plan(const ConvShape& s) {
     p.T = (unsigned)((long long)s.N * TH * TW);
     p.fblocks = (s.F + 63) / 64; p.cblocks = (s.C + 63) / 64;
     const int nob = p.fblocks * p.cblocks;
-    int splits = kCUs / nob;  // one 147 KB workgroup per CU
+    int splits = kCUs / nob;  // one 128 KB workgroup per CU
     if (splits < 1) splits = 1;
     unsigned per = (p.T + (unsigned)splits - 1) / (unsigned)splits;
     per = (per + WD_KT - 1) / WD_KT * WD_KT;
