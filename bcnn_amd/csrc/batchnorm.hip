@@ -27,7 +27,7 @@ struct ConstScratch {
     int dev = -1;
 };
 static thread_local ConstScratch g_bn_consts;
-static float4* bn_consts_scratch(int channels) {  // grow-only, per host thread (= per stream): finalize -> apply only
+float4* bn_consts_scratch(int channels) {  // grow-only, per host thread (= per stream): finalize -> apply only
     int dev = 0;
     HIP_CHECK(hipGetDevice(&dev));
     const size_t need = (size_t)channels * 3;
@@ -496,7 +496,8 @@ namespace bcnn_hip {
 void batchnorm_backward_sums(const float* dy, const float* y, int act, const float* scales, float* dscales,
                              float* dbias, const float* saved_mean, const float* saved_var, float* dmean,
                              float* dvar, const float* workspace, int n, int c, int hw, const float* fwd_bias,
-                             const float* res = nullptr, unsigned res_count = 0, float4* consts = nullptr) {
+                             const float* res = nullptr, unsigned res_count = 0, float4* consts = nullptr,
+                             float consts_fM = 0.f /* divisor of dmean in the table; 0: N * hw */) {
     const long long M = (long long)n * hw;
     const int splits = chan_splits(c, M);
     float* part = reduce_scratch((size_t)c * splits * 2);
@@ -506,7 +507,7 @@ void batchnorm_backward_sums(const float* dy, const float* y, int act, const flo
     launch_chan_reduce<2>(f, c, hw, M, splits, part);
     bn_bwd_finalize_kernel<<<ceil_div(c, 256), 256, 0, current_stream()>>>(part, c, splits, scales, saved_var,
                                                                           dbias, dscales, dmean, dvar, consts, saved_mean,
-                                                                          fwd_bias, (float)M);
+                                                                          fwd_bias, consts_fM > 0.f ? consts_fM : (float)M);
     KERNEL_CHECK();
 }
 

@@ -326,16 +326,15 @@ __global__ __launch_bounds__(256) void maxpool_bwd_vec4_k3s2_pair_kernel(const f
 __global__ __launch_bounds__(256) void maxpool_bwd_pair_bn_kernel(const float* __restrict__ dy, const int* __restrict__ idx,
                                                                   const float* __restrict__ raw, float* __restrict__ dx,
                                                                   int C, int H, int W, int OH, int OW,
-                                                                  const float* __restrict__ mean, const float* __restrict__ var,
-                                                                  const float* __restrict__ scale, const float* __restrict__ bias,
-                                                                  const float* __restrict__ dmean, const float* __restrict__ dvar,
-                                                                  float fM, int act) {
+                                                                  const float4* __restrict__ consts, unsigned w4_magic,
+                                                                  float fM, float rfM, int act) {
     const int W4 = W >> 2;
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int plane = blockIdx.y;
     const bool live = t < H * W4;
     const int tt = live ? t : 0;
-    const int h = tt / W4, k = tt - h * W4, w0 = k * 4;
+    // tt / W4 by multiply-high with ceil(2^32 / W4) (exact: tt * W4 < 2^32, checked by the launcher)
+    const int h = W4 > 1 ? (int)__umulhi((unsigned)tt, w4_magic) : tt, k = tt - h * W4, w0 = k * 4;
     const int s0 = (plane * H + h) * W + w0;
     const int i0 = h >= 2 ? (h - 1) >> 1 : 0;
     int i1 = h >> 1; if (i1 > OH - 1) i1 = OH - 1;
@@ -371,10 +370,12 @@ __global__ __launch_bounds__(256) void maxpool_bwd_pair_bn_kernel(const float* _
                 if (d == 0) v.x += gg; else if (d == 1) v.y += gg; else if (d == 2) v.z += gg; else v.w += gg;
             }
         }
+    // per-channel constants: the table bn_bwd_finalize_kernel left (wave-uniform: scalar loads). Four IEEE divisions and two
+    // square roots per thread -- for four elements -- had made this kernel vector-ALU bound (profiles/r04_sq_step_resnet18.txt)
     const int ch = plane % C;
-    const float m = mean[ch], sc = scale[ch], bb = bias[ch], vr = var[ch];
-    const BnDiv rs_fwd = bn_divisor(sqrtf(vr + 0.000001f)), rs = bn_divisor(sqrtf(vr + 0.00001f)), fMd = bn_divisor(fM);
-    const float dmm = __fdiv_rn(dmean[ch], fM), dv = dvar[ch];
+    const float4 k0 = consts[3 * ch], k1 = consts[3 * ch + 1], k2 = consts[3 * ch + 2];
+    const float m = k0.x, sc = k0.y, bb = k1.z, dmm = k1.w, dv = k2.x;
+    const BnDiv rs{k0.z, k0.w}, rs_fwd{k1.x, k1.y}, fMd{fM, rfM};
     float dummy;
     float4 o;
     o.x = bn_bwd_one(v.x, bn_one(xv.x, m, rs_fwd, sc, bb, 0, act, &dummy), xv.x, m, rs, sc, dmm, dv, fMd, act);
@@ -412,7 +413,8 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restric
 void batchnorm_backward_sums(const float* dy, const float* y, int act, const float* scales, float* dscales, float* dbias,
                              const float* saved_mean, const float* saved_var, float* dmean, float* dvar,
                              const float* workspace, int n, int c, int hw, const float* fwd_bias, const float* res,
-                             unsigned res_count, float4* consts = nullptr);
+                             unsigned res_count, float4* consts = nullptr, float consts_fM = 0.f);
+float4* bn_consts_scratch(int channels);  // batchnorm.hip: the per-channel constants its backward finalize kernel leaves
 
 }  // namespace bcnn_hip
 
@@ -495,6 +497,8 @@ void bcnn_hip_maxpool_bn_backward(const float* dpool, const int* indexes, const 
         fprintf(stderr, "[bcnn_hip] bcnn_hip_maxpool_bn_backward: not fusable (ask bcnn_hip_maxpool_bn_backward_fusable)\n");
         exit(1);
     }
+    float4* consts = bn_consts_scratch(c);
+    const float fM = (float)((long long)n * h * w);  // the un-pooled element count divides dmean and the dvar term
     // S1 = sum g act'(y), S2 = sum g act'(y) (x - mean) of the batch-norm backward: the gradient of the un-pooled tensor is
     // zero except where a window's maximum sits, and there it is the sum of the pooled gradients that selected the place --
     // so both sums are sums over the POOLED gradient against the pre-normalisation values that won (a quarter of the data;
@@ -502,12 +506,14 @@ void bcnn_hip_maxpool_bn_backward(const float* dpool, const int* indexes, const 
     {
         KTimer kt(K_BN_BWD, 0.0, 4.0 * 2.0 * (double)ptotal);
         batchnorm_backward_sums(dpool, nullptr, act, scales, dscales, dbias, mean, var, dmean, dvar, raw_at_max, n, c,
-                                out_h * out_w, act != BCNN_HIP_ACT_NONE ? bias : nullptr, nullptr, 0u);
+                                out_h * out_w, act != BCNN_HIP_ACT_NONE ? bias : nullptr, nullptr, 0u, consts, fM);
     }
     KTimer kt(K_POOL, 0.0, 4.0 * (2.0 * (double)total + 2.0 * (double)ptotal));
     dim3 grid((unsigned)ceil_div(h * (w / 4), 256), (unsigned)(n * c));
-    maxpool_bwd_pair_bn_kernel<<<grid, 256, 0, current_stream()>>>(dpool, indexes, raw, dx, c, h, w, out_h, out_w, mean, var, scales,
-                                                                   bias, dmean, dvar, (float)((long long)n * h * w), act);
+    const unsigned w4 = (unsigned)(w / 4);
+    maxpool_bwd_pair_bn_kernel<<<grid, 256, 0, current_stream()>>>(dpool, indexes, raw, dx, c, h, w, out_h, out_w, consts,
+                                                                   w4 > 1 ? (unsigned)((0x100000000ULL + w4 - 1) / w4) : 0u, fM,
+                                                                   1.0f / fM, act);
     KERNEL_CHECK();
 }
 
