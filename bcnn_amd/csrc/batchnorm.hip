@@ -27,7 +27,9 @@ struct ConstScratch {
     int dev = -1;
 };
 static thread_local ConstScratch g_bn_consts;
-float4* bn_consts_scratch(int channels) {  // grow-only, per host thread (= per stream): finalize -> apply only
+float4* bn_consts_scratch(int channels, bool required);
+float4* bn_consts_scratch(int channels, bool required) {  // grow-only, per host thread (= per stream): finalize -> apply only
+    if (!required && BCNN_EXP_ENV("BCNN_HIP_BN_NO_CONSTS")) return nullptr;  // A/B switch (experiment build): constants evaluated in the bodies
     int dev = 0;
     HIP_CHECK(hipGetDevice(&dev));
     const size_t need = (size_t)channels * 3;
@@ -441,7 +443,7 @@ void batchnorm_forward_impl(const float* x, float* y, float* run_mean, float* ru
     a.predict = (mode == BCNN_HIP_MODE_PREDICT);
     a.mean = run_mean; a.var = run_var;
     a.consts = nullptr;
-    float4* consts = (mode == BCNN_HIP_MODE_TRAIN && !stats_only) ? bn_consts_scratch(c) : nullptr;
+    float4* consts = (mode == BCNN_HIP_MODE_TRAIN && !stats_only) ? bn_consts_scratch(c, false) : nullptr;
     if (mode == BCNN_HIP_MODE_PREDICT) a.ws = nullptr;  // the reference keeps no copy in PREDICT mode
     if (mode == BCNN_HIP_MODE_VALID) a.xn = nullptr;    // x_norm is only written in TRAIN mode (:230)
     if (have_pre) {
@@ -543,7 +545,7 @@ void batchnorm_backward_impl(float* dy, float* dx, const float* y, int act, cons
         bcnn_hip_activation_backward(y, dy, (size_t)total, act, nullptr, nullptr, hw, c);
         act = BCNN_HIP_ACT_NONE;
     }
-    float4* consts = bn_consts_scratch(c);
+    float4* consts = bn_consts_scratch(c, false);
     batchnorm_backward_sums(dy, y, act, scales, dscales, dbias, saved_mean, saved_var, dmean, dvar, workspace, n, c, hw,
                             fwd_bias, nullptr, 0, consts);
     batchnorm_backward_apply(dy, dx, y, act, scales, saved_mean, saved_var, dmean, dvar, workspace, n, c, hw, fwd_bias, 0,
@@ -559,7 +561,7 @@ void batchnorm_backward_presummed(float* dy, const float* y, int act, const floa
     if (!total) return;
     if (act == BCNN_HIP_ACT_NONE) fwd_bias = nullptr;
     KTimer kt(K_BN_BWD, 0.0, 4.0 * ((act != BCNN_HIP_ACT_NONE && !fwd_bias) ? 4.0 : 3.0) * (double)total);
-    float4* consts = bn_consts_scratch(c);
+    float4* consts = bn_consts_scratch(c, false);
     bn_bwd_finalize_wide_kernel<<<c, 1024, 0, current_stream()>>>(sums, c, splits, scales, saved_var, dbias, dscales, dmean,
                                                                   dvar, consts, saved_mean, fwd_bias, (float)M);
     KERNEL_CHECK();
@@ -590,7 +592,7 @@ void batchnorm_backward_residual(const float* dout, const float* out, int act_re
         bn_residual_grad_kernel<<<stream_grid(cnt, 256), 256, 0, current_stream()>>>(out, dout, dres, cnt, act_res);
         KERNEL_CHECK();
     }
-    float4* consts = bn_consts_scratch(c);
+    float4* consts = bn_consts_scratch(c, false);
     batchnorm_backward_sums(dout, out, act_res, scales, dscales, dbias, saved_mean, saved_var, dmean, dvar, workspace, n, c,
                             hw, fwd_bias, res, cnt, consts);
     batchnorm_backward_apply(const_cast<float*>(dout), dx, out, act_res, scales, saved_mean, saved_var, dmean, dvar,

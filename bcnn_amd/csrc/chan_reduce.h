@@ -111,6 +111,21 @@ __global__ __launch_bounds__(256) void plane_map_kernel(const Body body, int C, 
         if (i < HW) body(base + i, c, (HW - i) >= 4 ? 4 : (HW - i));
     }
 }
+template <class Body>
+__global__ __launch_bounds__(256) void flat_map_div_kernel(const Body body, int C, int HW, unsigned total) {
+    const unsigned stride = gridDim.x * blockDim.x * 4u;
+    for (unsigned i = (blockIdx.x * blockDim.x + threadIdx.x) * 4u; i < total; i += stride) {
+        const unsigned plane = i / (unsigned)HW, in = i - plane * (unsigned)HW;
+        const int c = (int)(plane % (unsigned)C);
+        const int cnt = (total - i) >= 4u ? 4 : (int)(total - i);
+        if (in + (unsigned)cnt <= (unsigned)HW) { body(i, c, cnt); continue; }
+        // the 4 elements straddle a plane boundary: one at a time
+        for (int k = 0; k < cnt; ++k) {
+            const unsigned pl = (i + k) / (unsigned)HW;
+            body(i + k, (int)(pl % (unsigned)C), 1);
+        }
+    }
+}
 // The running element's (offset in plane, channel) are carried along instead of divided out per step: the grid stride is
 // step_planes whole planes + step_in elements (host), so one step is two adds, two compares and two conditional
 // subtracts -- the two 32-bit divisions per float4 this loop used to do cost more vector-ALU time than the map bodies
@@ -149,6 +164,11 @@ inline void launch_chan_map(const Body& body, int N, int C, int HW) {
         plane_map_kernel<Body><<<(unsigned)(N * C * chunks), 256, 0, current_stream()>>>(body, C, HW, chunks);
     } else {
         const int blocks = stream_grid((size_t)(total / 4 + 1), 256);
+        if (BCNN_EXP_ENV("BCNN_HIP_FLAT_MAP_DIV")) {  // A/B switch (experiment build): the loop with two divisions per step
+            flat_map_div_kernel<Body><<<blocks, 256, 0, current_stream()>>>(body, C, HW, (unsigned)total);
+            KERNEL_CHECK();
+            return;
+        }
         const unsigned stride = (unsigned)blocks * 256u * 4u;  // = step_planes * HW + step_in
         const unsigned step_planes = stride / (unsigned)HW;
         flat_map_kernel<Body><<<blocks, 256, 0, current_stream()>>>(body, C, HW, (unsigned)total,

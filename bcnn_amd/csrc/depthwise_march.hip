@@ -82,32 +82,60 @@ inline DwmGeom dwm_plan(const DwShape& s) {
     return g;
 }
 
+// Which band a lane group works on, and in which direction it marches. Planes cut into several bands (BPP > 1): the waves
+// come in pairs -- the even wave takes even bands and marches DOWN, the odd wave takes the odd bands of the same planes and
+// marches UP -- so the two bands either side of a boundary reach it at the same time (both at their last step, or both at
+// their first) and the halo row one of them reads is the row the other has just read: an L2 hit instead of a second trip to
+// HBM (rocprofv3 FETCH_SIZE with every band marching down: 1.20x the algorithmic bytes on the backward kernels, the halo
+// rows' 2 / 14 almost in full). The direction is wave-uniform: a scalar branch picks the window's orientation.
 struct DwmLane {
     bool on;           // this lane works on a band
+    bool up;           // the band is marched from its last row to its first (wave-uniform)
     bool first, last;  // first / last column group of the row
     int cg, grp;
-    unsigned band;     // global band index
     int p, c, bi;      // plane, channel, band within the plane
     int addr_l, addr_r;  // ds_bpermute byte addresses of the lanes to the left / right
 };
 
-__device__ __forceinline__ DwmLane dwm_lane(int L, int G, int BPP, int C, unsigned bands) {
+// lane group `grp` of wave `wave`: plane and band (false: none). planes = N * C.
+__device__ __forceinline__ bool dwm_map(unsigned wave, int grp, int G, int BPP, unsigned planes, int& p, int& bi, bool& up) {
+    up = false; p = 0; bi = 0;
+    if (grp >= G) return false;
+    if (BPP == 1) {
+        const unsigned k = wave * (unsigned)G + (unsigned)grp;
+        if (k >= planes) return false;
+        p = (int)k;
+        return true;
+    }
+    up = (wave & 1u) != 0u;
+    const unsigned per = up ? (unsigned)BPP / 2u : ((unsigned)BPP + 1u) / 2u;  // bands of this parity per plane
+    const unsigned k = (wave >> 1) * (unsigned)G + (unsigned)grp;
+    if (k >= planes * per) return false;
+    p = (int)(k / per);
+    bi = 2 * (int)(k - (unsigned)p * per) + (up ? 1 : 0);
+    return true;
+}
+
+__device__ __forceinline__ DwmLane dwm_lane(int L, int G, int BPP, int C, unsigned planes) {
     DwmLane m;
     const int lane = threadIdx.x & 63;
     const unsigned wave = blockIdx.x * 4u + (threadIdx.x >> 6);
     m.grp = lane / L;
     m.cg = lane - m.grp * L;
-    m.band = wave * (unsigned)G + (unsigned)m.grp;
-    m.on = m.grp < G && m.band < bands;
-    const unsigned b = m.on ? m.band : 0u;
-    m.p = (int)(b / (unsigned)BPP);
-    m.bi = (int)(b - (unsigned)m.p * (unsigned)BPP);
+    m.on = dwm_map(wave, m.grp, G, BPP, planes, m.p, m.bi, m.up);
+    m.up = BPP > 1 && (wave & 1u) != 0u;  // also for lanes without a band: the branch on it has to be wave-uniform
     m.c = m.p % C;
     m.first = m.cg == 0;
     m.last = m.cg == L - 1;
     m.addr_l = ((lane + 63) & 63) << 2;
     m.addr_r = ((lane + 1) & 63) << 2;
     return m;
+}
+
+// waves a launch needs
+inline unsigned dwm_waves(const DwmGeom& g, long long planes) {
+    if (g.BPP == 1) return (unsigned)ceil_div(planes, g.G);
+    return 2u * (unsigned)ceil_div(planes * ((g.BPP + 1) / 2), g.G);
 }
 
 __device__ __forceinline__ float dwm_from(int addr, float v) {
@@ -244,7 +272,8 @@ __global__ __launch_bounds__(256) void dwm_fwd_kernel(const DwmFwdArgs a) {
     __shared__ float red[4][2 * kSlab];
     const int act = RELU ? BCNN_HIP_ACT_RELU : a.act, in_act = RELU ? BCNN_HIP_ACT_RELU : a.in.act;
     constexpr int OV = S == 1 ? V : V / 2;  // outputs per lane and row
-    const DwmLane m = dwm_lane(a.g.L, a.g.G, a.g.BPP, a.C, (unsigned)a.g.bands);
+    const unsigned planes = (unsigned)(a.g.bands / a.g.BPP);
+    const DwmLane m = dwm_lane(a.g.L, a.g.G, a.g.BPP, a.C, planes);
     float w[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) w[i] = a.w[m.c * 9 + i];
@@ -255,7 +284,10 @@ __global__ __launch_bounds__(256) void dwm_fwd_kernel(const DwmFwdArgs a) {
     const unsigned xrow = (unsigned)a.W * 4u, yrow = (unsigned)a.OW * 4u;  // bytes per row
     const unsigned xbase = ((unsigned)m.p * a.H * a.W + m.cg * V) * 4u;
     const int r0 = m.bi * a.g.len, r1 = m.on ? min(r0 + a.g.len, a.OH) : r0;  // output rows [r0, r1)
-    unsigned yo = (((unsigned)m.p * a.OH + r0) * a.OW + m.cg * OV) * 4u;
+    // step k of the march is output row rf + dir * k, k < nrows
+    const int nrows = r1 - r0, dir = m.up ? -1 : 1, rf = m.up ? r1 - 1 : r0;
+    unsigned yo = (((unsigned)m.p * a.OH + rf) * a.OW + m.cg * OV) * 4u;
+    const unsigned ystep = m.up ? 0u - yrow : yrow;
     float s1 = 0.f, s2 = 0.f;
     auto in_row = [&](int r) -> bool { return m.on && r >= 0 && r < a.H; };
     auto fetch = [&](int r) -> Vals<V> { return dwm_ld<V>(a.x, xbase + (unsigned)r * xrow, in_row(r)); };
@@ -264,6 +296,7 @@ __global__ __launch_bounds__(256) void dwm_fwd_kernel(const DwmFwdArgs a) {
         return dwm_row<V, true, S == 1>(v, m);
     };
     auto finish = [&](float v) -> float { return act_fwd_cheap(__fadd_rn(v, b), act, 0.f); };
+    // A / B / Cr: the rows above, at and below the output row (in image order, whichever way the band is marched)
     auto emit = [&](const Row<V>& A, const Row<V>& B, const Row<V>& Cr, bool valid) {
         Vals<OV> o;
 #pragma unroll
@@ -285,46 +318,52 @@ __global__ __launch_bounds__(256) void dwm_fwd_kernel(const DwmFwdArgs a) {
                 s2 = __fmaf_rn(o.v[c], o.v[c], s2);
             }
         }
-        yo += yrow;
+        yo += ystep;
     };
     if constexpr (S == 1) {
-        Row<V> A = prep(fetch(r0 - 1), r0 - 1), B = prep(fetch(r0), r0);
-        Vals<V> ring[PF];  // rows r + 1 .. r + PF, loaded ahead of their use; nothing behind the band's halo row r1
+        // P: the row behind the march, Q: the output row's own input row, Nx: the row ahead (loaded PF steps before its use;
+        // nothing is requested beyond the band's far halo row, step nrows)
+        auto step_row = [&](int st) -> int { return st <= nrows ? rf + dir * st : -1; };
+        Row<V> P = prep(fetch(rf - dir), rf - dir), Q = prep(fetch(step_row(0)), step_row(0));
+        Vals<V> ring[PF];
 #pragma unroll
-        for (int u = 0; u < PF; ++u) ring[u] = fetch(r0 + 1 + u <= r1 ? r0 + 1 + u : -1);
+        for (int u = 0; u < PF; ++u) ring[u] = fetch(step_row(1 + u));
         for (int i0 = 0; i0 < a.g.len; i0 += PF) {
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
-                const int r = r0 + i0 + u;
+                const int k = i0 + u;
                 const Vals<V> cur = ring[u];
-                ring[u] = fetch(r + 1 + PF <= r1 ? r + 1 + PF : -1);
-                const Row<V> Cr = prep(cur, r + 1 <= r1 ? r + 1 : -1);
-                emit(A, B, Cr, r < r1);
-                A = B;
-                B = Cr;
+                ring[u] = fetch(step_row(k + 1 + PF));
+                const Row<V> Nx = prep(cur, step_row(k + 1));
+                if (m.up) emit(Nx, Q, P, k < nrows);
+                else emit(P, Q, Nx, k < nrows);
+                P = Q;
+                Q = Nx;
             }
         }
     } else {
-        // output row r reads input rows 2r - 1, 2r, 2r + 1; the lane's outputs are columns OV cg ..
-        Row<V> A = prep(fetch(2 * r0 - 1), 2 * r0 - 1);
-        Vals<V> ring0[PF], ring1[PF];  // input rows 2 r, 2 r + 1 of output rows r .. r + PF - 1
+        // output row r reads input rows 2r - 1, 2r, 2r + 1: per step the row 2r and the FAR row 2r + dir are new, the NEAR
+        // row 2r - dir is the previous step's far row. The lane's outputs are columns OV cg ..
+        Row<V> Nr = prep(fetch(m.on ? 2 * rf - dir : -1), m.on ? 2 * rf - dir : -1);
+        Vals<V> ring0[PF], ring1[PF];  // rows 2r and 2r + dir of steps k .. k + PF - 1
+        auto mid_row = [&](int st) -> int { return st < nrows ? 2 * (rf + dir * st) : -1; };
+        auto far_row = [&](int st) -> int { return st < nrows ? 2 * (rf + dir * st) + dir : -1; };
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
-            ring0[u] = fetch(r0 + u < r1 ? 2 * (r0 + u) : -1);
-            ring1[u] = fetch(r0 + u < r1 ? 2 * (r0 + u) + 1 : -1);
+            ring0[u] = fetch(mid_row(u));
+            ring1[u] = fetch(far_row(u));
         }
         for (int i0 = 0; i0 < a.g.len; i0 += PF) {
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
-                const int r = r0 + i0 + u;
-                const bool valid = r < r1;
+                const int k = i0 + u;
                 const Vals<V> c0 = ring0[u], c1 = ring1[u];
-                const bool more = r + PF < r1;
-                ring0[u] = fetch(more ? 2 * (r + PF) : -1);
-                ring1[u] = fetch(more ? 2 * (r + PF) + 1 : -1);
-                const Row<V> B = prep(c0, valid ? 2 * r : -1), Cr = prep(c1, valid ? 2 * r + 1 : -1);
-                emit(A, B, Cr, valid);
-                A = Cr;
+                ring0[u] = fetch(mid_row(k + PF));
+                ring1[u] = fetch(far_row(k + PF));
+                const Row<V> Md = prep(c0, mid_row(k)), Fr = prep(c1, far_row(k));
+                if (m.up) emit(Fr, Md, Nr, k < nrows);
+                else emit(Nr, Md, Fr, k < nrows);
+                Nr = Fr;
             }
         }
     }
@@ -333,9 +372,9 @@ __global__ __launch_bounds__(256) void dwm_fwd_kernel(const DwmFwdArgs a) {
     const int splits = (int)(a.g.bands / a.C);  // N * BPP
     const unsigned wave = blockIdx.x * 4u + (threadIdx.x >> 6);
     dwm_band_sums<2>(sv, red[threadIdx.x >> 6], a.g.L, a.g.G, [&](int q, int i, float t) {
-        const unsigned band = wave * (unsigned)a.g.G + (unsigned)q;
-        if (band >= (unsigned)a.g.bands) return;
-        const int p = (int)(band / (unsigned)a.g.BPP), bi = (int)(band - (unsigned)p * a.g.BPP);
+        int p, bi;
+        bool up;
+        if (!dwm_map(wave, q, a.g.G, a.g.BPP, planes, p, bi, up)) return;
         const int n = p / a.C, c = p - n * a.C;
         a.stats[((size_t)c * splits + (size_t)n * a.g.BPP + bi) * 2 + i] = t;
     });
@@ -372,7 +411,8 @@ __global__ __launch_bounds__(256, DWM_BWD_WAVES) void dwm_bwd_kernel(const DwmBw
     __shared__ float red[4][kDwmPart * kSlab];
     const int act = RELU ? BCNN_HIP_ACT_RELU : a.act, in_act = RELU ? BCNN_HIP_ACT_RELU : a.in.act;
     constexpr int GV = S == 1 ? V : V / 2;  // gradient values per lane and row
-    const DwmLane m = dwm_lane(a.g.L, a.g.G, a.g.BPP, a.C, (unsigned)a.g.bands);
+    const unsigned planes = (unsigned)(a.g.bands / a.g.BPP);
+    const DwmLane m = dwm_lane(a.g.L, a.g.G, a.g.BPP, a.C, planes);
     float w[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) w[i] = a.w[m.c * 9 + i];
@@ -450,115 +490,132 @@ __global__ __launch_bounds__(256, DWM_BWD_WAVES) void dwm_bwd_kernel(const DwmBw
         }
     };
 
+    // step k of the march is gradient row rf + dir * k, k < nrows
+    const int nrows = r1 - r0, dir = m.up ? -1 : 1, rf = m.up ? r1 - 1 : r0;
     if constexpr (S == 1) {
-        Row<V> A = make_g(fetch_g(r0 - 1), r0 - 1), B = make_g(fetch_g(r0), r0);
-        Raw gn = fetch_g(r0 + 1);
-        unsigned xo = xbase + (unsigned)r0 * xrow;
-        Vals<V> xn = dwm_ld<V>(a.x, xo, m.on && r0 < r1);
-        for (int i = 0; i < a.g.len; ++i) {
-            const int r = r0 + i;
-            const bool valid = r < r1;
+        // the rows of x / dx the band owns, one per step; A / B / Cr of `body`: the gradient rows above, at and below it
+        unsigned xo = xbase + (unsigned)rf * xrow;
+        const unsigned xstep = m.up ? 0u - xrow : xrow;
+        auto body = [&](const Row<V>& A, const Row<V>& B, const Row<V>& Cr, const Vals<V>& xraw) {
+            Vals<V> xv = xraw;
+            if (BNIN) xv = dwm_bnin_v<V>(xraw, kin, in_act);
+            // weight gradient from the rows of x this band owns: x[r][j] meets g[r - kh + 1][j - kw + 1]
+#pragma unroll
+            for (int c = 0; c < V; ++c) {
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    acc[0 + kw] = __fmaf_rn(xv.v[c], Cr.v[c + 2 - kw], acc[0 + kw]);
+                    acc[3 + kw] = __fmaf_rn(xv.v[c], B.v[c + 2 - kw], acc[3 + kw]);
+                    acc[6 + kw] = __fmaf_rn(xv.v[c], A.v[c + 2 - kw], acc[6 + kw]);
+                }
+                acc[9] += B.v[c + 1];
+            }
+            // data gradient, taps in the reference's scatter order: descending kh, descending kw
+            Vals<V> d = dwm_ld<V>(a.dx, xo, !a.overwrite);
+#pragma unroll
+            for (int c = 0; c < V; ++c) {
+                float v = d.v[c];
+#pragma unroll
+                for (int kw = 2; kw >= 0; --kw) v = __fadd_rn(v, __fmul_rn(w[6 + kw], A.v[c + 2 - kw]));
+#pragma unroll
+                for (int kw = 2; kw >= 0; --kw) v = __fadd_rn(v, __fmul_rn(w[3 + kw], B.v[c + 2 - kw]));
+#pragma unroll
+                for (int kw = 2; kw >= 0; --kw) v = __fadd_rn(v, __fmul_rn(w[0 + kw], Cr.v[c + 2 - kw]));
+                d.v[c] = v;
+            }
+            dwm_st<V>(a.dx, xo, d);
+            if (sums) in_sums(d, xv, xraw);
+        };
+        auto step_row = [&](int st) -> int { return st <= nrows ? rf + dir * st : -1; };
+        Row<V> P = make_g(fetch_g(rf - dir), rf - dir), Q = make_g(fetch_g(step_row(0)), step_row(0));
+        Raw gn = fetch_g(step_row(1));
+        Vals<V> xn = dwm_ld<V>(a.x, xo, m.on && nrows > 0);
+        for (int k = 0; k < a.g.len; ++k) {
+            const bool valid = k < nrows;
             const Raw gc = gn;
             const Vals<V> xraw = xn;
-            gn = fetch_g(r + 2 <= r1 ? r + 2 : -1);
-            xn = dwm_ld<V>(a.x, xo + xrow, m.on && r + 1 < r1);
-            const Row<V> Cr = make_g(gc, r + 1 <= r1 ? r + 1 : -1);
+            gn = fetch_g(step_row(k + 2));
+            xn = dwm_ld<V>(a.x, xo + xstep, m.on && k + 1 < nrows);
+            const Row<V> Nx = make_g(gc, step_row(k + 1));
             if (valid) {
-                Vals<V> xv = xraw;
-                if (BNIN) xv = dwm_bnin_v<V>(xraw, kin, in_act);
-                // weight gradient from the rows of x this band owns: x[r][j] meets g[r - kh + 1][j - kw + 1]
-#pragma unroll
-                for (int c = 0; c < V; ++c) {
-#pragma unroll
-                    for (int kw = 0; kw < 3; ++kw) {
-                        acc[0 + kw] = __fmaf_rn(xv.v[c], Cr.v[c + 2 - kw], acc[0 + kw]);
-                        acc[3 + kw] = __fmaf_rn(xv.v[c], B.v[c + 2 - kw], acc[3 + kw]);
-                        acc[6 + kw] = __fmaf_rn(xv.v[c], A.v[c + 2 - kw], acc[6 + kw]);
-                    }
-                    acc[9] += B.v[c + 1];
-                }
-                // data gradient, taps in the reference's scatter order: descending kh, descending kw
-                Vals<V> d = dwm_ld<V>(a.dx, xo, !a.overwrite);
-#pragma unroll
-                for (int c = 0; c < V; ++c) {
-                    float v = d.v[c];
-#pragma unroll
-                    for (int kw = 2; kw >= 0; --kw) v = __fadd_rn(v, __fmul_rn(w[6 + kw], A.v[c + 2 - kw]));
-#pragma unroll
-                    for (int kw = 2; kw >= 0; --kw) v = __fadd_rn(v, __fmul_rn(w[3 + kw], B.v[c + 2 - kw]));
-#pragma unroll
-                    for (int kw = 2; kw >= 0; --kw) v = __fadd_rn(v, __fmul_rn(w[0 + kw], Cr.v[c + 2 - kw]));
-                    d.v[c] = v;
-                }
-                dwm_st<V>(a.dx, xo, d);
-                if (sums) in_sums(d, xv, xraw);
+                if (m.up) body(Nx, Q, P, xraw);
+                else body(P, Q, Nx, xraw);
             }
-            xo += xrow;
-            A = B;
-            B = Cr;
+            xo += xstep;
+            P = Q;
+            Q = Nx;
         }
     } else {
-        // a gradient row: the lane's GV values and (index GV + 1 of the row) the right neighbour's first
-        Row<GV> B = make_g(fetch_g(r0), r0);
-        Raw gn = fetch_g(r0 + 1);
-        unsigned xo = xbase + (unsigned)(2 * r0) * xrow;
-        Vals<V> xn0 = dwm_ld<V>(a.x, xo, m.on && r0 < r1), xn1 = dwm_ld<V>(a.x, xo + xrow, m.on && r0 < r1 && 2 * r0 + 1 < a.H);
-        for (int i = 0; i < a.g.len; ++i) {
-            const int r = r0 + i;
-            const bool valid = r < r1, odd_ok = valid && 2 * r + 1 < a.H;
+        // a gradient row: the lane's GV values and (index GV + 1 of the row) the right neighbour's first. Step k works on
+        // gradient row r and the input rows 2r, 2r + 1 with the gradient rows r (Bg) and r + 1 (Cg): marching down the new
+        // row is r + 1 and r is carried, marching up r is new and r + 1 carried
+        unsigned xo = xbase + (unsigned)(2 * rf) * xrow;
+        const unsigned xstep = m.up ? 0u - 2u * xrow : 2u * xrow;
+        auto body = [&](const Row<GV>& Bg, const Row<GV>& Cg, const Vals<V>& xr0, const Vals<V>& xr1, bool odd_ok) {
+            Vals<V> x0 = xr0, x1 = xr1;
+            if (BNIN) x0 = dwm_bnin_v<V>(xr0, kin, in_act);
+            if (BNIN && odd_ok) x1 = dwm_bnin_v<V>(xr1, kin, in_act);
+            Vals<V> d0 = dwm_ld<V>(a.dx, xo, !a.overwrite), d1 = dwm_ld<V>(a.dx, xo + xrow, !a.overwrite && odd_ok);
+#pragma unroll
+            for (int j = 0; j < GV; ++j) {
+                // the 2 x 2 input block under gradient column j: g00 = g[r][j], g01 = g[r][j + 1], g10 / g11 one row down
+                const float g00 = Bg.v[1 + j], g01 = Bg.v[2 + j], g10 = Cg.v[1 + j], g11 = Cg.v[2 + j];
+                const float xe0 = x0.v[2 * j], xe1 = x0.v[2 * j + 1], xo0 = x1.v[2 * j], xo1 = x1.v[2 * j + 1];
+                // weight gradient from the owned x: even row meets kh = 1 of g[r]; odd row kh = 2 of g[r] and kh = 0 of
+                // g[r + 1]; even columns meet kw = 1, odd columns kw = 0 (gradient column to the right) and kw = 2
+                acc[4] = __fmaf_rn(xe0, g00, acc[4]);
+                acc[3] = __fmaf_rn(xe1, g01, acc[3]);
+                acc[5] = __fmaf_rn(xe1, g00, acc[5]);
+                acc[7] = __fmaf_rn(xo0, g00, acc[7]);
+                acc[6] = __fmaf_rn(xo1, g01, acc[6]);
+                acc[8] = __fmaf_rn(xo1, g00, acc[8]);
+                acc[1] = __fmaf_rn(xo0, g10, acc[1]);
+                acc[0] = __fmaf_rn(xo1, g11, acc[0]);
+                acc[2] = __fmaf_rn(xo1, g10, acc[2]);
+                acc[9] += g00;
+                // data gradient: the four parity classes meet 1, 2, 2 and 4 taps, in the reference's scatter order
+                d0.v[2 * j] = __fadd_rn(d0.v[2 * j], __fmul_rn(w[4], g00));
+                d0.v[2 * j + 1] = __fadd_rn(__fadd_rn(d0.v[2 * j + 1], __fmul_rn(w[5], g00)), __fmul_rn(w[3], g01));
+                d1.v[2 * j] = __fadd_rn(__fadd_rn(d1.v[2 * j], __fmul_rn(w[7], g00)), __fmul_rn(w[1], g10));
+                d1.v[2 * j + 1] = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(d1.v[2 * j + 1], __fmul_rn(w[8], g00)),
+                                                                __fmul_rn(w[6], g01)), __fmul_rn(w[2], g10)), __fmul_rn(w[0], g11));
+            }
+            dwm_st<V>(a.dx, xo, d0);
+            if (odd_ok) dwm_st<V>(a.dx, xo + xrow, d1);
+            if (sums) {
+                in_sums(d0, x0, xr0);
+                if (odd_ok) in_sums(d1, x1, xr1);
+            }
+        };
+        const int down1 = m.up ? 0 : 1;
+        auto new_row = [&](int st) -> int { return st < nrows ? rf + dir * st + down1 : -1; };  // the gradient row step st adds
+        Row<GV> X = make_g(fetch_g(m.on ? rf + 1 - down1 : -1), m.on ? rf + 1 - down1 : -1);   // carried: r (down) / r + 1 (up)
+        Raw gn = fetch_g(new_row(0));
+        Vals<V> xn0 = dwm_ld<V>(a.x, xo, m.on && nrows > 0), xn1 = dwm_ld<V>(a.x, xo + xrow, m.on && nrows > 0 && 2 * rf + 1 < a.H);
+        for (int k = 0; k < a.g.len; ++k) {
+            const int r = rf + dir * k;
+            const bool valid = k < nrows, odd_ok = valid && 2 * r + 1 < a.H;
             const Raw gc = gn;
             const Vals<V> xr0 = xn0, xr1 = xn1;
-            gn = fetch_g(r + 2 <= r1 ? r + 2 : -1);
-            const bool more = m.on && r + 1 < r1;
-            xn0 = dwm_ld<V>(a.x, xo + 2 * xrow, more);
-            xn1 = dwm_ld<V>(a.x, xo + 3 * xrow, more && 2 * r + 3 < a.H);
-            const Row<GV> Cg = make_g(gc, r + 1 <= r1 ? r + 1 : -1);
+            gn = fetch_g(new_row(k + 1));
+            const bool more = m.on && k + 1 < nrows;
+            xn0 = dwm_ld<V>(a.x, xo + xstep, more);
+            xn1 = dwm_ld<V>(a.x, xo + xstep + xrow, more && 2 * (r + dir) + 1 < a.H);
+            const Row<GV> Nw = make_g(gc, new_row(k));
             if (valid) {
-                Vals<V> x0 = xr0, x1 = xr1;
-                if (BNIN) x0 = dwm_bnin_v<V>(xr0, kin, in_act);
-                if (BNIN && odd_ok) x1 = dwm_bnin_v<V>(xr1, kin, in_act);
-                Vals<V> d0 = dwm_ld<V>(a.dx, xo, !a.overwrite), d1 = dwm_ld<V>(a.dx, xo + xrow, !a.overwrite && odd_ok);
-#pragma unroll
-                for (int j = 0; j < GV; ++j) {
-                    // the 2 x 2 input block under gradient column j: g00 = g[r][j], g01 = g[r][j + 1], g10 / g11 one row down
-                    const float g00 = B.v[1 + j], g01 = B.v[2 + j], g10 = Cg.v[1 + j], g11 = Cg.v[2 + j];
-                    const float xe0 = x0.v[2 * j], xe1 = x0.v[2 * j + 1], xo0 = x1.v[2 * j], xo1 = x1.v[2 * j + 1];
-                    // weight gradient from the owned x: even row meets kh = 1 of g[r]; odd row kh = 2 of g[r] and kh = 0 of
-                    // g[r + 1]; even columns meet kw = 1, odd columns kw = 0 (gradient column to the right) and kw = 2
-                    acc[4] = __fmaf_rn(xe0, g00, acc[4]);
-                    acc[3] = __fmaf_rn(xe1, g01, acc[3]);
-                    acc[5] = __fmaf_rn(xe1, g00, acc[5]);
-                    acc[7] = __fmaf_rn(xo0, g00, acc[7]);
-                    acc[6] = __fmaf_rn(xo1, g01, acc[6]);
-                    acc[8] = __fmaf_rn(xo1, g00, acc[8]);
-                    acc[1] = __fmaf_rn(xo0, g10, acc[1]);
-                    acc[0] = __fmaf_rn(xo1, g11, acc[0]);
-                    acc[2] = __fmaf_rn(xo1, g10, acc[2]);
-                    acc[9] += g00;
-                    // data gradient: the four parity classes meet 1, 2, 2 and 4 taps, in the reference's scatter order
-                    d0.v[2 * j] = __fadd_rn(d0.v[2 * j], __fmul_rn(w[4], g00));
-                    d0.v[2 * j + 1] = __fadd_rn(__fadd_rn(d0.v[2 * j + 1], __fmul_rn(w[5], g00)), __fmul_rn(w[3], g01));
-                    d1.v[2 * j] = __fadd_rn(__fadd_rn(d1.v[2 * j], __fmul_rn(w[7], g00)), __fmul_rn(w[1], g10));
-                    d1.v[2 * j + 1] = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(d1.v[2 * j + 1], __fmul_rn(w[8], g00)),
-                                                                    __fmul_rn(w[6], g01)), __fmul_rn(w[2], g10)), __fmul_rn(w[0], g11));
-                }
-                dwm_st<V>(a.dx, xo, d0);
-                if (odd_ok) dwm_st<V>(a.dx, xo + xrow, d1);
-                if (sums) {
-                    in_sums(d0, x0, xr0);
-                    if (odd_ok) in_sums(d1, x1, xr1);
-                }
+                if (m.up) body(Nw, X, xr0, xr1, odd_ok);
+                else body(X, Nw, xr0, xr1, odd_ok);
             }
-            xo += 2 * xrow;
-            B = Cg;
+            xo += xstep;
+            X = Nw;
         }
     }
     const int splits = (int)(a.g.bands / a.C);  // N * BPP
     const unsigned wave = blockIdx.x * 4u + (threadIdx.x >> 6);
     dwm_band_sums<kDwmPart>(acc, red[threadIdx.x >> 6], a.g.L, a.g.G, [&](int q, int i, float t) {
-        const unsigned band = wave * (unsigned)a.g.G + (unsigned)q;
-        if (band >= (unsigned)a.g.bands) return;
-        const int p = (int)(band / (unsigned)a.g.BPP), bi = (int)(band - (unsigned)p * a.g.BPP);
+        int p, bi;
+        bool up;
+        if (!dwm_map(wave, q, a.g.G, a.g.BPP, planes, p, bi, up)) return;
         const int n = p / a.C, c = p - n * a.C;
         const size_t slot = (size_t)c * splits + (size_t)n * a.g.BPP + bi;
         if (i < 10) a.partials[slot * kDwmPart + i] = t;
@@ -607,7 +664,7 @@ bool depthwise_forward_march(const float* x, const float* w, const float* bias, 
         }
     }
     a.in = in ? *in : DwBnIn{nullptr, nullptr, nullptr, nullptr, 0};
-    const unsigned waves = (unsigned)ceil_div(a.g.bands, a.g.G), blocks = (waves + 3) / 4;
+    const unsigned waves = dwm_waves(a.g, (long long)s.N * s.C), blocks = (waves + 3) / 4;
     hipStream_t st = current_stream();
     int pf = 2;
 #ifdef BCNN_HIP_EXPERIMENT
@@ -676,7 +733,7 @@ bool depthwise_backward_march(const float* x, const float* w, const float* y, fl
         a.in_sums = in_sums->partials;
         in_sums->splits = splits;
     }
-    const unsigned waves = (unsigned)ceil_div(a.g.bands, a.g.G), blocks = (waves + 3) / 4;
+    const unsigned waves = dwm_waves(a.g, (long long)s.N * s.C), blocks = (waves + 3) / 4;
     hipStream_t st = current_stream();
     bool relu = act == BCNN_HIP_ACT_RELU && (!in || in->act == BCNN_HIP_ACT_RELU);
     if (BCNN_EXP_ENV("BCNN_HIP_DWM_NORELU")) relu = false;  // A/B switch (experiment build only)

@@ -414,7 +414,7 @@ void batchnorm_backward_sums(const float* dy, const float* y, int act, const flo
                              const float* saved_mean, const float* saved_var, float* dmean, float* dvar,
                              const float* workspace, int n, int c, int hw, const float* fwd_bias, const float* res,
                              unsigned res_count, float4* consts = nullptr, float consts_fM = 0.f);
-float4* bn_consts_scratch(int channels);  // batchnorm.hip: the per-channel constants its backward finalize kernel leaves
+float4* bn_consts_scratch(int channels, bool required);  // batchnorm.hip: the per-channel constants its backward finalize kernel leaves
 
 }  // namespace bcnn_hip
 
@@ -497,7 +497,7 @@ void bcnn_hip_maxpool_bn_backward(const float* dpool, const int* indexes, const 
         fprintf(stderr, "[bcnn_hip] bcnn_hip_maxpool_bn_backward: not fusable (ask bcnn_hip_maxpool_bn_backward_fusable)\n");
         exit(1);
     }
-    float4* consts = bn_consts_scratch(c);
+    float4* consts = bn_consts_scratch(c, true);
     const float fM = (float)((long long)n * h * w);  // the un-pooled element count divides dmean and the dvar term
     // S1 = sum g act'(y), S2 = sum g act'(y) (x - mean) of the batch-norm backward: the gradient of the un-pooled tensor is
     // zero except where a window's maximum sits, and there it is the sum of the pooled gradients that selected the place --
