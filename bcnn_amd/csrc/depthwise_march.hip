@@ -38,6 +38,12 @@ namespace {
 #define DWM_BWD_WAVES 3  // waves per SIMD the backward kernels are compiled for (register budget 512 / that; at 4 the
                          // 112 x 112 instance spills inside its loop and takes twice the time)
 #endif
+#ifndef DWM_BWD_WAVES_SMALL
+#define DWM_BWD_WAVES_SMALL 3  // the same for lanes of 2 / 1 columns
+#endif
+#ifndef DWM_BWD_PF_SMALL
+#define DWM_BWD_PF_SMALL 4  // backward, lanes of 2 / 1 columns: rows requested ahead
+#endif
 #ifndef DWM_ROWS
 #define DWM_ROWS 14  // rows a band marches (target; the plan evens bands out)
 #endif
@@ -406,8 +412,11 @@ struct DwmBnC {
     bool sc0, any_sc0;
 };
 
-template <int S, int V, bool BN, bool BNIN, bool RELU>
-__global__ __launch_bounds__(256, DWM_BWD_WAVES) void dwm_bwd_kernel(const DwmBwdArgs a) {
+// PF: rows requested ahead of their use. 1 where a lane's rows are 16 bytes wide (the window already fills the register
+// budget of three waves per SIMD); small planes -- whole 14 x 14 / 7 x 7 planes per band, 8- and 4-byte rows, a few hundred
+// vector instructions per step -- were latency bound at 1 (waves 78 % waiting, 2.7 TB/s): they request PF = 4 rows ahead.
+template <int S, int V, bool BN, bool BNIN, bool RELU, int PF>
+__global__ __launch_bounds__(256, V == 4 ? DWM_BWD_WAVES : DWM_BWD_WAVES_SMALL) void dwm_bwd_kernel(const DwmBwdArgs a) {
     __shared__ float red[4][kDwmPart * kSlab];
     const int act = RELU ? BCNN_HIP_ACT_RELU : a.act, in_act = RELU ? BCNN_HIP_ACT_RELU : a.in.act;
     constexpr int GV = S == 1 ? V : V / 2;  // gradient values per lane and row
@@ -528,22 +537,30 @@ __global__ __launch_bounds__(256, DWM_BWD_WAVES) void dwm_bwd_kernel(const DwmBw
         };
         auto step_row = [&](int st) -> int { return st <= nrows ? rf + dir * st : -1; };
         Row<V> P = make_g(fetch_g(rf - dir), rf - dir), Q = make_g(fetch_g(step_row(0)), step_row(0));
-        Raw gn = fetch_g(step_row(1));
-        Vals<V> xn = dwm_ld<V>(a.x, xo, m.on && nrows > 0);
-        for (int k = 0; k < a.g.len; ++k) {
-            const bool valid = k < nrows;
-            const Raw gc = gn;
-            const Vals<V> xraw = xn;
-            gn = fetch_g(step_row(k + 2));
-            xn = dwm_ld<V>(a.x, xo + xstep, m.on && k + 1 < nrows);
-            const Row<V> Nx = make_g(gc, step_row(k + 1));
-            if (valid) {
-                if (m.up) body(Nx, Q, P, xraw);
-                else body(P, Q, Nx, xraw);
+        Raw gring[PF];      // gradient rows of steps k + 1 .. k + PF (the row ahead of the window), requested PF steps early
+        Vals<V> xring[PF];  // the band's own x rows of steps k .. k + PF - 1
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            gring[u] = fetch_g(step_row(1 + u));
+            xring[u] = dwm_ld<V>(a.x, xo + (unsigned)u * xstep, m.on && u < nrows);
+        }
+        for (int k0 = 0; k0 < a.g.len; k0 += PF) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int k = k0 + u;
+                const Raw gc = gring[u];
+                const Vals<V> xraw = xring[u];
+                gring[u] = fetch_g(step_row(k + 1 + PF));
+                xring[u] = dwm_ld<V>(a.x, xo + (unsigned)PF * xstep, m.on && k + PF < nrows);
+                const Row<V> Nx = make_g(gc, step_row(k + 1));
+                if (k < nrows) {
+                    if (m.up) body(Nx, Q, P, xraw);
+                    else body(P, Q, Nx, xraw);
+                }
+                xo += xstep;
+                P = Q;
+                Q = Nx;
             }
-            xo += xstep;
-            P = Q;
-            Q = Nx;
         }
     } else {
         // a gradient row: the lane's GV values and (index GV + 1 of the row) the right neighbour's first. Step k works on
@@ -590,24 +607,34 @@ __global__ __launch_bounds__(256, DWM_BWD_WAVES) void dwm_bwd_kernel(const DwmBw
         const int down1 = m.up ? 0 : 1;
         auto new_row = [&](int st) -> int { return st < nrows ? rf + dir * st + down1 : -1; };  // the gradient row step st adds
         Row<GV> X = make_g(fetch_g(m.on ? rf + 1 - down1 : -1), m.on ? rf + 1 - down1 : -1);   // carried: r (down) / r + 1 (up)
-        Raw gn = fetch_g(new_row(0));
-        Vals<V> xn0 = dwm_ld<V>(a.x, xo, m.on && nrows > 0), xn1 = dwm_ld<V>(a.x, xo + xrow, m.on && nrows > 0 && 2 * rf + 1 < a.H);
-        for (int k = 0; k < a.g.len; ++k) {
-            const int r = rf + dir * k;
-            const bool valid = k < nrows, odd_ok = valid && 2 * r + 1 < a.H;
-            const Raw gc = gn;
-            const Vals<V> xr0 = xn0, xr1 = xn1;
-            gn = fetch_g(new_row(k + 1));
-            const bool more = m.on && k + 1 < nrows;
-            xn0 = dwm_ld<V>(a.x, xo + xstep, more);
-            xn1 = dwm_ld<V>(a.x, xo + xstep + xrow, more && 2 * (r + dir) + 1 < a.H);
-            const Row<GV> Nw = make_g(gc, new_row(k));
-            if (valid) {
-                if (m.up) body(Nw, X, xr0, xr1, odd_ok);
-                else body(X, Nw, xr0, xr1, odd_ok);
+        Raw gring[PF];                 // the gradient rows steps k .. k + PF - 1 add
+        Vals<V> xring0[PF], xring1[PF];  // input rows 2r, 2r + 1 of those steps
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            gring[u] = fetch_g(new_row(u));
+            const bool on = m.on && u < nrows;
+            xring0[u] = dwm_ld<V>(a.x, xo + (unsigned)u * xstep, on);
+            xring1[u] = dwm_ld<V>(a.x, xo + (unsigned)u * xstep + xrow, on && 2 * (rf + dir * u) + 1 < a.H);
+        }
+        for (int k0 = 0; k0 < a.g.len; k0 += PF) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int k = k0 + u, r = rf + dir * k;
+                const bool valid = k < nrows, odd_ok = valid && 2 * r + 1 < a.H;
+                const Raw gc = gring[u];
+                const Vals<V> xr0 = xring0[u], xr1 = xring1[u];
+                gring[u] = fetch_g(new_row(k + PF));
+                const bool more = m.on && k + PF < nrows;
+                xring0[u] = dwm_ld<V>(a.x, xo + (unsigned)PF * xstep, more);
+                xring1[u] = dwm_ld<V>(a.x, xo + (unsigned)PF * xstep + xrow, more && 2 * (r + dir * PF) + 1 < a.H);
+                const Row<GV> Nw = make_g(gc, new_row(k));
+                if (valid) {
+                    if (m.up) body(Nw, X, xr0, xr1, odd_ok);
+                    else body(X, Nw, xr0, xr1, odd_ok);
+                }
+                xo += xstep;
+                X = Nw;
             }
-            xo += xstep;
-            X = Nw;
         }
     }
     const int splits = (int)(a.g.bands / a.C);  // N * BPP
@@ -737,12 +764,13 @@ bool depthwise_backward_march(const float* x, const float* w, const float* y, fl
     hipStream_t st = current_stream();
     bool relu = act == BCNN_HIP_ACT_RELU && (!in || in->act == BCNN_HIP_ACT_RELU);
     if (BCNN_EXP_ENV("BCNN_HIP_DWM_NORELU")) relu = false;  // A/B switch (experiment build only)
-#define DWM_LAUNCH_R(SV, VV, RV)                                                                 \
-    do {                                                                                         \
-        if (bn && in) dwm_bwd_kernel<SV, VV, true, true, RV><<<blocks, 256, 0, st>>>(a);         \
-        else if (bn) dwm_bwd_kernel<SV, VV, true, false, RV><<<blocks, 256, 0, st>>>(a);         \
-        else if (in) dwm_bwd_kernel<SV, VV, false, true, RV><<<blocks, 256, 0, st>>>(a);         \
-        else dwm_bwd_kernel<SV, VV, false, false, RV><<<blocks, 256, 0, st>>>(a);                \
+#define DWM_LAUNCH_R(SV, VV, RV)                                                                                    \
+    do {                                                                                                            \
+        constexpr int PFV = (VV) == 4 ? 1 : DWM_BWD_PF_SMALL;                                                       \
+        if (bn && in) dwm_bwd_kernel<SV, VV, true, true, RV, PFV><<<blocks, 256, 0, st>>>(a);                       \
+        else if (bn) dwm_bwd_kernel<SV, VV, true, false, RV, PFV><<<blocks, 256, 0, st>>>(a);                       \
+        else if (in) dwm_bwd_kernel<SV, VV, false, true, RV, PFV><<<blocks, 256, 0, st>>>(a);                       \
+        else dwm_bwd_kernel<SV, VV, false, false, RV, PFV><<<blocks, 256, 0, st>>>(a);                              \
     } while (0)
 #define DWM_LAUNCH(SV, VV)                     \
     do {                                       \
