@@ -255,6 +255,52 @@ __global__ __launch_bounds__(64 * NSUB) void conv_dw_dma_finalize_kernel(const f
     }
 }
 
+// The same sums (same association per element: bit-identical results) for ONE tap -- the pointwise layers, where dw[f][c] is
+// contiguous in c -- with 16 bytes per thread: a wave row reads 1 KB contiguous pieces of every split instead of 256 bytes
+// (the 4-byte version read the 32 MB of a 512 x 512 layer's 32 splits at 1.5 TB/s, 22 us per launch, 12 launches per
+// MobileNet step). Requires Cg % 4 == 0 and 16-byte aligned dw / partials.
+template <int NSUB>
+__global__ __launch_bounds__(64 * NSUB) void conv_dw_dma_finalize_x4_kernel(const float* __restrict__ partials, int qsplits,
+                                                                           int groups, int Mg, int Cg, int Mpad, int Npad,
+                                                                           float* __restrict__ dw) {
+    __shared__ float4 red[NSUB][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const size_t total4 = (size_t)groups * Mg * Cg / 4;
+    const size_t i4 = (size_t)blockIdx.x * 64 + tx;
+    const size_t plane = (size_t)Mpad * Npad;
+    const size_t qstride = (size_t)groups * plane;
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i4 < total4) {
+        const size_t i = i4 * 4;
+        const int c = (int)(i % Cg);
+        const size_t t = i / Cg;
+        const int f = (int)(t % Mg), g = (int)(t / Mg);
+        const float* p = partials + (size_t)g * plane + (size_t)f * Npad + c;
+        auto ld = [&](int qs) { return *reinterpret_cast<const float4*>(p + (size_t)qs * qstride); };
+        auto acc = [](float4& a, const float4& v) { a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; };
+        float4 s0 = sum, s1 = sum, s2 = sum, s3 = sum;
+        int qs = ty;
+        for (; qs + 3 * NSUB < qsplits; qs += 4 * NSUB) {
+            const float4 v0 = ld(qs), v1 = ld(qs + NSUB), v2 = ld(qs + 2 * NSUB), v3 = ld(qs + 3 * NSUB);
+            acc(s0, v0); acc(s1, v1); acc(s2, v2); acc(s3, v3);
+        }
+        for (; qs < qsplits; qs += NSUB) acc(s0, ld(qs));
+        sum = make_float4((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z),
+                          (s0.w + s1.w) + (s2.w + s3.w));
+    }
+    red[ty][tx] = sum;
+    __syncthreads();
+    if (ty == 0 && i4 < total4) {
+        float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < NSUB; ++r) { tot.x += red[r][tx].x; tot.y += red[r][tx].y; tot.z += red[r][tx].z; tot.w += red[r][tx].w; }
+        float4* o = reinterpret_cast<float4*>(dw) + i4;  // (((g * Mg + f) * Cg + c) * 1 + 0) / 4 == i4
+        float4 d = *o;
+        d.x += tot.x; d.y += tot.y; d.z += tot.z; d.w += tot.w;
+        *o = d;
+    }
+}
+
 // ---- host side ------------------------------------------------------------------------------------------
 struct DwTile { int bm, bn, threads; };
 constexpr int kNumDwTiles = 6;
@@ -340,7 +386,12 @@ bool conv_backward_weights_dma(const float* x, const float* dy, float* dw, const
     }
     KERNEL_CHECK();
     const size_t total = (size_t)s.groups * s.Mg * s.Cg * p.kk2;
-    if (p.qsplits > 16)
+    static const bool x4_on = BCNN_EXP_ENV("BCNN_HIP_NO_DW_FINALIZE_X4") == nullptr;  // A/B switch (experiment build only)
+    if (x4_on && p.kk2 == 1 && p.qsplits > 16 && (s.Cg & 3) == 0 && (p.Npad & 3) == 0 &&
+        ((reinterpret_cast<uintptr_t>(dw) | reinterpret_cast<uintptr_t>(workspace)) & 15) == 0)
+        conv_dw_dma_finalize_x4_kernel<16><<<(unsigned)((total / 4 + 63) / 64), 1024, 0, current_stream()>>>(
+            workspace, p.qsplits, s.groups, s.Mg, s.Cg, p.Mpad, p.Npad, dw);
+    else if (p.qsplits > 16)
         conv_dw_dma_finalize_kernel<16><<<(unsigned)((total + 63) / 64), 1024, 0, current_stream()>>>(
             workspace, p.qsplits, s.groups, s.Mg, s.Cg, p.kk2, p.Mpad, p.Npad, dw);
     else

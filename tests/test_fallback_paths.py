@@ -15,9 +15,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"BCNN_HIP_NO_DMA": "1"}, {"BCNN_HIP_NO_FUSED_STATS": "1"},
-                                 {"BCNN_HIP_NO_SMALLC_DX": "1", "BCNN_HIP_NO_PREFETCH": "1"}, {"BCNN_HIP_NO_DW_LDS": "1"}],
+                                 {"BCNN_HIP_NO_SMALLC_DX": "1", "BCNN_HIP_NO_PREFETCH": "1"}, {"BCNN_HIP_NO_DW_LDS": "1"},
+                                 {"BCNN_HIP_NO_DW_MARCH": "1"}, {"BCNN_HIP_BN_NO_CONSTS": "1", "BCNN_HIP_FLAT_MAP_DIV": "1"}],
                          ids=["register_staged_kernels", "unfused_bn_statistics", "implicit_gemm_dx_for_small_c",
-                              "register_window_depthwise_kernels"])
+                              "register_window_depthwise_kernels", "lds_staged_depthwise_kernels",
+                              "batchnorm_constants_in_the_bodies"])
 def test_golden_suite_on_the_other_code_path(env):
     e = dict(os.environ)
     e.update(env)
@@ -125,3 +127,43 @@ def test_depthwise_batchnorm_backward_fusion_trains_bit_identically():
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         shas.append([ln for ln in r.stdout.splitlines() if ln.startswith("SHA")][0])
     assert shas[0] == shas[1]
+
+
+_PW_DW = r"""
+import hashlib, sys
+sys.path.insert(0, %r)
+import torch
+from bcnn_amd import ops
+torch.manual_seed(5)
+n, c, hw, f = 64, 128, 28, 256            # pointwise layer: 50176 pixels -> more than 16 splits of the reduction
+x = torch.rand((n, c, hw, hw), device="cuda:0") * 2 - 1
+dy = (torch.rand((n, f, hw, hw), device="cuda:0") * 2 - 1) * 0.01
+w = torch.rand((f, c, 1, 1), device="cuda:0") - 0.5
+y = torch.empty((n, f, hw, hw), device="cuda:0")
+dw = torch.full((f, c, 1, 1), 0.25, device="cuda:0")      # accumulates onto what is there (momentum carry)
+db = torch.zeros(f, device="cuda:0")
+ws = torch.zeros(max(1, ops.conv_workspace_size(n, c, hw, hw, f, 1, 1, 0, 1)), device="cuda:0")
+ops.conv_backward(x, w, y, dy, None, dw, db, 1, 1, 0, 1, 0, ws)
+torch.cuda.synchronize()
+ref = torch.einsum("nfp,ncp->fc", dy.view(n, f, -1).double(), x.view(n, c, -1).double()) + 0.25
+err = float((dw.view(f, c).double() - ref).abs().max() / ref.abs().max())
+print("ERR", err)
+print("SHA", hashlib.sha256(dw.cpu().numpy().tobytes()).hexdigest())
+""" % ROOT
+
+
+@pytest.mark.gpu
+def test_sixteen_byte_weight_gradient_finalize_equals_the_four_byte_one_bit_for_bit():
+    """conv_dw_dma_finalize_x4_kernel (pointwise layers: 16 bytes per thread over the splits) forms every element's sum in
+    the association of conv_dw_dma_finalize_kernel: the weight gradient of a 1x1 layer must not change by a bit when the
+    experiment library is told to use the four-byte kernel (BCNN_HIP_NO_DW_FINALIZE_X4), and it matches float64."""
+    lib = os.path.join(ROOT, "bcnn_amd", "lib", "libbcnn_hip_exp.so")
+    outs = []
+    for extra in ({}, {"BCNN_HIP_NO_DW_FINALIZE_X4": "1"}):
+        e = dict(os.environ, BCNN_HIP_LIB=lib, **extra)
+        r = subprocess.run([sys.executable, "-c", _PW_DW], cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        lines = {ln.split()[0]: ln.split()[1] for ln in r.stdout.splitlines() if ln.startswith(("ERR", "SHA"))}
+        assert float(lines["ERR"]) < 1e-5, lines
+        outs.append(lines["SHA"])
+    assert outs[0] == outs[1]
