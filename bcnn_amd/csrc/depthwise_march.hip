@@ -693,9 +693,13 @@ bool depthwise_forward_march(const float* x, const float* w, const float* bias, 
     a.in = in ? *in : DwBnIn{nullptr, nullptr, nullptr, nullptr, 0};
     const unsigned waves = dwm_waves(a.g, (long long)s.N * s.C), blocks = (waves + 3) / 4;
     hipStream_t st = current_stream();
-    int pf = 2;
+    // rows requested ahead: 2 for 16-byte lanes at stride 1 (with the producer's batch-norm applied on load the kernel is vector-ALU
+    // bound and 4 costs it two waves per SIMD), 4 at stride 2 and for the 8- / 4-byte lanes of small planes (latency bound)
+    int pf = (s.stride == 2 || a.g.V < 4) ? 4 : 2;
 #ifdef BCNN_HIP_EXPERIMENT
     if (const char* e = getenv("BCNN_HIP_DWM_PF")) pf = atoi(e);
+    if (s.stride == 2) { if (const char* e = getenv("BCNN_HIP_DWM_PF_S2")) pf = atoi(e); }
+    if (a.g.V < 4) { if (const char* e = getenv("BCNN_HIP_DWM_PF_SMALL")) pf = atoi(e); }
 #endif
     bool relu = act == BCNN_HIP_ACT_RELU && (!in || in->act == BCNN_HIP_ACT_RELU);
     if (BCNN_EXP_ENV("BCNN_HIP_DWM_NORELU")) relu = false;  // A/B switch (experiment build only)
@@ -711,9 +715,9 @@ bool depthwise_forward_march(const float* x, const float* w, const float* bias, 
 #define DWM_FWD_PF(SV, VV, BV)                                                                      \
     do {                                                                                            \
         if (!relu) dwm_fwd_kernel<SV, VV, BV, 2, false><<<blocks, 256, 0, st>>>(a);                 \
-        else dwm_fwd_kernel<SV, VV, BV, 2, true><<<blocks, 256, 0, st>>>(a);                        \
+        else if (pf == 2) dwm_fwd_kernel<SV, VV, BV, 2, true><<<blocks, 256, 0, st>>>(a);           \
+        else dwm_fwd_kernel<SV, VV, BV, 4, true><<<blocks, 256, 0, st>>>(a);                        \
     } while (0)
-    (void)pf;
 #endif
 #define DWM_FWD(SV, VV)                      \
     do {                                     \
