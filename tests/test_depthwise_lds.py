@@ -39,6 +39,13 @@ SHAPES = [
     (2, 3, 20, 20, 1, ACT_LOGISTIC),
     (2, 3, 20, 20, 1, ACT_SOFTPLUS),  # expensive derivative: separate pass, then the fused kernel
     (1, 2, 24, 300, 1, ACT_RELU),     # wide rows
+    # depthwise_march.hip: an odd number of bands per plane (3: two march down, one up; the odd waves hold fewer bands),
+    # ragged last band, both strides; width 6 (lanes of 2 columns, 21 bands per wave); width 5 at stride 1 (lanes of 1 column)
+    (2, 3, 41, 40, 1, ACT_RELU),
+    (2, 3, 83, 40, 2, ACT_RELU),
+    (3, 5, 33, 6, 1, ACT_LRELU),
+    (3, 5, 33, 6, 2, ACT_RELU),
+    (2, 7, 30, 5, 1, ACT_RELU),
 ]
 
 
