@@ -10,11 +10,12 @@
 // 112 x 112 backward (118 per element and lane, 82 % of the SIMD issue cycles), most of them staging -- image scatter with
 // magic divisions, zero fill, collect-and-copy-out loops, per-item index arithmetic -- around ~45 instructions of real work.
 // Here nothing is staged:
-//   * a lane's window is a float4 per row plus the two neighbour values it takes from the adjacent lanes with
+//   * a lane's window is V floats per row plus the two neighbour values it takes from the adjacent lanes with
 //     ds_bpermute (no LDS storage, no vector-ALU cost); image borders are a select per row, rows outside the image are
 //     zeros that never left a register;
 //   * all global traffic is one V-float access per lane (stride 2 outputs: V / 2) with the lanes of a row contiguous, loaded
-//     one or two rows ahead of its use; every element is read once per band (plus one halo row per band end, an L2 hit);
+//     one to four rows ahead of its use; every element is read once per band, plus one halo row per band end -- an L2 hit,
+//     because the two bands either side of a boundary march towards each other (dwm_map);
 //     addresses are a uniform base plus a 32-bit byte offset per lane, advanced by one add per row and stream;
 //   * results go straight from registers to global memory;
 //   * lanes of a wave that do not fit a row (64 mod W/V) idle; a wave holds 64 / (W/V) independent bands, which may lie in
