@@ -60,6 +60,7 @@ struct DmaClass {
     int ih0, iw0, Hc, Wc;  // dX: first row/col and extent of the stride-parity class (forward: 0,0,OH,OW)
     int ntaps, tap0;       // taps of the class, index of its first tap in the packed At
     int nkx, sgn;          // tap t = (i, j) = (t / nkx, t % nkx) shifts the gathered element by sgn * (i, j)
+    unsigned cpi_magic, wc_magic;  // floor(2^32 / columns per image), floor(2^32 / Wc) (0: divisor 1), set by launch_dma
 };
 
 struct DmaArgs {
@@ -156,10 +157,19 @@ __global__ __launch_bounds__(64 * WM * WN, ABL_LB) void conv_igemm_dma_kernel(co
     const int lim_x = s.pointwise ? 1 : (fwd ? s.W : s.OW);
     const int row_stride = fwd ? s.W : s.OW;
 
+    // n / d for any 32-bit n with m = floor(2^32 / d): the multiply-high is at most one short, one compare puts it right
+    // (five vector instructions where the compiler's 32-bit division takes ~35: every thread decodes two columns per tile,
+    // and on a SIMD those instructions are taken from the MFMAs)
+    auto div_exact = [](unsigned n, unsigned d, unsigned m) -> unsigned {
+        if (m == 0u) return n;  // d == 1
+        unsigned q = __umulhi(n, m);
+        q += (n - q * d >= d) ? 1u : 0u;
+        return q;
+    };
     // decode one column -> element offset of tap (0,0) in the gathered tensor, its coordinates there, output offset
     auto decode = [&](int col, unsigned& pbase, int& cy, int& cx, unsigned& obase) -> bool {
         if (col >= total_cols) { pbase = 0; cy = -(1 << 20); cx = -(1 << 20); obase = 0; return false; }
-        const unsigned n = (unsigned)col / (unsigned)col_per_img;
+        const unsigned n = div_exact((unsigned)col, (unsigned)col_per_img, ci.cpi_magic);
         const unsigned pix = (unsigned)col - n * (unsigned)col_per_img;
         const unsigned in_img = n * (unsigned)s.C + (unsigned)(g * s.Cg), out_img = n * (unsigned)s.F + (unsigned)(g * s.Mg);
         if (s.pointwise) {  // raw [Cg][OH*OW] / [Mg][OH*OW] views on both sides
@@ -168,7 +178,7 @@ __global__ __launch_bounds__(64 * WM * WN, ABL_LB) void conv_igemm_dma_kernel(co
             obase = (fwd ? out_img * (unsigned)s.OHOW : in_img * (unsigned)s.HW) + pix;
             return true;
         }
-        const unsigned u = pix / (unsigned)c_Wc, v = pix - u * (unsigned)c_Wc;
+        const unsigned u = div_exact(pix, (unsigned)c_Wc, ci.wc_magic), v = pix - u * (unsigned)c_Wc;
         if (fwd) {
             cy = (int)u * s.stride - s.pad; cx = (int)v * s.stride - s.pad;
             pbase = (in_img * (unsigned)s.H + (unsigned)cy) * (unsigned)s.W + (unsigned)cx;
@@ -609,6 +619,12 @@ static void launch_dma_cfg(DmaArgs& a, int max_cols) {
 }
 
 static void launch_dma(DmaArgs& a, int max_cols) {
+    for (int c = 0; c < a.nclass && c < kDmaMaxClasses; ++c) {  // the divisors of the kernel's column decode
+        DmaClass& ci = a.cls[c];
+        const unsigned cpi = (unsigned)(a.s.pointwise ? a.s.OHOW : ci.Hc * ci.Wc), wc = (unsigned)ci.Wc;
+        ci.cpi_magic = cpi > 1u ? (unsigned)(0x100000000ULL / cpi) : 0u;
+        ci.wc_magic = wc > 1u ? (unsigned)(0x100000000ULL / wc) : 0u;
+    }
     switch (pick_dma_tile(a, max_cols)) {
         case 0: launch_dma_cfg<2, 2, 2, 2>(a, max_cols); break;  // 128 x 128
         case 1: launch_dma_cfg<1, 4, 2, 2>(a, max_cols); break;  //  64 x 256
