@@ -72,6 +72,20 @@ def depthwise_graph(net):
     net.avgpool("pw2", "avg")
 
 
+def depthwise_small_planes_graph(net):
+    """the tail of MobileNet-v1 in miniature: depthwise layers on 28 x 28, 14 x 14 and 7 x 7 planes, both strides, every one
+    between a 1x1 convolution with batch-norm (whose apply sweep the depthwise kernel takes over) and a stand-alone
+    batch-norm (whose backward it applies): the marching kernels with lanes of 4, 2 and 1 columns and both fusions"""
+    net.conv(8, 3, 2, 1, 1, 1, rb.ACT_RELU, "input", "stem")          # 56 -> 28
+    src = "stem"
+    for i, (width, stride) in enumerate(((16, 1), (16, 2), (24, 1), (24, 2), (32, 1)), start=1):
+        net.depthwise(3, stride, 1, rb.ACT_RELU, src, "dw%d" % i)      # planes 28, 28 -> 14, 14, 14 -> 7, 7
+        net.batchnorm("dw%d" % i, "dwbn%d" % i)
+        net.conv(width, 1, 1, 0, 1, 1, rb.ACT_RELU, "dwbn%d" % i, "pw%d" % i)
+        src = "pw%d" % i
+    net.avgpool(src, "avg")
+
+
 def prelu_node_graph(net):
     """a stand-alone PReLU activation node (the only stand-alone activation the reference's CPU build can run,
     bcnn_activation_layer.c:148-163): its slopes are stepped with batch_size = weights->n = 1, not the net's
@@ -91,16 +105,25 @@ GRAPHS = {
     # 1e-7 rounding noise (the reference's own results move with heap alignment of its AVX loops) to ~1e-4
     "lenet": (lenet_graph, dict(w=12, h=12, c=1, n=16), True),
     "mobilenet_unit": (depthwise_graph, dict(w=16, h=16, c=3, n=2), False),
+    "mobilenet_small_planes": (depthwise_small_planes_graph, dict(w=56, h=56, c=3, n=4), False),
 }
 
 
-def _compare(tag, a, b, tol=REL_TOL):
+ZERO_FLOOR = {
+    # absolute slack for values that are analytically zero -- the bias gradient of a layer in front of a batch-norm: both
+    # sides hold the rounding noise of a sum over N * H * W terms, which grows with the square root of the count (3136
+    # terms per channel on this graph's 28 x 28 planes against <= 512 on the others)
+    "mobilenet_small_planes": 4e-7,
+}
+
+
+def _compare(tag, a, b, tol=REL_TOL, floor=1e-7):
     assert a.shape == b.shape, (tag, a.shape, b.shape)
     # |a-b| <= tol*max|b| + 1e-7: gradients that are analytically zero (e.g. the bias of a BN feeding
     # another BN) are ~1e-9 noise on both sides and carry no relative information
     a64, b64 = np.asarray(a, np.float64), np.asarray(b, np.float64)
     diff = float(np.max(np.abs(a64 - b64))) if a64.size else 0.0
-    bound = tol * float(np.max(np.abs(b64))) + 1e-7 if b64.size else 0.0
+    bound = tol * float(np.max(np.abs(b64))) + floor if b64.size else 0.0
     assert diff <= bound, "%s: max abs diff %.3g > %.3g (rel %.3g)" % (tag, diff, bound, G.rel_err(a, b))
 
 
@@ -170,7 +193,8 @@ def test_net_matches_reference(gname):
             hip.download(i)
             _compare("%s it%d %s data" % (gname, it, names[i]), hip.data(i), ref.data(i))
             if ref.grad(i) is not None and i != 1:
-                _compare("%s it%d %s grad" % (gname, it, names[i]), hip.grad(i), ref.grad(i))
+                _compare("%s it%d %s grad" % (gname, it, names[i]), hip.grad(i), ref.grad(i),
+                         floor=ZERO_FLOOR.get(gname, 1e-7))
         ref.L.bcnn_update(ref.net)
         hip.update()
         for i in range(2, nt):
