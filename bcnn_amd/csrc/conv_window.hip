@@ -19,14 +19,19 @@
 #include "conv_common.h"
 #include "lds_dma.h"
 
+#include <mutex>
+
 // Timing experiments (tools/exp/win_variants.sh builds the file with -DWABL_*; normal builds define none of them):
-// WABL_NOSTORE / WABL_NOMFMA (forward), WABL_FWD_R (strip height), WABL_WAVES (launch bound), WABL_PREFETCH, ROWS_TM,
+// WABL_NOSTORE / WABL_NOMFMA (forward), WABL_FWD_R (strip height), WABL_NW (multiplying waves), WABL_NBUF, WABL_PREFETCH, ROWS_TM,
 // ROWS_INTERLEAVE, DY_DMA_PLAIN (dW).
 #ifndef WABL_FWD_R
-#define WABL_FWD_R 8
+#define WABL_FWD_R 4  // output rows per strip (round 5: the loader wave hides the fill, so the halo rows of short strips cost nothing;
+#endif                // forward-only loops 0.275 ms with 4 rows against 0.293 with 8, inside the fwd / dW alternation 0.305 / 0.31)
+#ifndef WABL_NBUF
+#define WABL_NBUF 2  // windows in LDS (loader form): the loader wave runs WABL_NBUF - 1 strips ahead
 #endif
-#ifndef WABL_WAVES
-#define WABL_WAVES 4
+#ifndef WABL_NW
+#define WABL_NW 8    // multiplying waves per workgroup of the forward kernel (4 / 7 / 12 / 15: +1 ... +4 %)
 #endif
 // Measured on configs[1] (tools/exp/win_variants.sh): one 8-wave workgroup per CU with both filter blocks 0.387 ms, two
 // independent 4-wave workgroups (one filter block each) 0.345; requests issued in one burst at the top of a row beat
@@ -87,46 +92,93 @@ struct ConvWindowFwdArgs {
     ConvShape s;
     int act, add_bias;
     int strips;  // ceil(OH / R)
+    int* sched;  // {next unit beyond the grid's first round, workgroups done}: both 0 between launches (nullptr: static walk)
 };
 
 // The window: [CG][R + 2][PITCH] floats, image row oh0 - pad + rr, image column L - kWinOrg.
-template <int CG, int R, int PITCH>
-__device__ __forceinline__ void window_fill(float* win, rsrc_i4 rx, const ConvShape& s, unsigned img_chan0, int oh0, int tid) {
-    constexpr int ROWS = R + 2, P4 = PITCH / 4;
-    for (int i = tid; i < CG * ROWS * P4; i += 256) {
-        const int c = i / (ROWS * P4), rem = i - c * (ROWS * P4);
-        const int rr = rem / P4, j = rem - rr * P4;
-        const int ih = oh0 - s.pad + rr, iw0 = 4 * j - kWinOrg;
-        const bool ok = (unsigned)ih < (unsigned)s.H && (unsigned)iw0 < (unsigned)s.W;  // W % 4 == 0: all four or none
-        const unsigned off = ok ? ((img_chan0 + (unsigned)c) * (unsigned)s.HW + (unsigned)(ih * s.W + iw0)) * 4u : kOOB;
-        const buf_f32x4 v = buffer_load_f32x4(rx, (int)off, 0, 0);
-        *reinterpret_cast<buf_f32x4*>(win + (c * ROWS + rr) * PITCH + 4 * j) = v;
-    }
-}
-
 // ================================================================================================
 // forward
 // ================================================================================================
-template <int CG, int R, int PITCH, int TM, int ACTM>
-__global__ __launch_bounds__(256, WABL_WAVES) void conv_fwd_window_kernel(const ConvWindowFwdArgs a) {
+// window_fill by LDS-DMA, for the loader wave: piece i (16 bytes) of the window lies at LDS byte 16 * i, so instruction k of
+// a wave deposits pieces 64 k ... 64 k + 63 in one 1 KB run; a lane's global offset is per piece (kOOB -> zeros: the padding)
+template <int CG, int R, int PITCH>
+__device__ __forceinline__ void window_fill_dma(unsigned lds_base, rsrc_i4 rx, const ConvShape& s, unsigned img_chan0, int oh0, int lane,
+                                                bool valid) {
+    constexpr int ROWS = R + 2, P4 = PITCH / 4, NP = CG * ROWS * P4;
+#pragma unroll 4
+    for (int k = 0; k < (NP + 63) / 64; ++k) {
+        const int i = k * 64 + lane;
+        const int c = i / (ROWS * P4), rem = i - c * (ROWS * P4);
+        const int rr = rem / P4, j = rem - rr * P4;
+        const int ih = oh0 - s.pad + rr, iw0 = 4 * j - kWinOrg;
+        const bool ok = valid && i < NP && (unsigned)ih < (unsigned)s.H && (unsigned)iw0 < (unsigned)s.W;
+        const unsigned off = ok ? ((img_chan0 + (unsigned)c) * (unsigned)s.HW + (unsigned)(ih * s.W + iw0)) * 4u : kOOB;
+        dma_row_x4(rx, lds_base + (unsigned)k * 1024u, off, 0);
+    }
+}
+
+// One persistent workgroup per CU: NW multiplying waves and one more wave that only moves input. While strip k is multiplied
+// out of one window, the loader wave asks a device counter for the next strip, fills the other window with LDS-DMA and waits
+// for it -- its vmcnt holds loads only, where a multiplying wave's counter is full of result stores that retire out of order
+// with loads -- so a strip costs the multiplying waves ONE barrier and no fill, and short strips (4 output
+// rows) cost nothing extra. 256 strips in flight instead of 1000+: fewer concurrent output streams is what the memory side
+// wants here (round 5, warm clocks, same box: one 4-wave workgroup per 8-row strip 0.33 ms; 1280 persistent 4-wave
+// workgroups 0.31-0.32; 256 x 8 waves + loader, 8-row strips 0.294; 4-row strips 0.275; the strips dealt out statically
+// instead of by the counter +0.01-0.04).
+template <int CG, int R, int PITCH, int TM, int ACTM, int NW>
+__global__ __launch_bounds__(64 * (NW + 1), 2) void conv_fwd_window_kernel(const ConvWindowFwdArgs a) {
     constexpr int ROWS = R + 2, PLANE = ROWS * PITCH;
+    constexpr int NBUF = WABL_NBUF;
+    constexpr int WINSZ = (CG * PLANE + 255) & ~255;  // floats per window buffer, whole DMA instructions
     constexpr WinSteps<CG> steps{};
     constexpr int NT = WinSteps<CG>::N;        // steps that read taps
     constexpr bool SPARE = (CG & 1) != 0;      // odd K: the last tap step's upper half-wave is free
     constexpr int KS = SPARE ? NT : NT + 1;    // + the bias: one more reduction row with B = 1 (like add_bias AFTER the gemm)
-    __shared__ __attribute__((aligned(16))) float win[CG * PLANE];
+    __shared__ __attribute__((aligned(1024))) float win_all[NBUF * WINSZ];
+    __shared__ int next_unit[NBUF < 2 ? 2 : NBUF];
     const ConvShape& s = a.s;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     const int g = blockIdx.y;
-    const int n = (int)blockIdx.x / a.strips, strip = (int)blockIdx.x - n * a.strips;
-    const int oh0 = strip * R;
-    const int rows_here = (s.OH - oh0 < R) ? s.OH - oh0 : R;
-
     const rsrc_i4 rx = make_rsrc(a.x, (unsigned)((long long)s.N * s.C * s.HW * 4));
     const rsrc_i4 ry = make_rsrc(a.y, (unsigned)((long long)s.N * s.F * s.OHOW * 4));
-    window_fill<CG, R, PITCH>(win, rx, s, (unsigned)(n * s.C + g * s.Cg), oh0, tid);
+    const int nunits = s.N * a.strips;
+    if (wid == NW) {
+        // ---- the loader wave: window k % NBUF and next_unit[k % NBUF] are ready before barrier k; the fill of strip
+        // k + NBUF - 2 is requested right after barrier k - 1 (its buffer held strip k - 2), so a fill has NBUF - 1 strip
+        // times to arrive. This wave's vmcnt counts nothing but its DMA instructions, which retire in order. ----
+        constexpr int NI = (CG * (R + 2) * (PITCH / 4) + 63) / 64;  // DMA instructions per window
+        constexpr int D = NBUF - 1;
+        static_assert((D - 1) * NI < 64, "vmcnt is a 6-bit counter");
+        int unit = (int)blockIdx.x;  // unit of the next strip to request
+        int j = 0;                   // its index
+        for (int k = 0;; ++k) {
+            for (; j <= k + D - 1; ++j) {
+                // beyond the last unit the same instructions run with every lane out of range (zeros into a window nobody
+                // reads): the count the wait below relies on stays the same
+                const int n = unit / a.strips, strip = unit - n * a.strips;
+                window_fill_dma<CG, R, PITCH>(lds_offset(win_all + (j % NBUF) * WINSZ), rx, s, (unsigned)(n * s.C + g * s.Cg), strip * R, lane,
+                                              unit < nunits);
+                if (lane == 0) next_unit[j % NBUF] = unit;
+                if (unit < nunits) {
+                    if (NBUF == 2 && a.sched) unit = (int)gridDim.x + __builtin_amdgcn_readfirstlane(lane == 0 ? atomicAdd(a.sched + 2 * g, 1) : 0);
+                    else unit += (int)gridDim.x;
+                }
+            }
+            dma_wait_n<(D - 1) * NI>();
+            lds_barrier();
+            if (__builtin_amdgcn_readfirstlane(next_unit[k % NBUF]) >= nunits) break;
+        }
+        dma_wait();
+        if (NBUF == 2 && a.sched && lane == 0) {  // the last workgroup of the launch to leave puts both counters back to zero
+            if (atomicAdd(a.sched + 2 * g + 1, 1) == (int)gridDim.x - 1) {
+                a.sched[2 * g] = 0;
+                a.sched[2 * g + 1] = 0;
+            }
+        }
+        return;
+    }
     // A operand: W[f = tm*32 + l31][tap of (step, half-wave)], zero where the tap or the filter does not exist; the bias
     // sits in the one reduction slot no tap uses
     const float* wg = a.w + (long long)g * s.Mg * s.K;
@@ -155,11 +207,8 @@ __global__ __launch_bounds__(256, WABL_WAVES) void conv_fwd_window_kernel(const 
         }
         if (!SPARE) areg[tm][KS - 1] = hi ? 0.f : bv;
     }
-    __syncthreads();
-
     // lane constants: LDS byte offset of the lane's pixel in window row 0 for each distance kind, output byte offset
     const int base_col = kWinOrg - s.pad;
-    const char* winb = reinterpret_cast<const char*>(win);
     int lds_lane[4];
     lds_lane[WD_ELEM] = 4 * (l31 + base_col + hi);
     lds_lane[WD_ROW] = 4 * (l31 + base_col + hi * PITCH);
@@ -167,11 +216,20 @@ __global__ __launch_bounds__(256, WABL_WAVES) void conv_fwd_window_kernel(const 
     lds_lane[WD_NONE] = 4 * (l31 + base_col);
     const unsigned fstride = (unsigned)s.OHOW * 4u;
     const unsigned y_lane = (unsigned)l31 * 4u + 4u * (unsigned)hi * fstride;
-    const unsigned y_img = ((unsigned)(n * s.F + g * s.Mg) * (unsigned)s.OHOW + (unsigned)(oh0 * s.OW)) * 4u;
     const int tpr = (s.OW + 31) >> 5;  // 32-pixel tiles per output row
-    const int ntile = rows_here * tpr;
     const bool full_m = (s.Mg == TM * 32);
     const bool ragged_w = (s.OW & 31) != 0;
+
+    // ---- the multiplying waves: strip iter comes out of window iter % NBUF; which unit it is, the loader wave says ----
+    int iter = 0;
+    lds_barrier();  // barrier 0: the first window is in place
+    for (int unit = (int)blockIdx.x; unit < nunits; ++iter) {
+    const int n = unit / a.strips, strip = unit - n * a.strips;
+    const int oh0 = strip * R;
+    const int rows_here = (s.OH - oh0 < R) ? s.OH - oh0 : R;
+    const char* winb = reinterpret_cast<const char*>(win_all + (iter % NBUF) * WINSZ);
+    const unsigned y_img = ((unsigned)(n * s.F + g * s.Mg) * (unsigned)s.OHOW + (unsigned)(oh0 * s.OW)) * 4u;
+    const int ntile = rows_here * tpr;
 
     int row = 0, ct = wid;
     while (ct >= tpr) { ct -= tpr; ++row; }
@@ -194,7 +252,7 @@ __global__ __launch_bounds__(256, WABL_WAVES) void conv_fwd_window_kernel(const 
         return (ragged_w && ct * 32 + l31 >= s.OW) ? kOOB : o;
     };
     auto step_tile = [&]() {
-        ct += 4;
+        ct += NW;
         while (ct >= tpr) { ct -= tpr; ++row; }
     };
     auto compute_store = [&](const float (&b)[KS], unsigned ycur) {
@@ -258,27 +316,51 @@ __global__ __launch_bounds__(256, WABL_WAVES) void conv_fwd_window_kernel(const 
     };
 
     // two operand buffers: the next tile's LDS reads are issued before the current tile's MFMAs
-    if (wid >= ntile) return;
+    if (wid < ntile) {  // wave-uniform; the barriers are reached by every wave
     float bufA[KS], bufB[KS];
     read_tile(bufA);
     int t = wid;
 #define WINDOW_STAGE(cur, nxt)                                       \
     {                                                                \
         const unsigned ycur = tile_out();                            \
-        const bool more = (t + 4 < ntile); /* wave-uniform */        \
+        const bool more = (t + NW < ntile); /* wave-uniform */       \
         if (more) {                                                  \
             step_tile();                                             \
             read_tile(nxt);                                          \
         }                                                            \
         compute_store(cur, ycur);                                    \
         if (!more) break;                                            \
-        t += 4;                                                      \
+        t += NW;                                                     \
     }
     for (;;) {
         WINDOW_STAGE(bufA, bufB)
         WINDOW_STAGE(bufB, bufA)
     }
 #undef WINDOW_STAGE
+    }
+    lds_barrier();  // barrier iter + 1: every wave is done with this window, the loader wave with the next one
+    unit = next_unit[(iter + 1) % NBUF];
+    }  // strips of this workgroup
+}
+
+// Counters of the dynamic strip walk: kSchedSlots x kSchedGroups pairs per device, zero when allocated and put back to zero by
+// every launch that used one; consecutive launches take consecutive slots, so two launches in flight on different streams
+// share a pair only if kSchedSlots launches lie between them.
+constexpr int kSchedSlots = 64, kSchedGroups = 8;
+static int* window_sched_slot(int groups) {
+    static int* base[64] = {};
+    static unsigned seq[64] = {};
+    static std::mutex mu;
+    if (groups > kSchedGroups) return nullptr;
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!base[dev]) {
+        HIP_CHECK(hipMalloc((void**)&base[dev], sizeof(int) * 2 * kSchedSlots * kSchedGroups));
+        HIP_CHECK(hipMemset(base[dev], 0, sizeof(int) * 2 * kSchedSlots * kSchedGroups));
+    }
+    return base[dev] + 2 * kSchedGroups * (seq[dev]++ % kSchedSlots);
 }
 
 static int window_pitch(const ConvShape& s) {
@@ -303,7 +385,6 @@ bool conv_forward_window(const float* x, const float* w, const float* bias, cons
     a.act = raw ? BCNN_HIP_ACT_NONE : act;
     a.add_bias = raw ? 0 : 1;
     a.strips = ceil_div(s.OH, R);
-    const dim3 grid((unsigned)(s.N * a.strips), (unsigned)s.groups);
     const int tm = (s.Mg <= 32) ? 1 : 2;
     const int actm = (a.act == BCNN_HIP_ACT_NONE) ? 0 : (a.act == BCNN_HIP_ACT_RELU ? 1 : 2);
     const int pitch = window_pitch(s);
@@ -312,7 +393,16 @@ bool conv_forward_window(const float* x, const float* w, const float* bias, cons
 #ifdef WABL_PREFETCH
     conv_prefetch_input(x, s, y);
 #endif
-#define LAUNCH4(CGv, Pv, TMv, Av) conv_fwd_window_kernel<CGv, R, Pv, TMv, Av><<<grid, 256, 0, current_stream()>>>(a)
+    // One workgroup per CU (fewer when there are fewer strips); strips beyond the first round are handed out by a device counter.
+    const int nunits = s.N * a.strips;
+    a.sched = window_sched_slot(s.groups);
+    int res = kCUs / s.groups > 0 ? kCUs / s.groups : 1;  // blockIdx.y = group
+#ifdef BCNN_HIP_EXPERIMENT
+    if (const char* genv = getenv("BCNN_HIP_WINDOW_GRID")) { if (atoi(genv) > 0) res = atoi(genv); }   // read per call: A/B inside one
+    if (const char* denv = getenv("BCNN_HIP_WINDOW_DYN")) { if (atoi(denv) == 0) a.sched = nullptr; }  // process (tools/exp/placement.py)
+#endif
+    const dim3 grid((unsigned)(nunits < res ? nunits : res), (unsigned)s.groups);
+#define LAUNCH4(CGv, Pv, TMv, Av) conv_fwd_window_kernel<CGv, R, Pv, TMv, Av, WABL_NW><<<grid, 64 * (WABL_NW + 1), 0, current_stream()>>>(a)
 #define LAUNCH3(CGv, Pv, TMv) do { if (actm == 0) LAUNCH4(CGv, Pv, TMv, 0); else if (actm == 1) LAUNCH4(CGv, Pv, TMv, 1); \
                                    else LAUNCH4(CGv, Pv, TMv, 2); } while (0)
 #define LAUNCH2(CGv, Pv) do { if (tm == 1) LAUNCH3(CGv, Pv, 1); else LAUNCH3(CGv, Pv, 2); } while (0)

@@ -123,6 +123,10 @@ def cpu_baseline(workload, sample_n):
                       % (workload, sample_n)}
 
 
+# (tests that compare parameter checksums between two runs need the same number of steps in both: no stretching there)
+MIN_WARM_S = 0.0 if os.environ.get("BENCH_TEST_CHECKSUM") == "1" else float(os.environ.get("BENCH_MIN_WARM_S", "0.08"))
+
+
 def read_profile(L):
     out = {}
     for cls in range(L.bcnn_hip_profile_num_classes()):
@@ -232,6 +236,7 @@ class Workload:
         import torch.distributed as dist
         from bcnn_amd import capi, ops
         self.name, self.n, self.world, self.L, self.net = name, n, world, L, None
+        self.dev, self.warmup_extra = dev, 0
         gen = torch.Generator(device=dev).manual_seed(1234 + rank)   # every rank owns different images
         dp = world > 1 or os.environ.get("BENCH_FORCE_DP") == "1"     # the env switch exercises the DP plumbing on 1 GPU
         if name in ("resnet18", "mobilenet"):
@@ -340,9 +345,33 @@ class Workload:
         import torch
         import torch.distributed as dist
         L = self.L
+        tw = time.perf_counter()
         for _ in range(warmup):
             self.step()
         L.bcnn_hip_sync()
+        torch.cuda.synchronize()
+        # Warm clocks: after an idle phase (building a workload is one) this part runs its first ~40 ms of load with the memory
+        # side not yet at speed -- tools/exp/pair_gap.py: the configs[1] step takes 0.70 ms for its first 24 repetitions,
+        # 0.60 for the next 24, 0.585 from there on, and again 0.70 after the host slept 2 s. W steps of a 0.6 ms workload
+        # are over long before that, so the untimed phase is stretched to MIN_WARM_S of wall time by further UNTIMED steps
+        # (their number is reported as `warmup_extra`); the timed region below is exactly `steps` steps either way.
+        self.warmup_extra = 0
+        if self.world > 1:
+            # every rank has to run the same number of steps (each one holds collectives): agree on the slowest rank's clock
+            spent = torch.tensor([time.perf_counter() - tw], dtype=torch.float64, device=self.dev if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(spent, op=dist.ReduceOp.MAX)
+            spent = float(spent.item())
+            per_step = spent / warmup if warmup > 0 else MIN_WARM_S / 4
+            extra = int(max(0.0, MIN_WARM_S - spent) / max(per_step, 1e-6) + 0.999)
+            for _ in range(min(extra, 1000)):
+                self.step()
+                self.warmup_extra += 1
+            L.bcnn_hip_sync()
+        else:
+            while time.perf_counter() - tw < MIN_WARM_S:
+                self.step()
+                L.bcnn_hip_sync()
+                self.warmup_extra += 1
         torch.cuda.synchronize()
         L.bcnn_hip_profile_reset()
         profile_every = max(1, int(os.environ.get("BENCH_PROFILE_EVERY", "4")))
@@ -502,7 +531,7 @@ def main():
         default_shape = n == wl.default_n and not args.input_grad
         out = {
             "metric": "images/sec fwd+bwd", "value": round(args.steps * n * world / dt, 2), "unit": "images/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_extra": wl.warmup_extra,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl.desc, "batch_per_gpu": n, "global_batch": n * world, "parallelism": "dp%d" % world},
@@ -524,12 +553,13 @@ def main():
     if rank == 0 and world == 1 and args.workload == "resnet18" and args.batch is None and not args.no_side_workloads \
             and os.environ.get("BENCH_FORCE_DP") != "1":
         side = {}
-        for name, sn, ssteps, swarm in (("conv3x3", 128, 20, 3), ("mobilenet", 256, 6, 2)):
+        for name, sn, ssteps, swarm in (("conv3x3", 128, 40, 3), ("mobilenet", 256, 6, 2)):
             torch.cuda.empty_cache()
             w2 = Workload(name, sn, 0, 1, dev, L, stream)
             sdt, sprof, sprofiled = w2.run(ssteps, swarm)
             side[name] = {"config": w2.desc, "images_per_s": round(ssteps * sn / sdt, 2),
                           "ms_per_step": round(sdt / ssteps * 1e3, 4), "steps": ssteps, "warmup": swarm,
+                          "warmup_extra": w2.warmup_extra,
                           "roofline": roofline_of(sprof, name, True),
                           "kernel_classes": class_table(sprof, sprofiled)}
             w2.close()

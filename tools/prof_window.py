@@ -20,7 +20,7 @@ ws = torch.zeros(max(1, ops.conv_workspace_size(n, c, h, w, f, 3, 1, 1, 1)), dev
 def run():
     ops.conv_forward(x, wt, bias, y, 3, 1, 1, 1, 0)
     ops.conv_backward(x, wt, y, dy, None, dw, db, 3, 1, 1, 1, 0, ws)
-for _ in range(3): run()
+for _ in range(int(os.environ.get('WARM', '100'))): run()   # the memory / fabric clocks need ~40 ms of load after an idle phase
 L.bcnn_hip_sync()
 L.bcnn_hip_profile_reset(); L.bcnn_hip_profile_enable(1)
 for _ in range(iters): run()
