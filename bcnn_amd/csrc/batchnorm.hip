@@ -26,21 +26,27 @@ struct ConstScratch {
     size_t cap = 0;
     int dev = -1;
 };
-static thread_local ConstScratch g_bn_consts;
+// One table per host thread AND device (a thread that alternates devices keeps each device's table). A thread drives
+// one stream at a time (runtime.hip: the current stream is per thread), and finalize -> apply run back to back on it: two nets
+// on different streams need two host threads, like every per-thread scratch of this library.
+constexpr int kMaxDevices = 64;
+static thread_local ConstScratch g_bn_consts[kMaxDevices];
 float4* bn_consts_scratch(int channels, bool required);
-float4* bn_consts_scratch(int channels, bool required) {  // grow-only, per host thread (= per stream): finalize -> apply only
+float4* bn_consts_scratch(int channels, bool required) {  // grow-only: finalize -> apply only
     if (!required && BCNN_EXP_ENV("BCNN_HIP_BN_NO_CONSTS")) return nullptr;  // A/B switch (experiment build): constants evaluated in the bodies
     int dev = 0;
     HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) { fprintf(stderr, "[bcnn_hip] device ordinal %d out of range\n", dev); exit(1); }
+    ConstScratch& sc = g_bn_consts[dev];
     const size_t need = (size_t)channels * 3;
-    if (g_bn_consts.p == nullptr || g_bn_consts.cap < need || g_bn_consts.dev != dev) {
-        if (g_bn_consts.p && g_bn_consts.dev == dev) HIP_CHECK(hipFree(g_bn_consts.p));  // hipFree syncs the device
+    if (sc.p == nullptr || sc.cap < need) {
+        if (sc.p) HIP_CHECK(hipFree(sc.p));  // hipFree syncs the device
         const size_t cap = need < 4096 ? 4096 : need * 2;
-        HIP_CHECK(hipMalloc((void**)&g_bn_consts.p, cap * sizeof(float4)));
-        g_bn_consts.cap = cap;
-        g_bn_consts.dev = dev;
+        HIP_CHECK(hipMalloc((void**)&sc.p, cap * sizeof(float4)));
+        sc.cap = cap;
+        sc.dev = dev;
     }
-    return g_bn_consts.p;
+    return sc.p;
 }
 __device__ __forceinline__ void bn_fwd_consts_store(float4* consts, int c, float mean, float var, const float* scale,
                                                     const float* bias) {

@@ -11,19 +11,21 @@ struct Scratch {
     size_t cap = 0;
     int dev = -1;
 };
-static thread_local Scratch g_scratch;
+static thread_local Scratch g_scratch[64];  // per host thread and device
 
 float* reduce_scratch(size_t floats) {
     int dev = 0;
     HIP_CHECK(hipGetDevice(&dev));
-    if (g_scratch.p == nullptr || g_scratch.cap < floats || g_scratch.dev != dev) {
-        if (g_scratch.p && g_scratch.dev == dev) HIP_CHECK(hipFree(g_scratch.p));  // hipFree syncs the device
+    if (dev < 0 || dev >= 64) { fprintf(stderr, "[bcnn_hip] device ordinal %d out of range\n", dev); exit(1); }
+    Scratch& sc = g_scratch[dev];
+    if (sc.p == nullptr || sc.cap < floats) {
+        if (sc.p) HIP_CHECK(hipFree(sc.p));  // hipFree syncs the device
         size_t cap = floats < (1u << 16) ? (1u << 16) : floats * 2;
-        HIP_CHECK(hipMalloc((void**)&g_scratch.p, cap * sizeof(float)));
-        g_scratch.cap = cap;
-        g_scratch.dev = dev;
+        HIP_CHECK(hipMalloc((void**)&sc.p, cap * sizeof(float)));
+        sc.cap = cap;
+        sc.dev = dev;
     }
-    return g_scratch.p;
+    return sc.p;
 }
 
 // ---- elementwise -------------------------------------------------------------------------------

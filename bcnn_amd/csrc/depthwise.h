@@ -53,6 +53,8 @@ bool depthwise_march_ok(const DwShape& s);
 size_t depthwise_march_splits(const DwShape& s);
 bool depthwise_forward_march(const float* x, const float* w, const float* bias, float* y, const DwShape& s, int act,
                              ConvStats* stats, const DwBnIn* in);
+bool depthwise_backward_march_takes(const float* x, const float* y, const float* dy, const float* dx, const DwShape& s, int act,
+                                    const DwBnBwd* bn, const DwBnIn* in);  // false: depthwise_backward_march would launch nothing
 bool depthwise_backward_march(const float* x, const float* w, const float* y, float* dy, float* dx, float* dw, float* dbias,
                               const DwShape& s, int act, int overwrite, int write_back, const DwBnBwd* bn, const DwBnIn* in,
                               ConvStats* in_sums);

@@ -702,10 +702,11 @@ void bcnn_hip_depthwise_backward(const float* x, const float* w, const float* y,
             bcnn_hip_activation_backward(y, dy, (size_t)total_o, act, nullptr, nullptr, ohow, c);
             a = BCNN_HIP_ACT_NONE;
         }
+        // a refusal (an LDS image above 64 KB on a shape the marching kernels do not take either) leaves dy as it was handed
+        // over: depthwise_backward_lds decides before it prepares anything
         if (depthwise_backward_lds(x, w, y, dy, dx, dw, dbias, s, a, overwrite, /*write_back=*/1, nullptr)) return;
-        if (a != act) {  // not reached: depthwise_lds_ok() is the kernel's only shape condition
-            fprintf(stderr, "[bcnn_hip] depthwise_backward_lds refused a shape depthwise_lds_ok accepted\n");
-            exit(1);
+        if (a != act) {  // the expensive derivative has been applied above: the generic path continues without it
+            act = BCNN_HIP_ACT_NONE;
         }
     }
     activation_backward_grad_bias(y, dy, dbias, n, c, ohow, act);  // one sweep: dy *= act'(y), dbias += sum

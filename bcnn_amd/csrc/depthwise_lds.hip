@@ -947,21 +947,11 @@ bool depthwise_backward_lds(const float* x, const float* w, const float* y, floa
     if (in_sums) in_sums->splits = 0;
     if (!depthwise_lds_ok(s) || !act_bwd_is_cheap(act) || act == BCNN_HIP_ACT_PRELU || !dx) return false;
     if (in && (!in->mean || !act_is_cheap(in->act) || in->act == BCNN_HIP_ACT_PRELU)) return false;
-    if (!bn && write_back && act != BCNN_HIP_ACT_NONE && act != BCNN_HIP_ACT_RELU && act != BCNN_HIP_ACT_CLAMP) {
-        // g = dy * act'(y) is written back over dy by the band that owns the row, while the neighbouring band reads the same
-        // row as its halo: harmless when applying the derivative twice changes nothing (a factor 0 or 1), a race otherwise
-        // (leaky ReLU: 0.01 instead of 0.1 on a band's edge row, whenever the owner happened to run first). Those
-        // activations get their own in-place pass first.
-        bcnn_hip_activation_backward(y, dy, (size_t)s.N * s.C * s.OH * s.OW, act, nullptr, nullptr, s.OH * s.OW, s.C);
-        act = BCNN_HIP_ACT_NONE;
-    }
-    if (depthwise_backward_march(x, w, y, dy, dx, dw, dbias, s, act, overwrite, write_back, bn, in, in_sums)) return true;
+    // Everything that can still refuse the layer is decided BEFORE dy is touched (a pre-pass followed by a refusal
+    // left the caller to apply the derivative a second time).
     DwlBwdArgs a;
     a.g = dwl_plan(s);
     const int S = s.stride, VR = S == 1 ? kVR1 : kVR2;
-    a.x = x; a.w = w; a.y = y; a.dy = dy; a.dx = dx;
-    a.C = s.C; a.H = s.H; a.W = s.W; a.OH = s.OH; a.OW = s.OW; a.planes = s.N * s.C; a.act = act;
-    a.overwrite = overwrite; a.write_back = write_back;
     a.splits = s.N * a.g.NB;
     a.RG = ceil_div(a.g.BR, VR);
     a.RGX = ceil_div(a.g.BR, 4);  // stride 1: a tile owns as many input rows as output rows
@@ -970,15 +960,6 @@ bool depthwise_backward_lds(const float* x, const float* w, const float* y, floa
     a.x_floats = (a.g.rows_x * a.g.PWX + 3) & ~3;
     if (a.x_floats < a.g.stage_floats) a.x_floats = a.g.stage_floats;  // the dx rows reuse the x image's space
     a.g_floats = (a.g.rows_g * a.g.PWG + 3) & ~3;
-    a.w_magic = dwl_magic((unsigned)s.W); a.h_magic = dwl_magic((unsigned)s.H);
-    a.ow_magic = dwl_magic((unsigned)s.OW); a.oh_magic = dwl_magic((unsigned)s.OH);
-    a.rg_magic = dwl_magic((unsigned)a.RG); a.rgx_magic = dwl_magic((unsigned)a.RGX);
-    a.hw2_magic = dwl_magic((unsigned)((s.W + 1) >> 1));
-    a.hw_magic = dwl_magic((unsigned)(s.H * s.W));
-    a.fM = (float)((long long)s.N * s.OH * s.OW);
-    a.rfM = 1.0f / a.fM;  // host division: IEEE, round to nearest
-    if (bn) a.bn = *bn;
-    else a.bn = DwBnBwd{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // the sums of the producer's batch-norm backward are of the COMPLETE gradient: only when this kernel is its sole writer;
     // for producer activations whose derivative is 0 or 1 (noted as one bit per element while staging); tiles of several
     // planes form g and g * (raw - mean) in LDS -- the dx piece and the g image's space, which then must hold a dx piece
@@ -990,7 +971,34 @@ bool depthwise_backward_lds(const float* x, const float* w, const float* y, floa
         else want_sums = false;
     }
     const size_t lds = (size_t)(a.x_floats + a.g_floats + a.g.P * kConst) * sizeof(float);
-    if (lds > 64 * 1024) return false;
+    const bool lds_takes = lds <= 64 * 1024;
+    const bool march_takes = depthwise_backward_march_takes(x, y, dy, dx, s, act, bn, in);
+    if (!lds_takes && !march_takes) return false;
+    if (!bn && write_back && act != BCNN_HIP_ACT_NONE && act != BCNN_HIP_ACT_RELU && act != BCNN_HIP_ACT_CLAMP) {
+        // g = dy * act'(y) is written back over dy by the band that owns the row, while the neighbouring band reads the same
+        // row as its halo: harmless when applying the derivative twice changes nothing (a factor 0 or 1), a race otherwise
+        // (leaky ReLU: 0.01 instead of 0.1 on a band's edge row, whenever the owner happened to run first). Those
+        // activations get their own in-place pass first.
+        bcnn_hip_activation_backward(y, dy, (size_t)s.N * s.C * s.OH * s.OW, act, nullptr, nullptr, s.OH * s.OW, s.C);
+        act = BCNN_HIP_ACT_NONE;
+    }
+    if (march_takes) {
+        if (depthwise_backward_march(x, w, y, dy, dx, dw, dbias, s, act, overwrite, write_back, bn, in, in_sums)) return true;
+        fprintf(stderr, "[bcnn_hip] depthwise_backward_march refused a layer depthwise_backward_march_takes accepted\n");
+        exit(1);
+    }
+    a.x = x; a.w = w; a.y = y; a.dy = dy; a.dx = dx;
+    a.C = s.C; a.H = s.H; a.W = s.W; a.OH = s.OH; a.OW = s.OW; a.planes = s.N * s.C; a.act = act;
+    a.overwrite = overwrite; a.write_back = write_back;
+    a.w_magic = dwl_magic((unsigned)s.W); a.h_magic = dwl_magic((unsigned)s.H);
+    a.ow_magic = dwl_magic((unsigned)s.OW); a.oh_magic = dwl_magic((unsigned)s.OH);
+    a.rg_magic = dwl_magic((unsigned)a.RG); a.rgx_magic = dwl_magic((unsigned)a.RGX);
+    a.hw2_magic = dwl_magic((unsigned)((s.W + 1) >> 1));
+    a.hw_magic = dwl_magic((unsigned)(s.H * s.W));
+    a.fM = (float)((long long)s.N * s.OH * s.OW);
+    a.rfM = 1.0f / a.fM;  // host division: IEEE, round to nearest
+    if (bn) a.bn = *bn;
+    else a.bn = DwBnBwd{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     a.partials = reduce_scratch((size_t)s.C * a.splits * kPart);
     a.in_sums = nullptr;
     if (want_sums) {

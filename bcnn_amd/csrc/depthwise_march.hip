@@ -739,15 +739,22 @@ bool depthwise_forward_march(const float* x, const float* w, const float* bias, 
     return true;
 }
 
+// every condition under which depthwise_backward_march launches nothing (a caller that has to prepare dy asks first)
+bool depthwise_backward_march_takes(const float* x, const float* y, const float* dy, const float* dx, const DwShape& s, int act,
+                                    const DwBnBwd* bn, const DwBnIn* in) {
+    if (!depthwise_march_ok(s) || !act_bwd_is_cheap(act) || act == BCNN_HIP_ACT_PRELU || !dx) return false;
+    if (in && (!in->mean || !act_is_cheap(in->act) || in->act == BCNN_HIP_ACT_PRELU)) return false;
+    const DwmGeom g = dwm_plan(s);
+    return dwm_aligned(g.V, {x, dx}) && dwm_aligned(s.stride == 1 ? g.V : g.V / 2, {y, dy, bn ? bn->dz : nullptr});
+}
+
 bool depthwise_backward_march(const float* x, const float* w, const float* y, float* dy, float* dx, float* dw, float* dbias,
                               const DwShape& s, int act, int overwrite, int write_back, const DwBnBwd* bn, const DwBnIn* in,
                               ConvStats* in_sums) {
     if (in_sums) in_sums->splits = 0;
-    if (!depthwise_march_ok(s) || !act_bwd_is_cheap(act) || act == BCNN_HIP_ACT_PRELU || !dx) return false;
-    if (in && (!in->mean || !act_is_cheap(in->act) || in->act == BCNN_HIP_ACT_PRELU)) return false;
+    if (!depthwise_backward_march_takes(x, y, dy, dx, s, act, bn, in)) return false;
     DwmBwdArgs a;
     a.g = dwm_plan(s);
-    if (!dwm_aligned(a.g.V, {x, dx}) || !dwm_aligned(s.stride == 1 ? a.g.V : a.g.V / 2, {y, dy, bn ? bn->dz : nullptr})) return false;
     a.x = x; a.w = w; a.y = y; a.dy = dy; a.dx = dx;
     a.C = s.C; a.H = s.H; a.W = s.W; a.OH = s.OH; a.OW = s.OW; a.act = act;
     a.overwrite = overwrite; a.write_back = write_back;

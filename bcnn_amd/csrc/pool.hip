@@ -484,6 +484,7 @@ int bcnn_hip_maxpool_bn_backward_fusable(int n, int c, int h, int w, int out_h, 
     const uintptr_t p8 = reinterpret_cast<uintptr_t>(dpool) | reinterpret_cast<uintptr_t>(indexes);
     return size == 3 && stride == 2 && (w & 3) == 0 && out_w * 2 == w && out_h * out_w > 0 &&
            (long long)n * c * h * w < 0x7fffffffLL && (long long)n * c <= 65535 && raw && dx && (p16 & 15) == 0 && (p8 & 7) == 0 &&
+           (long long)h * (w / 4) * (w / 4) < (1LL << 32) &&  // the kernel's t / (W / 4) by multiply-high is exact only while t * (W / 4) < 2^32
            act_is_cheap(act) && act_bwd_is_cheap(act) && act != BCNN_HIP_ACT_PRELU;
 }
 

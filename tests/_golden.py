@@ -33,3 +33,37 @@ def rel_err(a, b):
     b = np.asarray(b, np.float64)
     den = max(float(np.max(np.abs(b))), 1e-30)
     return float(np.max(np.abs(a - b))) / den
+
+
+# Element-wise bar next to the per-tensor norm: every element within rtol of ITS OWN reference value,
+# plus a floor of afrac of the tensor's largest magnitude for the elements that are sums cancelling to (almost) nothing --
+# rel_err alone leaves small-magnitude elements unconstrained.
+ELEM_RTOL, ELEM_AFRAC = 1e-4, 1e-5
+
+
+def elem_err(a, b, rtol=ELEM_RTOL, afrac=ELEM_AFRAC):
+    """(worst |a-b| / (rtol |b| + afrac max|b|), flat index of that element, a there, b there); <= 1 passes."""
+    a = np.asarray(a, np.float64).ravel()
+    b = np.asarray(b, np.float64).ravel()
+    if a.size == 0:
+        return 0.0, -1, 0.0, 0.0
+    bound = rtol * np.abs(b) + afrac * max(float(np.max(np.abs(b))), 1e-30)
+    ratio = np.abs(a - b) / bound
+    i = int(np.argmax(ratio))
+    return float(ratio[i]), i, float(a[i]), float(b[i])
+
+
+WORST = {}  # (tag) -> (rel_err, elem ratio): filled by assert_close, printed by tests/conftest.py at the end of a session
+
+
+def assert_close(tag, a, b, tol=1e-4, rtol=ELEM_RTOL, afrac=ELEM_AFRAC):
+    """both bars: max|a-b| / max|b| <= tol, and every element within rtol |b| + afrac max|b|; names the worst offender"""
+    err = rel_err(a, b)
+    ratio, i, av, bv = elem_err(a, b, rtol, afrac)
+    cls = str(tag).split("/")[-1]
+    old = WORST.get(cls, (0.0, 0.0))
+    WORST[cls] = (max(old[0], err), max(old[1], ratio))
+    assert err <= tol, "%s: rel err %.3g > %.1g" % (tag, err, tol)
+    assert ratio <= 1.0, ("%s: element %d is %.9g, reference %.9g: |diff| %.3g = %.2f x (%.0e |ref| + %.0e max|ref|)"
+                          % (tag, i, av, bv, abs(av - bv), ratio, rtol, afrac))
+    return err, ratio

@@ -39,6 +39,15 @@ SHAPES = [
     (2, 3, 20, 20, 1, ACT_LOGISTIC),
     (2, 3, 20, 20, 1, ACT_SOFTPLUS),  # expensive derivative: separate pass, then the fused kernel
     (1, 2, 24, 300, 1, ACT_RELU),     # wide rows
+    # rows too wide for the marching kernels, several bands per plane, an activation whose derivative is neither 0 nor 1: the
+    # pre-pass over dy, then the LDS kernel whose bands read their neighbours' edge rows (the halo race)
+    (1, 2, 24, 300, 1, ACT_LRELU),
+    (1, 2, 25, 300, 2, ACT_LRELU),
+    (1, 2, 24, 300, 1, ACT_SOFTPLUS),
+    # 2 x 500: neither 3x3 family takes it (more than 64 column groups; an LDS image above 64 KB) -- the refusal has to come
+    # BEFORE dy is prepared, or the generic path applies the derivative a second time
+    (1, 2, 2, 500, 1, ACT_LRELU),
+    (1, 3, 2, 508, 1, ACT_TANH),
     # depthwise_march.hip: an odd number of bands per plane (3: two march down, one up; the odd waves hold fewer bands),
     # ragged last band, both strides; width 6 (lanes of 2 columns, 21 bands per wave); width 5 at stride 1 (lanes of 1 column)
     (2, 3, 41, 40, 1, ACT_RELU),
