@@ -49,7 +49,7 @@ def lib():
     sig = {
         "bcnn_init_net": (i, [C.POINTER(vp), i]), "bcnn_end_net": (None, [C.POINTER(vp)]),
         "bcnn_set_log_context": (None, [vp, vp, i]), "bcnn_set_input_shape": (None, [vp, i, i, i, i]),
-        "bcnn_compile_net": (i, [vp]), "bcnn_set_mode": (i, [vp, i]),
+        "bcnn_compile_net": (i, [vp]), "bcnn_set_mode": (i, [vp, i]), "bcnn_resize_net": (i, [vp, i, i, i, i]),
         "bcnn_forward": (None, [vp]), "bcnn_backward": (None, [vp]), "bcnn_update": (None, [vp]),
         "bcnn_train_on_batch": (f, [vp]),
         "bcnn_set_sgd_optimizer": (None, [vp, f, f]), "bcnn_set_weight_regularizer": (None, [vp, f]),
@@ -138,6 +138,10 @@ class Net:
 
     def compile(self):
         assert self.L.bcnn_compile_net(self.net) == 0
+
+    def resize(self, w, h, c, need_realloc=True):
+        """bcnn_resize_net (reference bcnn_net.c:287-335): batch 1, destination tensors re-shaped (and re-allocated)"""
+        return self.L.bcnn_resize_net(self.net, w, h, c, 1 if need_realloc else 0)
 
     # tensors: host views; call download()/upload() around them
     def index(self, name):

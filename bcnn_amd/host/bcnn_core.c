@@ -480,6 +480,37 @@ static void relink_graph(bcnn_net *net) {
     hc->num_fill_chunks = -1;
 }
 
+/* Reference bcnn_net.c:287-335: new input extent (batch 1, like the reference's bcnn_set_input_shape(net, w, h, c, 1)), then
+ * the first destination tensor of every node re-shaped from its first source -- convolution and max-pooling by their output
+ * rules, every other node as a copy of the source's shape -- and, with need_realloc, re-allocated (host and device mirrors).
+ * As in the reference, layer-private buffers (batch-norm workspaces, pooling indexes, weights) keep the size they were built
+ * with: the call is meant for fully convolutional PREDICT nets that shrink or keep their extent. What this build derives
+ * from shapes (the conv scratch, the node-to-node links) is brought up to date before returning; the reference's function
+ * falls off its end without a return value, here the status is BCNN_SUCCESS. */
+bcnn_status bcnn_resize_net(bcnn_net *net, int w, int h, int c, int need_realloc) {
+    if (!net || w <= 0 || h <= 0 || c <= 0) return BCNN_INVALID_PARAMETER;
+    bcnn_set_input_shape(net, w, h, c, 1);
+    for (int i = 0; i < net->num_nodes; ++i) {
+        bcnn_node *nd = &net->nodes[i];
+        if (nd->num_src < 1 || nd->num_dst < 1) continue;
+        const bcnn_tensor *s = &net->tensors[nd->src[0]];
+        bcnn_tensor *d = &net->tensors[nd->dst[0]];
+        if (nd->type == BCNN_LAYER_CONV2D) {
+            const bcnn_conv_param *p = (const bcnn_conv_param *)nd->param;
+            bcnn_tensor_set_shape(d, s->n, p->num, (s->h + 2 * p->pad - p->size) / p->stride + 1,
+                                  (s->w + 2 * p->pad - p->size) / p->stride + 1, 1);
+        } else if (nd->type == BCNN_LAYER_MAXPOOL) {
+            const bcnn_maxpool_param *p = (const bcnn_maxpool_param *)nd->param;
+            bcnn_tensor_set_shape(d, s->n, s->c, (s->h - 1) / p->stride + 1, (s->w - 1) / p->stride + 1, 1);
+        } else {
+            bcnn_tensor_set_shape(d, s->n, s->c, s->h, s->w, 1);
+        }
+        if (need_realloc) BCNN_CHECK_STATUS(bcnn_tensor_allocate(d, net->mode));
+    }
+    if (hctx(net)->compiled) return bcnn_compile_net(net); /* input tensor, conv scratch, links */
+    return BCNN_SUCCESS;
+}
+
 bcnn_status bcnn_set_mode(bcnn_net *net, bcnn_mode mode) {
     if (net->mode == mode) return BCNN_SUCCESS;
     net->mode = mode;

@@ -15,10 +15,6 @@
         return BCNN_INVALID_PARAMETER;                                                                        \
     } while (0)
 
-bcnn_status bcnn_resize_net(bcnn_net *net, int w, int h, int c, int need_realloc) {
-    (void)w; (void)h; (void)c; (void)need_realloc;
-    NOT_BUILT(net, "bcnn_resize_net");
-}
 /* uint8 HWC image -> float CHW, reference bcnn_data.c:70-100 */
 void bcnn_convert_img_to_float(const uint8_t *src, int w, int h, int c, float norm_coeff, int swap_to_bgr,
                                float mean_r, float mean_g, float mean_b, float *dst) {

@@ -116,11 +116,27 @@ def cpu_baseline(workload, sample_n):
         if best is None or t < best[0]:
             best = (t, threads)
     t, threads = best
-    return {"value": round(sample_n / t, 2), "unit": "images/s", "cores": int(threads), "host_cores": ncpu, "kind": "reference",
-            "sample": "unmodified reference (oracle/_ref, AVX2+OpenMP, in-tree gemm), same %s graph at N=%d, "
-                      "bcnn_forward+bcnn_backward, best of 2 after 1 warm-up, best OpenMP team of {8,16,32} "
-                      "(`cores` = that team, `host_cores` = os.cpu_count())"
-                      % (workload, sample_n)}
+    out = {"value": round(sample_n / t, 2), "unit": "images/s", "cores": int(threads), "host_cores": ncpu, "kind": "reference",
+           "sample": "unmodified reference (oracle/_ref, AVX2+OpenMP, in-tree gemm), same %s graph at N=%d, "
+                     "bcnn_forward+bcnn_backward, best of 2 after 1 warm-up, best OpenMP team of {8,16,32} "
+                     "(`cores` = that team, `host_cores` = os.cpu_count())"
+                     % (workload, sample_n)}
+    if workload != "conv3x3" and sample_n < 8:
+        # the reference runs its GEMMs per image, so the batch does not change their shapes -- but at N=2 the fixed costs of a
+        # pass (OpenMP team start-up per gemm, batch-norm over two images) weigh more: the same graph at N=8 on the team
+        # chosen above is the headline CPU figure, the N=2 sample stays beside it
+        net = rb.RefNet(mode=rb.MODE_TRAIN, w=224, h=224, c=3, n=8)
+        (build_mobilenet_v1 if workload == "mobilenet" else build_resnet18)(net, rb)
+        net.compile()
+        net.L.ref_set_threads(net.net, threads)
+        net.data(0)[...] = rs.uniform(-1, 1, net.shape(0)).astype(np.float32)
+        t8, _, _ = net.time_fwd_bwd(1, 2)
+        net.close()
+        out["also"] = {"n": sample_n, "value": out["value"]}
+        out["value"] = round(8 / t8, 2)
+        out["sample"] = out["sample"].replace("at N=%d" % sample_n, "at N=8 (team chosen on N=%d, which gave %.2f images/s)"
+                                              % (sample_n, out["also"]["value"]))
+    return out
 
 
 # (tests that compare parameter checksums between two runs need the same number of steps in both: no stretching there)
@@ -215,8 +231,10 @@ def roofline_of(prof, workload, traffic_ok):
     if "winograd" in name:
         # the class timers of the Winograd kernels carry the FLOPs the MFMAs really execute (16 instead of 36
         # multiplies per 2x2 outputs: DESIGN.md section 4.8); the direct-convolution count of the same layers is 2.25x that
-        roof["flops_counted"] = "executed (Winograd transformed domain); direct-equivalent rate = 2.25 x achieved"
-        roof["direct_equivalent_tflops"] = round(2.25 * tf, 2)
+        roof["flops_counted"] = ("executed (Winograd transformed domain); direct-equivalent rate = 2.25 x the rate of the "
+                                 "multiplies that are not tile padding")
+        useful_tf = d.get("useful_flops", d["flops"]) / (d["ms"] * 1e-3) / 1e12
+        roof["direct_equivalent_tflops"] = round(2.25 * useful_tf, 2)  # algorithmic (direct) FLOPs of the layers / time
         # `frac` counts what the MFMAs execute, tile padding included (7 x 7 planes: 16 tiles cover 8 x 8);
         # frac_unpadded counts only the multiplies of tiles' cells that exist
         roof["frac_unpadded"] = round(d.get("useful_flops", d["flops"]) / (d["ms"] * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4)

@@ -5,7 +5,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/bpmc; rm -rf $O; mkdir -p $O
 WL=${1:-resnet18}
-ROUND=${ROUND:-r04}
+ROUND=${ROUND:-r05}
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/$C -- python3 $R/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline --no-side-workloads > $O/$C.log 2>&1
   tail -1 $O/$C.log | cut -c1-160
@@ -19,29 +19,42 @@ import bench
 # batch-norm-backward, pooling-backward or depthwise-backward kernel). The same LDS-DMA GEMM and the same fused Winograd
 # kernel serve forward and the data gradient: the phase, not the name, decides which class a launch belongs to.
 BWD_MARK = ("conv_dw", "wino_dw", "BnBwd", "bn_bwd", "BwdSums", "_bwd_kernel", "maxpool_bwd", "avgpool_bwd", "dwm_bwd", "dwl_bwd", "dw3_bwd", "eltwise_bwd", "cost_bwd", "softmax_bwd", "ActBwd")
-acc = collections.defaultdict(lambda: collections.defaultdict(float))
-cnt = collections.defaultdict(lambda: collections.defaultdict(int))
-steps_seen = 0
+# Per pass (= per counter: FETCH_SIZE and WRITE_SIZE come from separate runs, whose number of steps may differ now that
+# bench.py stretches its warm-up by wall time) the sums are divided by THAT pass's number of steps. A step is counted where
+# the backward phase begins (every step has exactly one such place, also the workloads without an SGD launch: configs[1]);
+# the phase goes back to "fwd" after the optimizer launch or, without one, at the next forward-only kernel.
+FWD_MARK = ("conv_fwd_window", "conv_fwd_direct", "conv_fwd_stem")
+per_step = collections.defaultdict(lambda: collections.defaultdict(float))   # (kernel, phase) -> counter -> value per step
+lps = collections.defaultdict(float)                                          # (kernel, phase) -> launches per step
+steps_by_counter = {}
 for f in glob.glob("$O/*/**/*counter_collection.csv", recursive=True):
     rows_f = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Dispatch_Id"]))
     phase, nsteps = "fwd", 0
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    cnt = collections.defaultdict(lambda: collections.defaultdict(int))
     for r in rows_f:
         k = r["Kernel_Name"]
-        if phase == "fwd" and any(t in k for t in BWD_MARK): phase = "bwd"
+        if phase == "bwd" and any(t in k for t in FWD_MARK): phase = "fwd"
+        if phase == "fwd" and any(t in k for t in BWD_MARK): phase, nsteps = "bwd", nsteps + 1
         key = (k, phase)
         acc[key][r["Counter_Name"]] += float(r["Counter_Value"])
         cnt[key][r["Counter_Name"]] += 1
-        if "sgd_chunks" in k or "adam_chunks" in k: phase, nsteps = "fwd", nsteps + 1
-    steps_seen = max(steps_seen, nsteps)
-STEPS = steps_seen or 4
+        if "sgd_chunks" in k or "adam_chunks" in k: phase = "fwd"
+    nsteps = max(nsteps, 1)
+    for key in acc:
+        for c, v in acc[key].items():
+            per_step[key][c] += v / nsteps
+            steps_by_counter[c] = nsteps
+            lps[key] = max(lps[key], cnt[key][c] / nsteps)
+STEPS = steps_by_counter
 KIB = 1024.0  # FETCH_SIZE / WRITE_SIZE are reported in KiB
 rows = {}
-for key in acc:
-    n = max(cnt[key].values())
-    f_raw = acc[key].get("FETCH_SIZE", 0.0) * KIB
-    w = acc[key].get("WRITE_SIZE", 0.0) * KIB
-    rows[key] = {"launches_per_step": n / STEPS, "fetch_bytes_raw_per_launch": f_raw / n, "write_bytes_per_launch": w / n,
-                 "hbm_bytes_per_launch": (2 * f_raw + w) / n, "hbm_bytes_per_step": (2 * f_raw + w) / STEPS}
+for key in per_step:
+    n = lps[key]
+    f_raw = per_step[key].get("FETCH_SIZE", 0.0) * KIB
+    w = per_step[key].get("WRITE_SIZE", 0.0) * KIB
+    rows[key] = {"launches_per_step": n, "fetch_bytes_raw_per_launch": f_raw / n, "write_bytes_per_launch": w / n,
+                 "hbm_bytes_per_launch": (2 * f_raw + w) / n, "hbm_bytes_per_step": 2 * f_raw + w}
 def cls(pred, phase=None):
     ks = [key for key in rows if pred(key[0]) and (phase is None or key[1] == phase)]
     # launches of the class = its main kernels (one per layer call); helpers (packing, transforms, finalize) only add bytes.
