@@ -64,10 +64,17 @@ static void* must_sym(void* lib, const char* name) {
 
 static void load_rccl() {
     if (g_comm.lib) return;
-    const char* names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+    // BCNN_HIP_RCCL_LIB: an explicit file instead of the system's RCCL (a site-specific build; the test double of
+    // tests/fake_rccl inside a process that already holds PyTorch's librccl, where the soname would resolve to that one)
+    const char* forced = getenv("BCNN_HIP_RCCL_LIB");
+    const char* names[] = {forced && forced[0] ? forced : "librccl.so.1", "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
     for (const char* n : names) {
         g_comm.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
         if (g_comm.lib) break;
+        if (forced && forced[0] && n == names[0]) {
+            fprintf(stderr, "[bcnn_hip] cannot load BCNN_HIP_RCCL_LIB=%s: %s\n", forced, dlerror());
+            exit(1);
+        }
     }
     if (!g_comm.lib) {
         fprintf(stderr, "[bcnn_hip] cannot load RCCL (librccl.so.1): %s\n", dlerror());

@@ -246,10 +246,17 @@ def roofline_of(prof, workload, traffic_ok):
     return roof
 
 
+def comm_id_path():
+    """where rank 0 publishes the RCCL unique id for --comm inlib: one file per launch, the same on every rank"""
+    tag = os.environ.get("TORCHELASTIC_RUN_ID", "none") + "_" + os.environ.get("MASTER_PORT", "0")
+    os.environ.setdefault("BCNN_HIP_JOB_NONCE", tag)   # records of another launch at a reused path are ignored (csrc/comm.hip)
+    return os.environ.get("BENCH_COMM_ID_PATH") or os.path.join(os.environ.get("TMPDIR", "/tmp"), "bcnn_bench_comm_%s.id" % tag)
+
+
 class Workload:
     """one synthetic workload resident in HBM: .step() runs one pass of the hot path over one batch"""
 
-    def __init__(self, name, n, rank, world, dev, L, stream, input_grad=False, overlap=True):
+    def __init__(self, name, n, rank, world, dev, L, stream, input_grad=False, overlap=True, comm="torch"):
         import torch
         import torch.distributed as dist
         from bcnn_amd import capi, ops
@@ -263,7 +270,14 @@ class Workload:
             (build_resnet18 if name == "resnet18" else build_mobilenet_v1)(net, capi)
             net.compile()
             net.set_sgd(0.01, 0.9, 5e-4)
-            net.set_data_parallel(rank, world)
+            inlib = dp and comm == "inlib"
+            if inlib:
+                # the product's own collective (csrc/comm.hip): parameters broadcast from rank 0, ~8 MB tail buckets of the
+                # gradient arena all-reduced from inside bcnn_backward on the communicator's stream, bcnn_update ordered
+                # behind the last bucket -- nothing of torch.distributed touches a gradient in this mode
+                net.set_data_parallel_comm(rank, world, comm_id_path())
+            else:
+                net.set_data_parallel(rank, world)
             x = torch.rand((n, 3, 224, 224), device=dev, generator=gen) * 2 - 1
             lab = torch.zeros((n, 1000), device=dev)
             lab[torch.arange(n, device=dev), torch.randint(0, 1000, (n,), device=dev, generator=gen)] = 1.0
@@ -273,13 +287,13 @@ class Workload:
             L.bcnn_hip_sync()
             del x, lab
             gptr, gsize = net.gradient_arena()
-            grads = torch.as_tensor(capi.DeviceArray(gptr, gsize), device=dev) if dp else None
-            if dp:   # every rank continues from rank 0's parameters, whatever its own initialisation drew
+            grads = torch.as_tensor(capi.DeviceArray(gptr, gsize), device=dev) if dp and not inlib else None
+            if dp and not inlib:   # every rank continues from rank 0's parameters, whatever its own initialisation drew
                 pptr, psize = net.parameter_arena()
                 dist.broadcast(torch.as_tensor(capi.DeviceArray(pptr, psize), device=dev), 0)
                 torch.cuda.synchronize()
             bar = None
-            if dp and overlap:
+            if dp and overlap and not inlib:
                 # Gradient all-reduce overlapped with backward: the C executor reports growing tail ranges of the
                 # gradient arena as their nodes finish (bcnn_set_gradient_ready_callback); ranges are gathered into
                 # ~8 MB buckets and each bucket is all-reduced asynchronously on RCCL's stream, ordered after the
@@ -305,8 +319,8 @@ class Workload:
                               file=sys.stderr, flush=True)
                         os._exit(3)
                 else:
-                    net.backward()
-                    if dp:
+                    net.backward()                  # --comm inlib: the all-reduce happens in here
+                    if dp and not inlib:
                         L.bcnn_hip_sync()           # gradients complete on our stream before RCCL reads them
                         dist.all_reduce(grads)      # ONE all-reduce of the flat weight/bias-gradient arena (xGMI)
                         torch.cuda.synchronize()
@@ -341,10 +355,17 @@ class Workload:
             torch.cuda.synchronize()
             self._keep = (x, params, grads, y, dy, ws, dxg)
 
+            inlib = world > 1 and comm == "inlib"
+            if inlib:
+                L.bcnn_hip_comm_init(rank, world, comm_id_path().encode())
+
             def step():
                 ops.conv_forward(x, wt, bias, y, k, s, p, 1, 0)
                 ops.conv_backward(x, wt, y, dy, dxg, dw, db, k, s, p, 1, 0, ws)
-                if world > 1:
+                if inlib:
+                    L.bcnn_hip_allreduce_sum(grads.data_ptr(), grads.numel())   # queued behind the stream's work so far
+                    L.bcnn_hip_comm_join()                                      # the stream waits for it, the host does not
+                elif world > 1:
                     L.bcnn_hip_sync()
                     dist.all_reduce(grads)
                     torch.cuda.synchronize()
@@ -483,6 +504,10 @@ def main():
                          "timings reported under `workloads`")
     ap.add_argument("--input-grad", action="store_true",
                     help="conv3x3 only: give the source a gradient so that backward also runs dX (SURVEY.md 8d, config #2 variant)")
+    ap.add_argument("--comm", default="torch", choices=["torch", "inlib"],
+                    help="data-parallel runs: who runs the gradient all-reduce -- torch.distributed (RCCL through PyTorch, the "
+                         "default) or the library's own communicator (csrc/comm.hip behind bcnn_set_data_parallel_comm: what "
+                         "a plain C consumer of libbcnn.so uses, INTEGRATION.md C1)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="data-parallel runs: one blocking all-reduce after backward instead of overlapped buckets")
     args = ap.parse_args()
@@ -525,7 +550,8 @@ def main():
     if world > 1 or os.environ.get("BENCH_FORCE_DP") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        if same_device:
+        if same_device or args.comm == "inlib":
+            # gloo: with --comm inlib torch.distributed only carries the barriers and the max over the ranks' clocks
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:  # "nccl" IS RCCL on ROCm; device_id binds the communicator to this rank's GPU up front
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -537,10 +563,10 @@ def main():
     L.bcnn_hip_set_stream(stream)
 
     overlap = not args.no_overlap and os.environ.get("BENCH_NO_OVERLAP") != "1"
-    wl = Workload(args.workload, n, rank, world, dev, L, stream, input_grad=args.input_grad, overlap=overlap)
+    wl = Workload(args.workload, n, rank, world, dev, L, stream, input_grad=args.input_grad, overlap=overlap, comm=args.comm)
     dt, prof, profiled_steps = wl.run(args.steps, args.warmup)
     if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([dt], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -552,7 +578,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_extra": wl.warmup_extra,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": wl.desc, "batch_per_gpu": n, "global_batch": n * world, "parallelism": "dp%d" % world},
+            "config": {"workload": wl.desc, "batch_per_gpu": n, "global_batch": n * world, "parallelism": "dp%d" % world,
+                       "comm": ("none (one rank)" if world == 1 and os.environ.get("BENCH_FORCE_DP") != "1" else
+                                "in-library RCCL (csrc/comm.hip, bcnn_set_data_parallel_comm)" if args.comm == "inlib" else
+                                "torch.distributed (%s)" % dist.get_backend())},
             "roofline": roofline_of(prof, args.workload, default_shape),
             "profiled_steps": profiled_steps,
             "kernel_classes": class_table(prof, profiled_steps),

@@ -156,6 +156,45 @@ def test_bench_two_ranks_overlapped_allreduce_equals_blocking_allreduce():
     assert a["param_checksum"] == b["param_checksum"], (a["param_checksum"], b["param_checksum"])
 
 
+def test_bench_comm_inlib_two_ranks_equal_the_torch_distributed_run(tmp_path):
+    """`bench.py --comm inlib`: the product's own collective (csrc/comm.hip behind bcnn_set_data_parallel_comm -- parameter
+    broadcast, bucketed all-reduce from inside bcnn_backward, update ordered behind the last bucket) under the bench, two
+    ranks on this one GPU over the test double of librccl (tests/fake_rccl: buffers staged through the host, exchanged as
+    files, summed in rank order). The parameters after three steps have to be the ones the torch.distributed run leaves
+    (gloo here): the same sums of the same two shards, a + b == b + a."""
+    import os
+    import socket
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fake = tmp_path / "fake"
+    fake.mkdir()
+    r = subprocess.run(["gcc", "-shared", "-fPIC", "-O1", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                        os.path.join(root, "tests", "fake_rccl", "fake_rccl.c"), "-o", str(fake / "libfake_rccl.so"),
+                        "-L/opt/rocm/lib", "-lamdhip64"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ports = []
+    for _ in range(2):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            ports.append(s.getsockname()[1])
+    a = _run_bench_two_ranks(["--no-overlap"], ports[0], self_launch=False)
+    old = {k: os.environ.get(k) for k in ("BCNN_HIP_RCCL_LIB", "FAKE_RCCL_DIR", "BENCH_COMM_ID_PATH")}
+    os.environ.update(BCNN_HIP_RCCL_LIB=str(fake / "libfake_rccl.so"), FAKE_RCCL_DIR=str(tmp_path),
+                      BENCH_COMM_ID_PATH=str(tmp_path / "bench.id"))
+    try:
+        b = _run_bench_two_ranks(["--comm", "inlib"], ports[1], self_launch=True)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    for d in (a, b):
+        assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp2"
+    assert "in-library" in b["config"]["comm"] and "torch.distributed" in a["config"]["comm"]
+    assert a["param_checksum"] == b["param_checksum"], (a["param_checksum"], b["param_checksum"])
+
+
 def test_bench_rccl_path_on_one_gpu_prints_one_line_and_leaves_the_same_parameters():
     """BENCH_FORCE_DP=1 runs bench.py's data-parallel step with a real RCCL communicator of world size 1: the
     gradient-ready callback, the bucketed asynchronous all-reduce on RCCL's stream ordered against the library's
