@@ -57,6 +57,9 @@ bool conv_backward_data_winograd(const float* w, const float* dy, float* dx, con
 bool conv_forward_winograd_fused(const float* x, const float* w, const float* bias, const float* slopes, float* y,
                                  const ConvShape& s, int act, int raw, ConvStats* stats);
 bool conv_backward_data_winograd_fused(const float* w, const float* dy, float* dx, const ConvShape& s);
+// conv_winograd43.hip: F(4x4, 3x3) for planes of whole 4 x 4 tiles, raw output only
+bool conv_forward_winograd43(const float* x, const float* w, float* y, const ConvShape& s, int raw, ConvStats* stats);
+bool conv_backward_data_winograd43(const float* w, const float* dy, float* dx, const ConvShape& s);
 // few input channels (the RGB stem): padded-plane GEMM over all (c, kr, kc) rows (conv_dw_dma.hip)
 size_t conv_dw_small_c_workspace_floats(const ConvShape& s);
 bool conv_backward_weights_small_c(const float* x, const float* dy, float* dw, const ConvShape& s, float* workspace,
@@ -102,6 +105,7 @@ static void conv_fwd_any(const float* x, const float* w, const float* bias, cons
     if (window_on && conv_forward_window(x, w, bias, slopes, y, s, act, raw)) return;
     if (window_on && conv_forward_stem(x, w, bias, slopes, y, s, act, raw, stats)) return;
     if (conv_forward_direct(x, w, bias, slopes, y, s, act, raw)) return;
+    if (raw && conv_forward_winograd43(x, w, y, s, raw, stats)) return;
     if (conv_forward_winograd_fused(x, w, bias, slopes, y, s, act, raw, stats)) return;
     if (conv_forward_winograd(x, w, bias, slopes, y, s, act, raw, stats)) return;
     conv_forward_dispatch(x, w, bias, slopes, y, s, act, raw, stats);
@@ -435,7 +439,8 @@ static void conv_backward_impl(const float* x, const float* w, const float* bias
     }
     if (!batch_norm && !bias_done) bcnn_hip_grad_bias(dbias, dy, n, f, s.OHOW);  // uses the shared reduce scratch
     if (bs) bs->splits = 0;
-    if (dx && !conv_backward_data_winograd_fused(w, dy, dx, s) && !conv_backward_data_winograd(w, dy, dx, s))
+    if (dx && !conv_backward_data_winograd43(w, dy, dx, s) && !conv_backward_data_winograd_fused(w, dy, dx, s) &&
+        !conv_backward_data_winograd(w, dy, dx, s))
         conv_backward_data(w, dy, dx, s, bs);
     if (side) HIP_CHECK(hipStreamWaitEvent(main_stream, side->done, 0));
 }

@@ -2,7 +2,8 @@
 round of the persistent workgroups would hold are cut along the input channels and dealt out over all CUs; a fix-up kernel
 adds the pieces in channel order, stores them and takes the batch-norm statistics). Shapes whose block counts leave such a
 tail (288 and 576 blocks on 256 CUs; a ragged channel count; a partial last tile block): raw forward with batch-norm
-statistics and dX against torch's float64 convolution at 1e-5 (the parity bar is 1e-4), and bit-identical repeats."""
+statistics and dX against torch's float64 convolution at 1e-5 (the parity bar is 1e-4; 3e-5 where the F(4x4, 3x3) kernel of
+conv_winograd43.hip takes the shape: whole 4 x 4 tiles and >= 512 units), and bit-identical repeats."""
 import numpy as np
 import pytest
 import torch
@@ -36,10 +37,11 @@ def test_tail_pieces_add_up(shape):
     bn = forward()
     raw = F.conv2d(x.double(), wt.double(), None, padding=1)
     rel = lambda a, r: float((a.double() - r).abs().max() / max(float(r.abs().max()), 1e-30))
-    assert rel(bn["workspace"], raw) <= 1e-5
+    tol = 3e-5 if (h % 4 == 0 and w % 4 == 0) else 1e-5   # F(4x4, 3x3) in fp32: ~1e-5 (tools/exp/wino43_error.py)
+    assert rel(bn["workspace"], raw) <= tol
     mean = raw.mean(dim=(0, 2, 3))
     var = (raw * raw).mean(dim=(0, 2, 3)) - mean * mean
-    assert rel(bn["saved_mean"], mean) <= 1e-5 and rel(bn["saved_var"], var) <= 1e-4
+    assert rel(bn["saved_mean"], mean) <= tol and rel(bn["saved_var"], var) <= 1e-4
     bn2 = forward()
     assert torch.equal(bn["workspace"], bn2["workspace"]) and torch.equal(bn["saved_mean"], bn2["saved_mean"])
     assert torch.equal(bn["saved_var"], bn2["saved_var"])
@@ -52,7 +54,7 @@ def test_tail_pieces_add_up(shape):
     ops.conv_backward(x, wt, y, dy.clone(), dx, dw, db, 3, 1, 1, 1, 0, ws)
     torch.cuda.synchronize()
     dxr = F.conv_transpose2d(dy.double(), wt.double(), None, padding=1)
-    assert rel(dx, dxr) <= 1e-5
+    assert rel(dx, dxr) <= tol
     dx2 = torch.full_like(x, float("nan"))
     ops.conv_backward(x, wt, y, dy.clone(), dx2, torch.zeros_like(wt), torch.zeros(f, device=DEV), 3, 1, 1, 1, 0, ws)
     torch.cuda.synchronize()
