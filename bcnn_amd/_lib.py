@@ -68,6 +68,8 @@ SIGNATURES = {
     "bcnn_hip_depthwise_stats_size": (sz, [i] * 7),
     "bcnn_hip_depthwise_forward_stats": (i, [vp, vp, vp, vp] + [i] * 8 + [vp, sz]),
     "bcnn_hip_batchnorm_forward_stats": (None, [vp] * 10 + [i, i, i, i, i, vp, i]),
+    "bcnn_hip_batchnorm_forward_stats_only": (None, [vp] * 7 + [i, i, i, vp, i]),
+    "bcnn_hip_conv_bnfold_fusable": (i, [i] * 5), "bcnn_hip_conv_set_input_bnfold": (None, [vp] * 4),
     "bcnn_hip_depthwise_bn_fusable": (i, [i] * 8),
     "bcnn_hip_batchnorm_backward_sums": (None, [vp] * 9 + [i, i, i]),
     "bcnn_hip_depthwise_backward_bn": (None, [vp] * 7 + [i] * 9 + [vp] * 5),

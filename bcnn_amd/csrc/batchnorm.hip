@@ -83,7 +83,7 @@ __global__ void bn_stats_finalize_kernel(const float* __restrict__ partials, int
                                          float* __restrict__ saved_mean, float* __restrict__ saved_var,
                                          float* __restrict__ run_mean, float* __restrict__ run_var,
                                          float4* __restrict__ consts, const float* __restrict__ scale,
-                                         const float* __restrict__ bias) {
+                                         const float* __restrict__ bias, const float* __restrict__ mean_shift) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double s = 0.0, ss = 0.0;
@@ -96,7 +96,10 @@ __global__ void bn_stats_finalize_kernel(const float* __restrict__ partials, int
     const float var = __fsub_rn(__fmul_rn((float)ss, inv), __fmul_rn(mean, mean));      // bcnn_varmean
     saved_mean[c] = mean;
     saved_var[c] = var;
-    run_mean[c] = __fadd_rn(__fmul_rn(mean, 0.1f), __fmul_rn(run_mean[c], 0.9f));        // scal 0.9, axpy 0.1
+    // mean_shift (BnFold, conv_common.h): a per-channel constant the producer left out of x; the RUNNING mean is the one
+    // place where it shows (saved_mean stays in the frame of the stored x, which is what apply and backward pair it with)
+    const float vis = mean_shift ? __fadd_rn(mean, mean_shift[c]) : mean;
+    run_mean[c] = __fadd_rn(__fmul_rn(vis, 0.1f), __fmul_rn(run_mean[c], 0.9f));        // scal 0.9, axpy 0.1
     run_var[c] = __fadd_rn(__fmul_rn(var, 0.1f), __fmul_rn(run_var[c], 0.9f));
     bn_fwd_consts_store(consts, c, mean, var, scale, bias);
 }
@@ -108,7 +111,8 @@ constexpr int kFinalizeThreads = 1024;
 __global__ __launch_bounds__(kFinalizeThreads) void bn_stats_finalize_wide_kernel(
     const float* __restrict__ partials, int C, int splits, int M, float* __restrict__ saved_mean,
     float* __restrict__ saved_var, float* __restrict__ run_mean, float* __restrict__ run_var,
-    float4* __restrict__ consts, const float* __restrict__ scale, const float* __restrict__ bias) {
+    float4* __restrict__ consts, const float* __restrict__ scale, const float* __restrict__ bias,
+    const float* __restrict__ mean_shift) {
     constexpr int NW = kFinalizeThreads / 64;
     __shared__ double red[NW][2];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -141,7 +145,8 @@ __global__ __launch_bounds__(kFinalizeThreads) void bn_stats_finalize_wide_kerne
     const float var = __fsub_rn(__fmul_rn((float)ss, inv), __fmul_rn(mean, mean));
     saved_mean[c] = mean;
     saved_var[c] = var;
-    run_mean[c] = __fadd_rn(__fmul_rn(mean, 0.1f), __fmul_rn(run_mean[c], 0.9f));
+    const float vis = mean_shift ? __fadd_rn(mean, mean_shift[c]) : mean;  // see bn_stats_finalize_kernel
+    run_mean[c] = __fadd_rn(__fmul_rn(vis, 0.1f), __fmul_rn(run_mean[c], 0.9f));
     run_var[c] = __fadd_rn(__fmul_rn(var, 0.1f), __fmul_rn(run_var[c], 0.9f));
     bn_fwd_consts_store(consts, c, mean, var, scale, bias);
 }
@@ -428,7 +433,7 @@ struct BnBwdApplyBody {
 void batchnorm_forward_impl(const float* x, float* y, float* run_mean, float* run_var, const float* scales,
                             const float* bias, float* saved_mean, float* saved_var, float* x_norm, float* workspace,
                             int n, int c, int hw, int mode, int act, const ConvStats* pre, const BnResidual* res,
-                            bool stats_only) {
+                            bool stats_only, const float* mean_shift) {
     const long long M = (long long)n * hw, total = M * c;
     if (!total) return;
     const bool have_pre = pre && pre->splits > 0 && mode == BCNN_HIP_MODE_TRAIN;
@@ -454,7 +459,7 @@ void batchnorm_forward_impl(const float* x, float* y, float* run_mean, float* ru
     if (mode == BCNN_HIP_MODE_VALID) a.xn = nullptr;    // x_norm is only written in TRAIN mode (:230)
     if (have_pre) {
         bn_stats_finalize_wide_kernel<<<c, kFinalizeThreads, 0, current_stream()>>>(
-            pre->partials, c, pre->splits, (int)M, saved_mean, saved_var, run_mean, run_var, consts, scales, bias);
+            pre->partials, c, pre->splits, (int)M, saved_mean, saved_var, run_mean, run_var, consts, scales, bias, mean_shift);
         KERNEL_CHECK();
         a.mean = saved_mean; a.var = saved_var; a.consts = consts;
     } else if (mode == BCNN_HIP_MODE_TRAIN) {
@@ -462,7 +467,7 @@ void batchnorm_forward_impl(const float* x, float* y, float* run_mean, float* ru
         float* part = reduce_scratch((size_t)c * splits * 2);
         launch_chan_reduce<2>(StatsF{x}, c, hw, M, splits, part);
         bn_stats_finalize_kernel<<<ceil_div(c, 256), 256, 0, current_stream()>>>(
-            part, c, splits, (int)M, saved_mean, saved_var, run_mean, run_var, consts, scales, bias);
+            part, c, splits, (int)M, saved_mean, saved_var, run_mean, run_var, consts, scales, bias, mean_shift);
         KERNEL_CHECK();
         a.mean = saved_mean; a.var = saved_var; a.consts = consts;
     }
@@ -483,7 +488,7 @@ void bcnn_hip_batchnorm_forward(const float* x, float* y, float* run_mean, float
                                 float* saved_var, float* x_norm, float* workspace, int n, int c, int hw,
                                 int mode, int act) {
     batchnorm_forward_impl(x, y, run_mean, run_var, scales, bias, saved_mean, saved_var, x_norm, workspace, n, c, hw,
-                           mode, act, nullptr, nullptr, false);
+                           mode, act, nullptr, nullptr, false, nullptr);
 }
 
 void bcnn_hip_batchnorm_forward_stats(const float* x, float* y, float* run_mean, float* run_var, const float* scales,
@@ -493,7 +498,18 @@ void bcnn_hip_batchnorm_forward_stats(const float* x, float* y, float* run_mean,
     ConvStats st;
     st.partials = const_cast<float*>(stats); st.splits = stats ? splits : 0; st.capacity = 0;
     batchnorm_forward_impl(x, y, run_mean, run_var, scales, bias, saved_mean, saved_var, x_norm, workspace, n, c, hw,
-                           mode, act, &st, nullptr, false);
+                           mode, act, &st, nullptr, false, nullptr);
+}
+
+// TRAIN-mode batch statistics (saved and running) WITHOUT the apply sweep: the 1x1 convolution behind the node takes the
+// node's input and folds the affine map into its weights (bcnn_hip_conv_set_input_bnfold); `stats` as above
+void bcnn_hip_batchnorm_forward_stats_only(const float* x, float* run_mean, float* run_var, const float* scales,
+                                           const float* bias, float* saved_mean, float* saved_var, int n, int c, int hw,
+                                           const float* stats, int splits) {
+    ConvStats st;
+    st.partials = const_cast<float*>(stats); st.splits = stats ? splits : 0; st.capacity = 0;
+    batchnorm_forward_impl(x, nullptr, run_mean, run_var, scales, bias, saved_mean, saved_var, nullptr, nullptr, n, c, hw,
+                           BCNN_HIP_MODE_TRAIN, BCNN_HIP_ACT_NONE, &st, nullptr, true, nullptr);
 }
 
 }  // extern "C"

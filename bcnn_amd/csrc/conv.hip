@@ -11,7 +11,7 @@ void conv_forward_dispatch(const float* x, const float* w, const float* bias, co
 void batchnorm_forward_impl(const float* x, float* y, float* run_mean, float* run_var, const float* scales,
                             const float* bias, float* saved_mean, float* saved_var, float* x_norm, float* workspace,
                             int n, int c, int hw, int mode, int act, const ConvStats* pre,
-                            const BnResidual* res, bool stats_only);  // batchnorm.hip
+                            const BnResidual* res, bool stats_only, const float* mean_shift = nullptr);  // batchnorm.hip
 void batchnorm_backward_residual(const float* dout, const float* out, int act_res, const float* res, float* dres,
                                  size_t res_count, float* dx, const float* scales, float* dscales, float* dbias,
                                  const float* fwd_bias, const float* saved_mean, const float* saved_var, float* dmean,
@@ -31,7 +31,10 @@ void conv_backward_data(const float* w, const float* dy, float* dx, const ConvSh
 // conv_dw_dma.hip: per-tap GEMM with LDS-DMA staging (the general fast path)
 size_t conv_dw_dma_workspace_floats(const ConvShape& s);
 bool conv_backward_weights_dma(const float* x, const float* dy, float* dw, const ConvShape& s, float* workspace,
-                               size_t workspace_floats);
+                               size_t workspace_floats, const BnFold* fold = nullptr);
+bool conv_forward_dma(const float* x, const float* w, const float* bias, const float* slopes, float* y,
+                      const ConvShape& s, int act, int raw, ConvStats* stats, const BnFold* fold = nullptr);  // conv_igemm_dma.hip
+bool conv_forward_dma_supported(const ConvShape& s);
 // conv_direct.hip: LDS-free kernels for small reduction lengths (K <= 32)
 bool conv_forward_direct(const float* x, const float* w, const float* bias, const float* slopes, float* y,
                          const ConvShape& s, int act, int raw);
@@ -72,12 +75,60 @@ bool conv_backward_weights_winograd(const float* x, const float* dy, float* dw, 
                                     size_t workspace_floats);
 
 static bool conv_backward_weights_dma_timed(const float* x, const float* dy, float* dw, const ConvShape& s,
-                                            float* workspace, size_t workspace_floats) {
+                                            float* workspace, size_t workspace_floats, const BnFold* fold = nullptr) {
     if (conv_dw_dma_workspace_floats(s) == 0) return false;
     KTimer kt(K_CONV_DW, 2.0 * (double)s.total_q * s.Mg * s.K * s.groups,
               4.0 * ((double)s.N * s.C * s.HW + (double)s.F * s.K + (double)s.N * s.F * s.OHOW));
-    return conv_backward_weights_dma(x, dy, dw, s, workspace, workspace_floats);
+    return conv_backward_weights_dma(x, dy, dw, s, workspace, workspace_floats, fold);
 }
+
+// ---- a stand-alone batch-norm node in front of a 1x1 convolution, folded into it (BnFold, conv_common.h) -------------
+// The host announces the fold right before the forward / backward call it applies to (same thread): the call takes it.
+static thread_local BnFold g_fold_pending = {nullptr, nullptr, nullptr, nullptr};
+static BnFold take_fold() {
+    const BnFold f = g_fold_pending;
+    g_fold_pending = BnFold{nullptr, nullptr, nullptr, nullptr};
+    return f;
+}
+static bool bnfold_shape_ok(const ConvShape& s) {
+    return s.ksz == 1 && s.stride == 1 && s.pad == 0 && s.groups == 1 && conv_forward_dma_supported(s) &&
+           conv_dw_dma_workspace_floats(s) > 0;
+}
+// rowc[f] = sum_c W[f][c] b[c], b[c] = bias - mean a[c] (a = scale / sqrt(var + 1e-6); the reference's bcnn_add_scalar adds
+// nothing for a bias of exactly 0 or 1, bcnn_mat.c:366-412): what the folded-away constant adds to every output of filter f.
+// One wave per filter.
+__global__ __launch_bounds__(256) void bnfold_rowconst_kernel(const float* __restrict__ w, const BnFold fold, int F, int C,
+                                                              float* __restrict__ rowc) {
+    const int f = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (f >= F) return;
+    double acc = 0.0;
+    for (int c = lane; c < C; c += 64) {
+        float bv = fold.bias[c];
+        if (bv == 1.0f) bv = 0.f;
+        const float b = bv - fold.mean[c] * bnfold_a(fold.var, fold.scales, c);
+        acc += (double)w[(size_t)f * C + c] * (double)b;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) rowc[f] = (float)acc;
+}
+struct FoldScratch { float* p = nullptr; size_t cap = 0; };
+static thread_local FoldScratch g_fold_scratch[64];
+static float* fold_rowconst(const BnFold& fold, const float* w, int C, int F) {
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) { fprintf(stderr, "[bcnn_hip] device ordinal %d out of range\n", dev); exit(1); }
+    FoldScratch& sc = g_fold_scratch[dev];
+    if (!sc.p || sc.cap < (size_t)F) {
+        if (sc.p) { HIP_CHECK(hipStreamSynchronize(current_stream())); HIP_CHECK(hipFree(sc.p)); }
+        sc.cap = F < 8192 ? 8192 : (size_t)F * 2;
+        HIP_CHECK(hipMalloc((void**)&sc.p, sc.cap * sizeof(float)));
+    }
+    bnfold_rowconst_kernel<<<ceil_div(F, 4), 256, 0, current_stream()>>>(w, fold, F, C, sc.p);
+    KERNEL_CHECK();
+    return sc.p;
+}
+
 
 // per-thread side stream for the weight-gradient GEMM of bcnn_hip_conv_backward
 struct SideStream {
@@ -284,6 +335,12 @@ static void conv_forward_impl(const float* x, const float* w, const float* bias,
                               float* saved_mean, float* saved_var, float* x_norm, float* bn_workspace, int mode,
                               const BnResidual* res, float* res_out, bool stats_only = false) {
     const ConvShape s = make_conv_shape(n, c, h, wd, f, k, stride, pad, groups);
+    const BnFold fold = take_fold();  // announced by bcnn_hip_conv_set_input_bnfold: x then is the batch-norm's INPUT
+    if (fold.mean && (!batch_norm || mode != BCNN_HIP_MODE_TRAIN || !bnfold_shape_ok(s))) {
+        fprintf(stderr, "[bcnn_hip] conv forward: a batch-norm fold was announced for a layer that cannot take it (ask "
+                        "bcnn_hip_conv_bnfold_fusable)\n");
+        exit(1);
+    }
     if (!batch_norm) {
         if (act_is_cheap(act)) {
             conv_fwd_any(x, w, bias, slopes, y, s, act, /*raw=*/0);
@@ -307,16 +364,41 @@ static void conv_forward_impl(const float* x, const float* w, const float* bias,
         st.capacity = (size_t)f * (size_t)(slots_gemm > slots_wino ? slots_gemm : slots_wino) * 2;
         st.partials = reduce_scratch(st.capacity);
     }
-    conv_fwd_any(x, w, nullptr, nullptr, raw, s, BCNN_HIP_ACT_NONE, /*raw=*/1, st.partials ? &st : nullptr);
+    const float* mean_shift = nullptr;
+    if (fold.mean) {
+        // W z = (W diag(a)) y + W b: the GEMM reads y with column-scaled weights (packed here: a depends on this batch). The
+        // constant W b is left out of the stored pre-normalisation values -- the batch-norm behind subtracts the batch mean,
+        // so every later use (apply, backward, the consumers that normalise on the fly) sees raw - mean either way -- and
+        // is added where it is visible: the running mean.
+        mean_shift = fold_rowconst(fold, w, c, f);
+        KTimer kt(K_CONV_FWD, 2.0 * (double)s.total_q * s.Mg * s.K * s.groups,
+                  4.0 * ((double)s.N * s.C * s.HW + (double)s.F * s.K + (double)s.N * s.F * s.OHOW));
+        ConvStats* stp = st.partials ? &st : nullptr;
+        if (!conv_forward_dma(x, w, nullptr, nullptr, raw, s, BCNN_HIP_ACT_NONE, /*raw=*/1, stp, &fold)) {
+            fprintf(stderr, "[bcnn_hip] conv forward: the LDS-DMA GEMM refused a folded layer\n");
+            exit(1);
+        }
+    } else {
+        conv_fwd_any(x, w, nullptr, nullptr, raw, s, BCNN_HIP_ACT_NONE, /*raw=*/1, st.partials ? &st : nullptr);
+    }
     const int fused_act = (act == BCNN_HIP_ACT_PRELU) ? BCNN_HIP_ACT_NONE : act;
     // x_norm is not materialised on this path: the backward pass recomputes it from the raw convolution
     // output kept in bn_workspace (a full-tensor write and read less per layer and step).
     (void)x_norm;
     batchnorm_forward_impl(raw, res ? res_out : y, run_mean, run_var, scales, bias, saved_mean, saved_var, nullptr, raw, n, f,
-                           s.OHOW, mode, fused_act, &st, res, stats_only);
+                           s.OHOW, mode, fused_act, &st, res, stats_only, mean_shift);
     if (stats_only) return;
     if (act == BCNN_HIP_ACT_PRELU)
         bcnn_hip_activation_forward(y, (size_t)n * f * s.OHOW, act, slopes, s.OHOW, f);
+}
+
+int bcnn_hip_conv_bnfold_fusable(int n, int c, int h, int wd, int f) {
+    if (n <= 0 || c <= 0 || h <= 0 || wd <= 0 || f <= 0) return 0;
+    return bnfold_shape_ok(make_conv_shape(n, c, h, wd, f, 1, 1, 0, 1)) ? 1 : 0;
+}
+
+void bcnn_hip_conv_set_input_bnfold(const float* mean, const float* var, const float* scales, const float* bias) {
+    g_fold_pending = BnFold{mean, var, scales, bias};
 }
 
 void bcnn_hip_conv_forward(const float* x, const float* w, const float* bias, float* y, int n, int c, int h,
@@ -372,6 +454,11 @@ static void conv_backward_impl(const float* x, const float* w, const float* bias
                                int own_splits = 0, bool bn_done = false) {
     const ConvShape s = make_conv_shape(n, c, h, wd, f, k, stride, pad, groups);
     const size_t ysize = (size_t)n * f * s.OHOW;
+    const BnFold fold = take_fold();  // x then is the INPUT of the batch-norm in front: d/dW of W diag(a) is (dy x^T) diag(a)
+    if (fold.mean && (!batch_norm || !bnfold_shape_ok(s))) {
+        fprintf(stderr, "[bcnn_hip] conv backward: a batch-norm fold was announced for a layer that cannot take it\n");
+        exit(1);
+    }
     if (rb) {
         // dy <- batch-norm backward of dout * act'(out): the eltwise node's backward and this node's batch-norm backward
         // in the two sweeps the latter takes alone
@@ -412,7 +499,15 @@ static void conv_backward_impl(const float* x, const float* w, const float* bias
     bool bias_done;
     static const int dma_on = BCNN_EXP_ENV("BCNN_HIP_NO_DMA") ? 0 : 1;  // A/B switch for profiling
     static const int window_on = BCNN_EXP_ENV("BCNN_HIP_NO_WINDOW") ? 0 : 1;
-    if (window_on && conv_backward_weights_window(x, dy, dw, batch_norm ? nullptr : dbias, s, workspace, workspace_elems))
+    if (fold.mean) {
+        // (the term b (x) sum_q dy of the exact derivative is left out: dy here is the gradient of a batch-norm's input, whose
+        // sum over the batch is zero up to rounding -- in the reference too, where it multiplies the same b)
+        if (!conv_backward_weights_dma_timed(x, dy, dw, s, workspace, workspace_elems, &fold)) {
+            fprintf(stderr, "[bcnn_hip] conv backward: the LDS-DMA weight-gradient kernel refused a folded layer\n");
+            exit(1);
+        }
+        bias_done = false;
+    } else if (window_on && conv_backward_weights_window(x, dy, dw, batch_norm ? nullptr : dbias, s, workspace, workspace_elems))
         bias_done = true;
     else if (window_on && conv_backward_weights_stem(x, dy, dw, batch_norm ? nullptr : dbias, s, workspace, workspace_elems))
         bias_done = true;

@@ -75,7 +75,27 @@ struct IgemmPackJob {
     int mode, groups;
     int gx, gy, gz;  // block grid of this job: 64 m x 4 j per block, gz = groups * taps
     unsigned char tapoff[kPackMaxTaps];  // kr*ksz + kc of packed tap index
+    // forward form only, optional (BnFold below): row j (input channel c = g * Cg + j) of the pack is multiplied by
+    // fold_scales[c] / sqrtf(fold_var[c] + 1e-6f)
+    const float* fold_var;
+    const float* fold_scales;
 };
+
+// The stand-alone batch-norm node IN FRONT of a 1x1 convolution, folded into that convolution (TRAIN mode, no activation in
+// between: z = a y + b per channel with a = scale / sqrt(var + 1e-6), b = bias - mean a, bcnn_batchnorm_layer.c:226-241):
+// W z = (W diag(a)) y + W b, so the GEMM reads the batch-norm's INPUT y with column-scaled weights and the per-filter
+// constant W b only moves the mean of the convolution's own batch-norm behind it (conv.hip: bcnn_hip_conv_set_input_bnfold).
+struct BnFold {
+    const float* mean;   // saved batch mean [C]; nullptr: no fold
+    const float* var;
+    const float* scales;
+    const float* bias;
+};
+#ifdef __HIPCC__
+__device__ __forceinline__ float bnfold_a(const float* __restrict__ var, const float* __restrict__ scales, int c) {
+    return scales[c] / sqrtf(var[c] + 0.000001f);  // one formula for the pack, the constant and the weight gradient
+}
+#endif
 // the pack of (w, kind, mode) made by the current prepack batch and not yet used, or nullptr (conv.hip)
 float* prepack_take(const float* w, int kind, int mode, size_t floats);
 // what the kernel a layer will run on needs packed; false: nothing (another kernel takes the layer)

@@ -218,7 +218,9 @@ template <int NSUB>
 __global__ __launch_bounds__(64 * NSUB) void conv_dw_dma_finalize_kernel(const float* __restrict__ partials,
                                                                         int qsplits, int groups, int Mg, int Cg,
                                                                         int kk2, int Mpad, int Npad,
-                                                                        float* __restrict__ dw) {
+                                                                        float* __restrict__ dw,
+                                                                        const float* __restrict__ fold_var,
+                                                                        const float* __restrict__ fold_scales) {
     __shared__ float red[NSUB][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const size_t total = (size_t)groups * kk2 * Mg * Cg;
@@ -251,6 +253,7 @@ __global__ __launch_bounds__(64 * NSUB) void conv_dw_dma_finalize_kernel(const f
         float tot = 0.f;
 #pragma unroll
         for (int r = 0; r < NSUB; ++r) tot += red[r][tx];
+        if (fold_var) tot *= bnfold_a(fold_var, fold_scales, (int)((i / ((size_t)Mg * Cg * kk2)) * Cg + (i % Cg)));  // BnFold: d/dW of W diag(a)
         dw[o] += tot;
     }
 }
@@ -262,7 +265,9 @@ __global__ __launch_bounds__(64 * NSUB) void conv_dw_dma_finalize_kernel(const f
 template <int NSUB>
 __global__ __launch_bounds__(64 * NSUB) void conv_dw_dma_finalize_x4_kernel(const float* __restrict__ partials, int qsplits,
                                                                            int groups, int Mg, int Cg, int Mpad, int Npad,
-                                                                           float* __restrict__ dw) {
+                                                                           float* __restrict__ dw,
+                                                                           const float* __restrict__ fold_var,
+                                                                           const float* __restrict__ fold_scales) {
     __shared__ float4 red[NSUB][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const size_t total4 = (size_t)groups * Mg * Cg / 4;
@@ -295,6 +300,12 @@ __global__ __launch_bounds__(64 * NSUB) void conv_dw_dma_finalize_x4_kernel(cons
 #pragma unroll
         for (int r = 0; r < NSUB; ++r) { tot.x += red[r][tx].x; tot.y += red[r][tx].y; tot.z += red[r][tx].z; tot.w += red[r][tx].w; }
         float4* o = reinterpret_cast<float4*>(dw) + i4;  // (((g * Mg + f) * Cg + c) * 1 + 0) / 4 == i4
+        if (fold_var) {  // BnFold: d/dW of W diag(a); c .. c + 3 are four consecutive input channels of group g
+            const size_t i = i4 * 4;
+            const int c = (int)(i % Cg) + (int)(i / ((size_t)Mg * Cg)) * Cg;
+            tot.x *= bnfold_a(fold_var, fold_scales, c); tot.y *= bnfold_a(fold_var, fold_scales, c + 1);
+            tot.z *= bnfold_a(fold_var, fold_scales, c + 2); tot.w *= bnfold_a(fold_var, fold_scales, c + 3);
+        }
         float4 d = *o;
         d.x += tot.x; d.y += tot.y; d.z += tot.z; d.w += tot.w;
         *o = d;
@@ -356,8 +367,9 @@ size_t conv_dw_dma_workspace_floats(const ConvShape& s) { return plan_dw_dma(s).
 static unsigned magic_of_u(int d) { return d > 1 ? (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned)d) : 0u; }
 
 // Returns false when the shape is not covered (caller falls back to conv_bwd.hip's kernel).
+// fold: the layer ran on W diag(a) (BnFold, conv_common.h): the weight gradient's columns take the same factors
 bool conv_backward_weights_dma(const float* x, const float* dy, float* dw, const ConvShape& s, float* workspace,
-                               size_t workspace_floats) {
+                               size_t workspace_floats, const BnFold* fold) {
     const DwDmaPlan p = plan_dw_dma(s);
     if (!p.ok) return false;
     if (workspace == nullptr || workspace_floats < p.partial_floats) {
@@ -390,13 +402,13 @@ bool conv_backward_weights_dma(const float* x, const float* dy, float* dw, const
     if (x4_on && p.kk2 == 1 && p.qsplits > 16 && (s.Cg & 3) == 0 && (p.Npad & 3) == 0 &&
         ((reinterpret_cast<uintptr_t>(dw) | reinterpret_cast<uintptr_t>(workspace)) & 15) == 0)
         conv_dw_dma_finalize_x4_kernel<16><<<(unsigned)((total / 4 + 63) / 64), 1024, 0, current_stream()>>>(
-            workspace, p.qsplits, s.groups, s.Mg, s.Cg, p.Mpad, p.Npad, dw);
+            workspace, p.qsplits, s.groups, s.Mg, s.Cg, p.Mpad, p.Npad, dw, fold ? fold->var : nullptr, fold ? fold->scales : nullptr);
     else if (p.qsplits > 16)
         conv_dw_dma_finalize_kernel<16><<<(unsigned)((total + 63) / 64), 1024, 0, current_stream()>>>(
-            workspace, p.qsplits, s.groups, s.Mg, s.Cg, p.kk2, p.Mpad, p.Npad, dw);
+            workspace, p.qsplits, s.groups, s.Mg, s.Cg, p.kk2, p.Mpad, p.Npad, dw, fold ? fold->var : nullptr, fold ? fold->scales : nullptr);
     else
         conv_dw_dma_finalize_kernel<4><<<(unsigned)((total + 63) / 64), 256, 0, current_stream()>>>(
-            workspace, p.qsplits, s.groups, s.Mg, s.Cg, p.kk2, p.Mpad, p.Npad, dw);
+            workspace, p.qsplits, s.groups, s.Mg, s.Cg, p.kk2, p.Mpad, p.Npad, dw, fold ? fold->var : nullptr, fold ? fold->scales : nullptr);
     KERNEL_CHECK();
     return true;
 }
@@ -459,10 +471,10 @@ bool conv_backward_weights_small_c(const float* x, const float* dy, float* dw, c
     const size_t total = (size_t)s.Mg * s.K;
     if (p.qsplits > 16)
         conv_dw_dma_finalize_kernel<16><<<(unsigned)((total + 63) / 64), 1024, 0, current_stream()>>>(
-            workspace, p.qsplits, 1, s.Mg, s.K, 1, p.Mpad, p.Npad, dw);
+            workspace, p.qsplits, 1, s.Mg, s.K, 1, p.Mpad, p.Npad, dw, nullptr, nullptr);
     else
         conv_dw_dma_finalize_kernel<4><<<(unsigned)((total + 63) / 64), 256, 0, current_stream()>>>(
-            workspace, p.qsplits, 1, s.Mg, s.K, 1, p.Mpad, p.Npad, dw);
+            workspace, p.qsplits, 1, s.Mg, s.K, 1, p.Mpad, p.Npad, dw, nullptr, nullptr);
     KERNEL_CHECK();
     return true;
 }

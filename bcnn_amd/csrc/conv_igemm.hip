@@ -311,7 +311,7 @@ static void dispatch_igemm(IgemmArgs& a, long long max_cols) {
 }
 
 bool conv_forward_dma(const float* x, const float* w, const float* bias, const float* slopes, float* y,
-                      const ConvShape& s, int act, int raw, ConvStats* stats);        // conv_igemm_dma.hip
+                      const ConvShape& s, int act, int raw, ConvStats* stats, const BnFold* fold = nullptr);        // conv_igemm_dma.hip
 bool conv_backward_data_dma(const float* w, const float* dy, float* dx, const ConvShape& s, DxBnSums* bs);
 bool conv_forward_small_c(const float* x, const float* w, const float* bias, const float* slopes, float* y,
                           const ConvShape& s, int act, int raw, ConvStats* stats);   // conv_igemm_dma.hip

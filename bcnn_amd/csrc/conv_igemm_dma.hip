@@ -527,6 +527,7 @@ __device__ __forceinline__ void pack_weights_block(const IgemmPackJob& a, int bx
     if (m < a.M && j < a.J) {
         const int f = a.mode == 0 ? m : j, c = a.mode == 0 ? j : m;
         v = a.w[((size_t)(g * a.Mg + f) * a.Cg + c) * a.kk2 + a.tapoff[t]];
+        if (a.fold_var) v *= bnfold_a(a.fold_var, a.fold_scales, g * a.Cg + c);  // a batch-norm in front of the layer, folded in
     }
     a.at[((size_t)gt * a.Jpad + j) * a.Mpad + m] = v;
 }
@@ -641,12 +642,14 @@ static void fill_pack_job(IgemmPackJob& p, const float* w, float* at, const Conv
     p.M = M; p.J = J; p.Jpad = Jpad; p.Mpad = Mpad; p.mode = mode; p.groups = s.groups;
     for (int t = 0; t < kPackMaxTaps; ++t) p.tapoff[t] = t < kk2 ? tapoff[t] : (unsigned char)0;
     p.gx = Mpad / 64; p.gy = ceil_div(Jpad, 4); p.gz = s.groups * kk2;
+    p.fold_var = nullptr; p.fold_scales = nullptr;
 }
 
 static void pack_weights(const float* w, float* at, const ConvShape& s, int mode, int M, int J, int Jpad, int Mpad,
-                         int kk2, const unsigned char* tapoff) {
+                         int kk2, const unsigned char* tapoff, const BnFold* fold = nullptr) {
     IgemmPackJob p;
     fill_pack_job(p, w, at, s, mode, M, J, Jpad, Mpad, kk2, tapoff);
+    if (fold) { p.fold_var = fold->var; p.fold_scales = fold->scales; }
     dim3 grid((unsigned)p.gx, (unsigned)p.gy, (unsigned)p.gz);
     conv_pack_weights_kernel<<<grid, 256, 0, current_stream()>>>(p);
     KERNEL_CHECK();
@@ -686,8 +689,11 @@ void dma_pack_launch(const IgemmPackJob* jobs_dev, int n, int max_blocks) {
 // Returns false when the shape is not covered (caller falls back to the register-staged kernel).
 // stats (optional, raw mode only): in  -> partials buffer with room for F * ceil(N*OH*OW / 64) * 2 floats
 //                                   out -> splits = number of column tiles written per channel (0: none)
+bool conv_forward_dma_supported(const ConvShape& s) { return dma_supported(s, s.Mg, s.Cg, (size_t)s.N * s.C * s.HW); }
+
+// fold: the batch-norm in front of the layer whose per-channel factors go into the packed weights (BnFold)
 bool conv_forward_dma(const float* x, const float* w, const float* bias, const float* slopes, float* y,
-                      const ConvShape& s, int act, int raw, ConvStats* stats) {
+                      const ConvShape& s, int act, int raw, ConvStats* stats, const BnFold* fold) {
     if (stats) stats->splits = 0;
     if (!dma_supported(s, s.Mg, s.Cg, (size_t)s.N * s.C * s.HW)) return false;
     const int kk2 = s.pointwise ? 1 : s.ksz * s.ksz;
@@ -698,7 +704,7 @@ bool conv_forward_dma(const float* x, const float* w, const float* bias, const f
     a.M = s.Mg; a.J = s.Cg; a.Jpad = round_up(a.J, kDmaBK); a.Mpad = round_up(a.M, 128); a.kk2 = kk2;
     const size_t at_floats = (size_t)s.groups * kk2 * a.Jpad * a.Mpad;
     float* at = prepack_take(w, PREPACK_IGEMM, 0, at_floats);  // packed ahead by bcnn_hip_conv_prepack?
-    const bool packed = at != nullptr;
+    const bool packed = at != nullptr && fold == nullptr;   // a scaled pack depends on this batch's statistics: made here
     if (!packed) at = dma_scratch(at_floats);
     a.at = at; a.at_bytes = (unsigned)(at_floats * 4);
     a.b_bytes = (unsigned)((size_t)s.N * s.C * s.HW * 4);
@@ -709,7 +715,7 @@ bool conv_forward_dma(const float* x, const float* w, const float* bias, const f
     unsigned char tapoff[kDmaMaxTaps];
     ci.nkx = s.pointwise ? 1 : s.ksz; ci.sgn = 1;
     for (int t = 0; t < kk2; ++t) tapoff[t] = (unsigned char)t;
-    if (!packed) pack_weights(w, at, s, 0, a.M, a.J, a.Jpad, a.Mpad, kk2, tapoff);
+    if (!packed) pack_weights(w, at, s, 0, a.M, a.J, a.Jpad, a.Mpad, kk2, tapoff, fold);
     a.stats = (stats && raw) ? stats->partials : nullptr;
     a.bs_out = nullptr; a.bs_y = nullptr; a.bs_mean = nullptr;
     launch_dma(a, (int)s.total_q);

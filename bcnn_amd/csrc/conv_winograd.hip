@@ -24,10 +24,10 @@
 namespace bcnn_hip {
 
 bool conv_forward_dma(const float* x, const float* w, const float* bias, const float* slopes, float* y,
-                      const ConvShape& s, int act, int raw, ConvStats* stats);  // conv_igemm_dma.hip
+                      const ConvShape& s, int act, int raw, ConvStats* stats, const BnFold* fold = nullptr);  // conv_igemm_dma.hip
 size_t conv_dw_dma_workspace_floats(const ConvShape& s);                        // conv_dw_dma.hip
 bool conv_backward_weights_dma(const float* x, const float* dy, float* dw, const ConvShape& s, float* workspace,
-                               size_t workspace_floats);
+                               size_t workspace_floats, const BnFold* fold = nullptr);
 
 // ---- transforms --------------------------------------------------------------------------------------------
 // B^T d B for one 4x4 patch (rows first, then columns): 32 additions.

@@ -264,6 +264,9 @@ typedef struct bcnn_conv_param {
     int dw_node;       /* index of the depthwise node that is this node's only consumer and normalises this node's
                         * pre-normalisation output while staging it (bcnn_link_conv_depthwise), -1: none */
     int apply_skipped; /* this node left its batch-norm apply sweep to its consumer in the running forward pass */
+    int fold_bn;       /* the stand-alone batch-norm node in front of this (1x1) node that leaves its apply sweep to this node's
+                        * packed weights inside a forward pass (bcnn_link_batchnorm_conv), -1: none */
+    int folded;        /* the running pass's forward took that route: the backward reads the batch-norm's INPUT */
     int pool_bwd_pending; /* pool_node >= 0, inside a backward pass: that node left its backward to this node's (one kernel
                            * does the pooling backward and this node's batch-norm backward: bcnn_hip_maxpool_bn_backward) */
     float *insums_gpu;   /* dw_node >= 0: partial backward sums of this node's batch-norm, left by that depthwise node's */
@@ -312,6 +315,10 @@ typedef struct bcnn_batchnorm_param {
     int bsums_splits;    /* > 0: bsums_gpu holds the sums of the gradient written in the running backward pass */
     int input_kept;      /* the input tensor is not this node's output and has no other consumer: it IS the copy of the
                           * input the reference keeps in `workspace` (bcnn_batchnorm_layer.c:208) */
+    int fold_conv;       /* the 1x1 convolution node that is this node's only consumer and folds this node's affine map into
+                          * its weights inside a forward pass (bcnn_hip_conv_set_input_bnfold), -1: none */
+    int apply_skipped;   /* the running forward pass left this node's output tensor unwritten for that node ... */
+    int data_pending;    /* ... and nobody has asked for it since (bcnn_materialize_data produces it on demand) */
 #endif
 } bcnn_batchnorm_param;
 

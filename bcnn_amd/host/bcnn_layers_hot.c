@@ -110,6 +110,7 @@ bcnn_status bcnn_add_convolutional_layer(bcnn_net *net, int num_filters, int siz
     param->pool_node = -1;
     param->dw_node = -1;
     param->bnsums_node = -1;
+    param->fold_bn = -1;
     node.forward = bcnn_forward_conv_layer;
     node.backward = bcnn_backward_conv_layer;
     node.update = bcnn_update_conv_layer;
@@ -159,15 +160,34 @@ static conv_io conv_tensors(bcnn_net *net, bcnn_node *node) {
     return io;
 }
 
+/* the stand-alone batch-norm node in front of a node whose forward folded it (cp->folded), for the calls that follow */
+static const float *announce_bnfold(bcnn_net *net, const bcnn_conv_param *p) {
+    const bcnn_node *bn = &net->nodes[p->fold_bn];
+    const bcnn_batchnorm_param *bp = (const bcnn_batchnorm_param *)bn->param;
+    bcnn_hip_conv_set_input_bnfold(bp->saved_mean.data_gpu, bp->saved_variance.data_gpu, net->tensors[bn->src[3]].data_gpu,
+                                   net->tensors[bn->src[4]].data_gpu);
+    return net->tensors[bn->src[0]].data_gpu; /* the batch-norm's INPUT: what the convolution multiplies */
+}
+
 void bcnn_forward_conv_layer(bcnn_net *net, bcnn_node *node) {
     bcnn_conv_param *p = (bcnn_conv_param *)node->param;
     conv_io io = conv_tensors(net, node);
     p->data_pending = 0;
     p->apply_skipped = 0;
+    p->folded = 0;
+    const float *xin = io.x->data_gpu;
+    if (hctx(net)->in_pass == 1 && net->mode == BCNN_MODE_TRAIN && p->fold_bn >= 0 &&
+        ((bcnn_batchnorm_param *)net->nodes[p->fold_bn].param)->apply_skipped) {
+        /* the batch-norm node that ran just before in this pass stopped after its statistics: whichever forward entry runs
+         * below reads ITS input and packs weights that carry its affine map */
+        ((bcnn_batchnorm_param *)net->nodes[p->fold_bn].param)->apply_skipped = 0;
+        xin = announce_bnfold(net, p);
+        p->folded = 1;
+    }
     if (hctx(net)->in_pass == 1 && (p->pool_node >= 0 || p->dw_node >= 0) && net->mode == BCNN_MODE_TRAIN) {
         /* the max-pooling / depthwise node that runs next in this pass normalises this node's pre-normalisation output on
          * the fly: convolution and batch statistics only; this node's own output tensor is not written */
-        bcnn_hip_conv_forward_stats_only(io.x->data_gpu, io.w->data_gpu, io.b->data_gpu, io.x->n, io.x->c, io.x->h, io.x->w,
+        bcnn_hip_conv_forward_stats_only(xin, io.w->data_gpu, io.b->data_gpu, io.x->n, io.x->c, io.x->h, io.x->w,
                                          p->num, p->size, p->stride, p->pad, p->num_groups, io.run_mean->data_gpu,
                                          io.run_var->data_gpu, io.scales->data_gpu, p->saved_mean.data_gpu,
                                          p->saved_variance.data_gpu, p->bn_workspace_gpu);
@@ -181,7 +201,7 @@ void bcnn_forward_conv_layer(bcnn_net *net, bcnn_node *node) {
         bcnn_node *en = &net->nodes[p->elt_node];
         bcnn_eltwise_param *ep = (bcnn_eltwise_param *)en->param;
         bcnn_tensor *r = &net->tensors[en->src[1]], *out = &net->tensors[en->dst[0]];
-        bcnn_hip_conv_forward_residual(io.x->data_gpu, io.w->data_gpu, io.b->data_gpu, io.x->n, io.x->c, io.x->h, io.x->w,
+        bcnn_hip_conv_forward_residual(xin, io.w->data_gpu, io.b->data_gpu, io.x->n, io.x->c, io.x->h, io.x->w,
                                        p->num, p->size, p->stride, p->pad, p->num_groups, io.run_mean->data_gpu,
                                        io.run_var->data_gpu, io.scales->data_gpu, p->saved_mean.data_gpu,
                                        p->saved_variance.data_gpu, p->bn_workspace_gpu, r->data_gpu,
@@ -190,7 +210,7 @@ void bcnn_forward_conv_layer(bcnn_net *net, bcnn_node *node) {
         p->data_pending = 1;
         return;
     }
-    bcnn_hip_conv_forward(io.x->data_gpu, io.w->data_gpu, io.b->data_gpu, io.y->data_gpu, io.x->n, io.x->c, io.x->h,
+    bcnn_hip_conv_forward(xin, io.w->data_gpu, io.b->data_gpu, io.y->data_gpu, io.x->n, io.x->c, io.x->h,
                           io.x->w, p->num, p->size, p->stride, p->pad, p->num_groups, (int)p->activation,
                           io.slopes ? io.slopes->data_gpu : NULL, p->batch_norm,
                           io.run_mean ? io.run_mean->data_gpu : NULL, io.run_var ? io.run_var->data_gpu : NULL,
@@ -201,6 +221,9 @@ void bcnn_forward_conv_layer(bcnn_net *net, bcnn_node *node) {
 void bcnn_backward_conv_layer(bcnn_net *net, bcnn_node *node) {
     bcnn_conv_param *p = (bcnn_conv_param *)node->param;
     conv_io io = conv_tensors(net, node);
+    const float *xin = io.x->data_gpu;
+    if (hctx(net)->in_pass == 2 && p->folded && p->fold_bn >= 0) /* this pass's forward folded the batch-norm in front: */
+        xin = announce_bnfold(net, p);                           /* the weight gradient is formed against ITS input */
     if (hctx(net)->in_pass == 2 && p->pool_bwd_pending) {
         /* the max-pooling node (which ran just before in this pass) left its backward to this node */
         bcnn_node *pn = &net->nodes[p->pool_node];
@@ -245,7 +268,7 @@ void bcnn_backward_conv_layer(bcnn_net *net, bcnn_node *node) {
         bcnn_node *bn = to_bn ? &net->nodes[p->bnsums_node] : NULL;
         bcnn_batchnorm_param *bp = bn ? (bcnn_batchnorm_param *)bn->param : NULL;
         const int splits = bcnn_hip_conv_backward_presummed(
-            io.x->data_gpu, io.w->data_gpu, io.b->data_gpu, io.y->data_gpu, io.y->grad_data_gpu, io.x->grad_data_gpu,
+            xin, io.w->data_gpu, io.b->data_gpu, io.y->data_gpu, io.y->grad_data_gpu, io.x->grad_data_gpu,
             io.w->grad_data_gpu, io.b->grad_data_gpu, io.x->n, io.x->c, io.x->h, io.x->w, p->num, p->size, p->stride, p->pad,
             p->num_groups, (int)p->activation, io.slopes ? io.slopes->data_gpu : NULL,
             io.slopes ? io.slopes->grad_data_gpu : NULL, p->batch_norm, io.scales ? io.scales->data_gpu : NULL,
@@ -257,7 +280,7 @@ void bcnn_backward_conv_layer(bcnn_net *net, bcnn_node *node) {
         if (bp) bp->bsums_splits = splits;
         return;
     }
-    bcnn_hip_conv_backward(io.x->data_gpu, io.w->data_gpu, io.b->data_gpu, io.y->data_gpu, io.y->grad_data_gpu,
+    bcnn_hip_conv_backward(xin, io.w->data_gpu, io.b->data_gpu, io.y->data_gpu, io.y->grad_data_gpu,
                            io.x->grad_data_gpu /* NULL for the net input: no dX */, io.w->grad_data_gpu,
                            io.b->grad_data_gpu, io.x->n, io.x->c, io.x->h, io.x->w, p->num, p->size, p->stride,
                            p->pad, p->num_groups, (int)p->activation, io.slopes ? io.slopes->data_gpu : NULL,
@@ -458,6 +481,7 @@ bcnn_status bcnn_add_batchnorm_layer(bcnn_net *net, const char *src_id, const ch
     node.param = param;
     param->dw_node = -1;
     param->sums_conv = -1;
+    param->fold_conv = -1;
     node.forward = bcnn_forward_batchnorm_layer;
     node.backward = bcnn_backward_batchnorm_layer;
     node.release_param = bcnn_release_param_batchnorm_layer;
@@ -493,6 +517,19 @@ void bcnn_forward_batchnorm_layer(bcnn_net *net, bcnn_node *node) {
         stats = dp->stats_gpu;
         splits = dp->stats_splits;
         dp->stats_splits = 0;
+    }
+    p->apply_skipped = 0;
+    p->data_pending = 0;
+    if (hctx(net)->in_pass == 1 && net->mode == BCNN_MODE_TRAIN && p->fold_conv >= 0) {
+        /* the 1x1 convolution that runs next in this pass multiplies this node's INPUT by weights that carry this node's
+         * affine map: statistics only, the output tensor is not written (bcnn_materialize_data produces it on demand) */
+        bcnn_hip_batchnorm_forward_stats_only(x->data_gpu, net->tensors[node->src[1]].data_gpu,
+                                              net->tensors[node->src[2]].data_gpu, net->tensors[node->src[3]].data_gpu,
+                                              net->tensors[node->src[4]].data_gpu, p->saved_mean.data_gpu,
+                                              p->saved_variance.data_gpu, x->n, x->c, x->h * x->w, stats, splits);
+        p->apply_skipped = 1;
+        p->data_pending = 1;
+        return;
     }
     bcnn_hip_batchnorm_forward_stats(x->data_gpu, y->data_gpu, net->tensors[node->src[1]].data_gpu,
                                      net->tensors[node->src[2]].data_gpu, net->tensors[node->src[3]].data_gpu,
@@ -672,10 +709,15 @@ void bcnn_link_conv_depthwise(bcnn_net *net) {
 void bcnn_link_batchnorm_conv(bcnn_net *net) {
     for (int i = 0; i < net->num_nodes; ++i) {
         bcnn_node *nd = &net->nodes[i];
-        if (nd->type == BCNN_LAYER_CONV2D) ((bcnn_conv_param *)nd->param)->bnsums_node = -1;
-        else if (nd->type == BCNN_LAYER_BATCHNORM) {
+        if (nd->type == BCNN_LAYER_CONV2D) {
+            ((bcnn_conv_param *)nd->param)->bnsums_node = -1;
+            ((bcnn_conv_param *)nd->param)->fold_bn = -1;
+            ((bcnn_conv_param *)nd->param)->folded = 0;
+        } else if (nd->type == BCNN_LAYER_BATCHNORM) {
             ((bcnn_batchnorm_param *)nd->param)->sums_conv = -1;
             ((bcnn_batchnorm_param *)nd->param)->bsums_splits = 0;
+            ((bcnn_batchnorm_param *)nd->param)->fold_conv = -1;
+            ((bcnn_batchnorm_param *)nd->param)->apply_skipped = 0;
         }
     }
     if (BCNN_EXP_ENV("BCNN_NO_NODE_FUSION") || BCNN_EXP_ENV("BCNN_NO_BN_CONV_FUSION")) return;
@@ -702,6 +744,15 @@ void bcnn_link_batchnorm_conv(bcnn_net *net) {
         }
         bp->sums_conv = c;
         cp->bnsums_node = c - 1;
+        /* forward: the same pair can drop the batch-norm's apply sweep -- its affine map goes into the convolution's packed
+         * weights (the parity bar is per reference-visible tensor, not operation order). Needs the
+         * convolution's own batch-norm behind (it absorbs the constant W b), TRAIN mode, the batch-norm's input still in
+         * place at backward time (input_kept), and kernels that take the folded form. */
+        if (net->mode == BCNN_MODE_TRAIN && !BCNN_EXP_ENV("BCNN_NO_BN_FOLD") && cp->batch_norm && bp->input_kept &&
+            bcnn_hip_conv_bnfold_fusable(z->n, z->c, z->h, z->w, cp->num)) {
+            bp->fold_conv = c;
+            cp->fold_bn = c - 1;
+        }
     }
 }
 
@@ -709,6 +760,18 @@ void bcnn_link_batchnorm_conv(bcnn_net *net) {
  * eltwise node behind it. Its pre-normalisation values and batch statistics are in place, so the tensor is one batch-norm
  * apply sweep away (bcnn_batchnorm_layer.c:226-241 with the saved statistics). */
 void bcnn_materialize_data(bcnn_net *net, int tensor) {
+    for (int i = 0; i < net->num_nodes; ++i) { /* batch-norm nodes whose apply sweep went into the next node's weights */
+        bcnn_node *bn = &net->nodes[i];
+        if (bn->type != BCNN_LAYER_BATCHNORM) continue;
+        bcnn_batchnorm_param *bp = (bcnn_batchnorm_param *)bn->param;
+        if (!bp->data_pending || (tensor >= 0 && tensor != bn->dst[0])) continue;
+        bp->data_pending = 0;
+        const bcnn_tensor *x = &net->tensors[bn->src[0]];
+        bcnn_tensor *z = &net->tensors[bn->dst[0]];
+        bcnn_hip_batchnorm_apply(x->data_gpu, z->data_gpu, net->tensors[bn->src[3]].data_gpu,
+                                 net->tensors[bn->src[4]].data_gpu, bp->saved_mean.data_gpu, bp->saved_variance.data_gpu,
+                                 z->n, z->c, z->h * z->w, BCNN_HIP_ACT_NONE);
+    }
     for (int i = 0; i < net->num_nodes; ++i) {
         bcnn_node *cn = &net->nodes[i];
         if (cn->type != BCNN_LAYER_CONV2D) continue;

@@ -377,6 +377,22 @@ void bcnn_hip_batchnorm_forward_stats(const float *x_d, float *y_d, float *run_m
                                       const float *scales_d, const float *bias_d, float *saved_mean_d,
                                       float *saved_var_d, float *x_norm_d, float *workspace_d, int n, int c, int hw,
                                       int mode, int act, const float *stats_d, int splits);
+/* A stand-alone batch-norm node (no activation) whose only consumer is a 1x1 / stride 1 / one-group convolution with its own
+ * fused batch-norm, TRAIN mode (MobileNet: [depthwise] -> [batchnorm] -> [conv 1x1 + BN]): z = a y + b per channel, so
+ * W z = (W diag(a)) y + W b and the batch-norm's apply sweep (bcnn_batchnorm_layer.c:226-241) folds into the GEMM.
+ *   bcnn_hip_batchnorm_forward_stats_only  the batch-norm node's part: saved and running statistics, nothing written
+ *   bcnn_hip_conv_bnfold_fusable           1: the convolution's kernels take the folded form for this shape
+ *   bcnn_hip_conv_set_input_bnfold         announces, to the NEXT bcnn_hip_conv_forward* / bcnn_hip_conv_backward* call of
+ *                                          this thread (which consumes it), that its x_d is the batch-norm's INPUT y and
+ *                                          the batch-norm is (mean, var, scales, bias): forward packs W diag(a) and shifts
+ *                                          only the running mean of the convolution's own batch-norm by W b (the stored
+ *                                          pre-normalisation values are W diag(a) y: every later use subtracts the batch
+ *                                          mean); backward returns (dy y^T) diag(a) as the weight gradient. */
+void bcnn_hip_batchnorm_forward_stats_only(const float *x_d, float *run_mean_d, float *run_var_d, const float *scales_d,
+                                           const float *bias_d, float *saved_mean_d, float *saved_var_d, int n, int c,
+                                           int hw, const float *stats_d, int splits);
+int bcnn_hip_conv_bnfold_fusable(int n, int c, int h, int w, int f);
+void bcnn_hip_conv_set_input_bnfold(const float *mean_d, const float *var_d, const float *scales_d, const float *bias_d);
 int bcnn_hip_depthwise_bn_fusable(int n, int c, int h, int w, int k, int stride, int pad, int act);
 void bcnn_hip_batchnorm_backward_sums(const float *dy_d, const float *scales_d, float *dscales_d, float *dbias_d,
                                       const float *saved_mean_d, const float *saved_var_d, float *dmean_d,
