@@ -83,7 +83,10 @@ __device__ __forceinline__ void w43_at(const float (&m)[6], float (&y)[4]) {
     y[3] = __builtin_fmaf(8.f, d2, d1) + m[5];
 }
 
-template <bool STATS>
+// RAG: planes that are not whole 4 x 4 tiles (14 x 14, 7 x 7): the last tile row / column hangs over -- rows beyond H arrive
+// as zeros through the row test, columns beyond W (which a 16-byte row load takes from the NEXT image row) are zeroed by
+// selects, outputs beyond the plane are dropped by address and left out of the statistics; rows are 4-byte aligned only.
+template <bool STATS, bool RAG>
 __global__ __launch_bounds__(64 * W4_NW, 3) void wino43_kernel(const Wino43Args a) {
     __shared__ __attribute__((aligned(1024))) float lds[2 * W4_STAGE];  // 147,456 bytes: two stages; the epilogue's M in the second
     const int tid = threadIdx.x, lane = tid & 63;
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(64 * W4_NW, 3) void wino43_kernel(const Wino43Args 
     if (nitems == 0) return;
 
     // the item whose chunks are being REQUESTED (from the end of the previous item's K loop on, that is the next one)
-    int kb = 0, nchunks = nch, slot = -1, m0 = 0, tb = 0, th = 0;
+    int kb = 0, nchunks = nch, slot = -1, m0 = 0, tb = 0, th = 0, ncols = 4, nrows = 4;
     bool tile_ok = false, pad_l = false, pad_r = false, edge = false;
     unsigned vbase = 0, edge_delta = 0, o00 = kOOB;
     auto start_item = [&](int it) {
@@ -148,6 +151,8 @@ __global__ __launch_bounds__(64 * W4_NW, 3) void wino43_kernel(const Wino43Args 
         edge = edge_l || edge_r;
         edge_delta = edge_l ? (unsigned)-4 : 16u;
         o00 = tile_ok ? (n * (unsigned)a.M * (unsigned)HW + (unsigned)(4 * th * a.W + 4 * tw)) * 4u : kOOB;
+        ncols = a.W - 4 * tw < 4 ? a.W - 4 * tw : 4;  // RAG: own columns / rows that exist
+        nrows = a.H - 4 * th < 4 ? a.H - 4 * th : 4;
     };
 
     float p[6][4], e[6];  // a patch: own columns and the edge lanes' neighbour column (0.0 elsewhere)
@@ -159,7 +164,10 @@ __global__ __launch_bounds__(64 * W4_NW, 3) void wino43_kernel(const Wino43Args 
             const bool row_ok = tile_ok && (unsigned)ih < (unsigned)a.H;
             const unsigned row = vbase + (unsigned)i * row_bytes;
             const buf_f32x4 v = buffer_load_f32x4(rs_src, (int)(row_ok ? row : kOOB), (int)soff, 0);
-            p[i][0] = v[0]; p[i][1] = v[1]; p[i][2] = v[2]; p[i][3] = v[3];
+            p[i][0] = v[0];
+            p[i][1] = (RAG && ncols < 2) ? 0.f : v[1];
+            p[i][2] = (RAG && ncols < 3) ? 0.f : v[2];
+            p[i][3] = (RAG && ncols < 4) ? 0.f : v[3];
             e[i] = buffer_load_f32(rs_src, (int)((row_ok && edge) ? row + edge_delta : kOOB), (int)soff, 0);
         }
     };
@@ -252,7 +260,7 @@ __global__ __launch_bounds__(64 * W4_NW, 3) void wino43_kernel(const Wino43Args 
         // S[(xi * 8 + g) * 64 + h * 32 + tile], channel within the half = (g & 3) + 8 (g >> 2) + 4 h
         float* const S = lds + W4_STAGE;
         const unsigned e_o00 = o00;
-        const int e_m0 = m0, e_tb = tb, e_slot = slot;
+        const int e_m0 = m0, e_tb = tb, e_slot = slot, e_ncols = ncols, e_nrows = nrows;
         const bool e_tile_ok = tile_ok;
         const bool has_next = it + 1 < nitems;
         if (has_next) start_item(it + 1);
@@ -304,18 +312,31 @@ __global__ __launch_bounds__(64 * W4_NW, 3) void wino43_kernel(const Wino43Args 
                     }
                 } else {
                     const unsigned off = ((f_ok && e_tile_ok) ? e_o00 + (unsigned)f * (unsigned)HW * 4u : kOOB);  // per lane: f differs by half-wave
+                    if (!RAG) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const unsigned ro = (off >= kOOB) ? kOOB : off + (unsigned)r * row_bytes;
-                        buffer_store_f32x2(buf_f32x2{o[r][0], o[r][1]}, rs_dst, (int)ro, 0, 0);
-                        buffer_store_f32x2(buf_f32x2{o[r][2], o[r][3]}, rs_dst, (int)(ro >= kOOB ? kOOB : ro + 8u), 0, 0);
+                        for (int r = 0; r < 4; ++r) {
+                            const unsigned ro = (off >= kOOB) ? kOOB : off + (unsigned)r * row_bytes;
+                            buffer_store_f32x2(buf_f32x2{o[r][0], o[r][1]}, rs_dst, (int)ro, 0, 0);
+                            buffer_store_f32x2(buf_f32x2{o[r][2], o[r][3]}, rs_dst, (int)(ro >= kOOB ? kOOB : ro + 8u), 0, 0);
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                const bool in = off < kOOB && r < e_nrows && c < e_ncols;
+                                buffer_store_f32(o[r][c], rs_dst, (int)(in ? off + (unsigned)r * row_bytes + 4u * c : kOOB), 0, 0);
+                            }
                     }
                     if (STATS) {  // a half-wave holds channel f for the unit's 32 tiles
                         float sv = 0.f, sq = 0.f;
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
 #pragma unroll
-                            for (int c = 0; c < 4; ++c) { sv += o[r][c]; sq += o[r][c] * o[r][c]; }
+                            for (int c = 0; c < 4; ++c) {
+                                const float v = (RAG && (r >= e_nrows || c >= e_ncols)) ? 0.f : o[r][c];
+                                sv += v; sq += v * v;
+                            }
                         if (!e_tile_ok) { sv = 0.f; sq = 0.f; }
                         sv = w43_half_sum(sv);
                         sq = w43_half_sum(sq);
@@ -365,16 +386,26 @@ __global__ __launch_bounds__(256) void wino43_tail_fixup_kernel(const Wino43Args
         r1.x += x1.x; r1.y += x1.y; r1.z += x1.z; r1.w += x1.w;
     }
     const int HW = a.H * a.W;
-    if (tile_ok && f_ok) {
-        float* d = a.dst + ((size_t)n * a.M + f) * HW + (size_t)(4 * th + 2 * half) * a.W + 4 * tw;
-        *reinterpret_cast<float4*>(d) = r0;
-        *reinterpret_cast<float4*>(d + a.W) = r1;
+    const int ncols = a.W - 4 * tw < 4 ? a.W - 4 * tw : 4, row0 = 4 * th + 2 * half;
+    float v0[4] = {r0.x, r0.y, r0.z, r0.w}, v1[4] = {r1.x, r1.y, r1.z, r1.w};
+    const bool in0 = tile_ok && row0 < a.H, in1 = tile_ok && row0 + 1 < a.H;
+    if (f_ok) {
+        float* d = a.dst + ((size_t)n * a.M + f) * HW + (size_t)row0 * a.W + 4 * tw;
+        if (ncols == 4 && (a.W & 3) == 0) {
+            if (in0) *reinterpret_cast<float4*>(d) = r0;
+            if (in1) *reinterpret_cast<float4*>(d + a.W) = r1;
+        } else {
+            for (int c = 0; c < ncols; ++c) {
+                if (in0) d[c] = v0[c];
+                if (in1) d[a.W + c] = v1[c];
+            }
+        }
     }
     if (STATS) {
         float sv = 0.f, sq = 0.f;
-        if (tile_ok) {
-            sv = (r0.x + r0.y + r0.z + r0.w) + (r1.x + r1.y + r1.z + r1.w);
-            sq = (r0.x * r0.x + r0.y * r0.y + r0.z * r0.z + r0.w * r0.w) + (r1.x * r1.x + r1.y * r1.y + r1.z * r1.z + r1.w * r1.w);
+        for (int c = 0; c < ncols; ++c) {
+            if (in0) { sv += v0[c]; sq += v0[c] * v0[c]; }
+            if (in1) { sv += v1[c]; sq += v1[c] * v1[c]; }
         }
         sv = wave_sum_dpp(sv);
         sq = wave_sum_dpp(sq);
@@ -474,7 +505,7 @@ static float* w43_tail_scratch(size_t floats) {
 static int g_w43_force = -1;  // experiment build: BCNN_HIP_WINOGRAD43=0/1 overrides the rule
 bool wino43_wanted(const ConvShape& s, int J, int M) {
     if (s.ksz != 3 || s.stride != 1 || s.pad != 1 || s.groups != 1) return false;
-    if ((s.H & 3) != 0 || (s.W & 3) != 0 || s.H < 4 || s.W < 4) return false;  // whole 4 x 4 tiles, 16-byte rows
+    if (s.H < 3 || s.W < 3) return false;
     if (J < 16 || (J % W4_KC) != 0 || M < 16) return false;
     if ((size_t)s.N * J * s.HW * 4 >= 0x7ffffff0ull || (size_t)s.N * M * s.HW * 4 >= 0x7ffffff0ull) return false;
     if (g_w43_force < 0) {
@@ -483,16 +514,26 @@ bool wino43_wanted(const ConvShape& s, int J, int M) {
     }
     if (g_w43_force != 2) return g_w43_force == 1;
     // enough units to fill the chip, and the channel counts the 32-wide blocks are made for
-    const long long T = (long long)s.N * (s.H / 4) * (s.W / 4);
-    return J >= 64 && M >= 64 && ceil_div(T, W4_BT) * ((M + W4_BF - 1) / W4_BF) >= 2LL * kCUs;
+    // Measured against the F(2x2,3x3) kernel on the ResNet-18 stages (N = 128, forward with statistics / dX, ms, same box):
+    // 64 ch 56 x 56 0.157 / 0.152 against 0.195 / 0.177; 128 ch 28 x 28 0.143 / 0.141 against 0.168 / 0.163; 512 ch 7 x 7
+    // (four tiles cover 8 x 8, as do the sixteen 2 x 2 tiles) 0.179 / 0.172 against 0.184 / 0.181; 256 ch 14 x 14 (tiles cover
+    // 16 x 16: 31 % overhang where F(2x2,3x3) has none) 0.169 / 0.168 against 0.159 / 0.157. So: planes this tiling pads no
+    // more than the 2 x 2 tiling does, enough units for a full round of the chip, the channel counts the blocks are made for --
+    // Inside the ResNet-18 step the 7 x 7 layers came out even or worse (forward class 1.94 against 1.91 ms, step 10.79
+    // against 10.73 ms): whole-tile planes only. The RAG instantiations stay (experiment switch, tests/test_winograd43.py).
+    const long long th4 = (s.H + 3) / 4, tw4 = (s.W + 3) / 4;
+    if ((s.H & 3) != 0 || (s.W & 3) != 0) return false;
+    const long long T = (long long)s.N * th4 * tw4;
+    return J >= 64 && M >= 64 && ceil_div(T, W4_BT) * ((M + W4_BF - 1) / W4_BF) >= (long long)kCUs;
 }
 
 // what can still send a wanted layer to the F(2x2, 3x3) kernel: 16-byte rows need 16-byte aligned tensors, and the caller's
 // statistics buffer has to hold one slot per channel and block of 32 tiles
 static bool wino43_usable(const float* src, const float* dst, const ConvShape& s, int dx_mode, const ConvStats* stats) {
-    if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) != 0) return false;
+    const bool rag = (s.H & 3) != 0 || (s.W & 3) != 0;
+    if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & (rag ? 3 : 15)) != 0) return false;
     if (stats && stats->partials) {
-        const long long T = (long long)s.N * (s.H / 4) * (s.W / 4);
+        const long long T = (long long)s.N * ((s.H + 3) / 4) * ((s.W + 3) / 4);
         const int M = dx_mode ? s.C : s.F;
         if ((size_t)M * (size_t)ceil_div(T, W4_BT) * 2 > stats->capacity) return false;
     }
@@ -503,7 +544,7 @@ static void wino43_run(const float* src, const float* w, float* dst, const ConvS
     Wino43Args a;
     a.src = src; a.dst = dst;
     a.N = s.N; a.J = dx_mode ? s.F : s.C; a.M = dx_mode ? s.C : s.F; a.H = s.H; a.W = s.W;
-    a.TH = s.H / 4; a.TW = s.W / 4;
+    a.TH = (s.H + 3) / 4; a.TW = (s.W + 3) / 4;
     a.T = (unsigned)((long long)s.N * a.TH * a.TW);
     a.Jpad = (a.J + W4_KC - 1) / W4_KC * W4_KC;
     a.Mpad = (a.M + W4_BF - 1) / W4_BF * W4_BF;
@@ -541,8 +582,11 @@ static void wino43_run(const float* src, const float* w, float* dst, const ConvS
             a.tail_scr_bytes = (unsigned)(scr_floats * sizeof(float));
         }
     }
-    if (a.stats) wino43_kernel<true><<<grid, 64 * W4_NW, 0, current_stream()>>>(a);
-    else wino43_kernel<false><<<grid, 64 * W4_NW, 0, current_stream()>>>(a);
+    const bool rag = (s.H & 3) != 0 || (s.W & 3) != 0;
+    if (a.stats && rag) wino43_kernel<true, true><<<grid, 64 * W4_NW, 0, current_stream()>>>(a);
+    else if (a.stats) wino43_kernel<true, false><<<grid, 64 * W4_NW, 0, current_stream()>>>(a);
+    else if (rag) wino43_kernel<false, true><<<grid, 64 * W4_NW, 0, current_stream()>>>(a);
+    else wino43_kernel<false, false><<<grid, 64 * W4_NW, 0, current_stream()>>>(a);
     KERNEL_CHECK();
     if (a.tail_units > 0) {
         if (a.stats) wino43_tail_fixup_kernel<true><<<(unsigned)(a.tail_units * 8), 256, 0, current_stream()>>>(a);
@@ -552,7 +596,9 @@ static void wino43_run(const float* src, const float* w, float* dst, const ConvS
     if (stats) stats->splits = a.stats ? a.tblocks : 0;
 }
 
-static double w43_flops(const ConvShape& s) { return 2.0 * 36.0 * ((double)s.N * (s.H / 4) * (s.W / 4)) * s.C * s.F; }
+static double w43_flops(const ConvShape& s) { return 2.0 * 36.0 * ((double)s.N * ((s.H + 3) / 4) * ((s.W + 3) / 4)) * s.C * s.F; }
+// the same without the tiles' overhang on planes that are not whole tiles (7 x 7: four tiles cover 8 x 8)
+static double w43_useful_flops(const ConvShape& s) { return 2.0 * 36.0 * ((double)s.N * s.H * s.W / 16.0) * s.C * s.F; }
 static double w43_bytes(const ConvShape& s) {
     return 4.0 * ((double)s.N * s.C * s.HW + (double)s.F * s.K + (double)s.N * s.F * s.OHOW);
 }
@@ -560,14 +606,14 @@ static double w43_bytes(const ConvShape& s) {
 // raw output only (a fused batch-norm behind it, or a caller that adds nothing): the other forms stay on F(2x2, 3x3)
 bool conv_forward_winograd43(const float* x, const float* w, float* y, const ConvShape& s, int raw, ConvStats* stats) {
     if (!raw || !wino43_wanted(s, s.C, s.F) || !wino43_usable(x, y, s, 0, stats)) return false;
-    KTimer kt(K_CONV_FWD_WINO, w43_flops(s), w43_bytes(s), w43_flops(s));
+    KTimer kt(K_CONV_FWD_WINO, w43_flops(s), w43_bytes(s), w43_useful_flops(s));
     wino43_run(x, w, y, s, 0, stats);
     return true;
 }
 
 bool conv_backward_data_winograd43(const float* w, const float* dy, float* dx, const ConvShape& s) {
     if (!wino43_wanted(s, s.F, s.C) || !wino43_usable(dy, dx, s, 1, nullptr)) return false;
-    KTimer kt(K_CONV_DX_WINO, w43_flops(s), w43_bytes(s), w43_flops(s));
+    KTimer kt(K_CONV_DX_WINO, w43_flops(s), w43_bytes(s), w43_useful_flops(s));
     wino43_run(dy, w, dx, s, 1, nullptr);
     return true;
 }

@@ -26,6 +26,13 @@ SHAPES = [  # n, c, h, w, f, act, bn
     (3, 32, 20, 20, 64, 5, 1),    # 75 tiles: three units
     (2, 16, 8, 8, 64, 0, 0),      # no batch-norm: the forward stays on the other kernels, dX runs here
     (4, 128, 8, 8, 128, 2, 1),    # 16 chunks of 8 channels
+    # planes that are not whole 4 x 4 tiles: the last tile row / column hangs over (rows / columns beyond the plane read as
+    # zeros, are not stored and stay out of the statistics); rows are only 4-byte aligned
+    (3, 32, 14, 14, 64, 2, 1),    # 4 x 4 tiles cover 16 x 16
+    (5, 64, 7, 7, 96, 2, 1),      # 2 x 2 tiles cover 8 x 8, 7-float rows
+    (2, 16, 9, 13, 40, 0, 1),     # one row / one column of overhang, ragged channel block
+    (2, 24, 6, 5, 32, 5, 1),      # two columns of the last tile column exist... W = 5: tiles of 4 + 1 columns
+    (3, 16, 3, 3, 16, 0, 0),      # a single partial tile per image (dX only)
 ]
 
 
