@@ -65,6 +65,7 @@ struct WinoPackJob {
     float* u;
     int F, C, dx_mode, Jpad, Mpad;
     int blocks;  // of 256 threads
+    int npos;    // 16: G g G^T of F(2x2,3x3) (conv_winograd_fused.hip); 36: of F(4x4,3x3) (conv_winograd43.hip)
 };
 constexpr int kPackMaxTaps = 49;
 struct IgemmPackJob {
@@ -100,6 +101,7 @@ __device__ __forceinline__ float bnfold_a(const float* __restrict__ var, const f
 float* prepack_take(const float* w, int kind, int mode, size_t floats);
 // what the kernel a layer will run on needs packed; false: nothing (another kernel takes the layer)
 bool wino_fused_pack_plan(const ConvShape& s, int dx_mode, WinoPackJob* job, size_t* floats);  // conv_winograd_fused.hip
+bool wino43_pack_plan(const ConvShape& s, int dx_mode, WinoPackJob* job, size_t* floats);      // conv_winograd43.hip
 bool dma_pack_plan(const ConvShape& s, int dx_mode, IgemmPackJob* job, size_t* floats);        // conv_igemm_dma.hip
 bool conv_winograd_unfused_takes(const ConvShape& s);                                          // conv_winograd.hip
 void wino_fused_pack_launch(const WinoPackJob* jobs_dev, int n, int max_blocks);

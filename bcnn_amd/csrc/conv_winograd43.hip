@@ -23,6 +23,7 @@
 // is the precedent for computing these layers in a transformed domain; the transform matrices are Lavin & Gray's F(4x4,3x3).
 #include "conv_common.h"
 #include "lds_dma.h"
+#include "wino43_pack.h"
 
 namespace bcnn_hip {
 
@@ -416,50 +417,9 @@ __global__ __launch_bounds__(256) void wino43_tail_fixup_kernel(const Wino43Args
     }
 }
 
-// U[xi][j][m] = (G g G^T)[xi] packed [36][Jpad][Mpad] with zero padding.
-//   forward: m = f, j = c; dX: m = c, j = f and the filter rotated by 180 degrees
 __global__ __launch_bounds__(256) void wino43_pack_weights_kernel(const float* __restrict__ w, float* __restrict__ u, int F, int C,
                                                                   int dx_mode, int Jpad, int Mpad) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= Jpad * Mpad) return;
-    const int j = idx / Mpad, m = idx - j * Mpad;
-    const int M = dx_mode ? C : F, J = dx_mode ? F : C;
-    float g[3][3];
-    const bool live = m < M && j < J;
-    {
-        const int f = dx_mode ? j : m, c = dx_mode ? m : j;
-        const float* p = w + (live ? ((size_t)f * C + c) * 9 : 0);
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int b = 0; b < 3; ++b) g[r][b] = live ? (dx_mode ? p[(2 - r) * 3 + (2 - b)] : p[r * 3 + b]) : 0.f;
-    }
-    // G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
-    auto gvec = [](float a0, float a1, float a2, float (&o)[6]) {
-        o[0] = a0 * (1.f / 4.f);
-        o[1] = (a0 + a1 + a2) * (-1.f / 6.f);
-        o[2] = (a0 - a1 + a2) * (-1.f / 6.f);
-        o[3] = a0 * (1.f / 24.f) + a1 * (1.f / 12.f) + a2 * (1.f / 6.f);
-        o[4] = a0 * (1.f / 24.f) - a1 * (1.f / 12.f) + a2 * (1.f / 6.f);
-        o[5] = a2;
-    };
-    float t[6][3];
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-        float o[6];
-        gvec(g[0][b], g[1][b], g[2][b], o);
-#pragma unroll
-        for (int r = 0; r < 6; ++r) t[r][b] = o[r];
-    }
-    const size_t plane = (size_t)Jpad * Mpad;
-    float* dst = u + idx;
-#pragma unroll
-    for (int r = 0; r < 6; ++r) {
-        float o[6];
-        gvec(t[r][0], t[r][1], t[r][2], o);
-#pragma unroll
-        for (int c = 0; c < 6; ++c) dst[(size_t)(6 * r + c) * plane] = o[c];
-    }
+    wino43_pack_one(w, u, F, C, dx_mode, Jpad, Mpad, blockIdx.x * 256 + threadIdx.x);
 }
 
 // ---- host side ------------------------------------------------------------------------------------------
@@ -557,10 +517,13 @@ static void wino43_run(const float* src, const float* w, float* dst, const ConvS
     a.dst_bytes = (unsigned)((size_t)s.N * a.M * s.HW * 4);
     const size_t u_floats = (size_t)W4_NP * a.Jpad * a.Mpad;
     a.upk_bytes = (unsigned)(u_floats * 4);
-    float* U = w43_scratch(u_floats);
-    wino43_pack_weights_kernel<<<ceil_div((long long)a.Jpad * a.Mpad, 256), 256, 0, current_stream()>>>(w, U, s.F, s.C, dx_mode, a.Jpad,
-                                                                                                      a.Mpad);
-    KERNEL_CHECK();
+    float* U = prepack_take(w, PREPACK_WINO, dx_mode, u_floats);  // transformed ahead by bcnn_hip_conv_prepack?
+    if (!U) {
+        U = w43_scratch(u_floats);
+        wino43_pack_weights_kernel<<<ceil_div((long long)a.Jpad * a.Mpad, 256), 256, 0, current_stream()>>>(w, U, s.F, s.C, dx_mode,
+                                                                                                          a.Jpad, a.Mpad);
+        KERNEL_CHECK();
+    }
     a.upk = U;
     const int nblocks = a.nunits;
     const unsigned grid = (unsigned)(nblocks < kCUs ? nblocks : kCUs);  // persistent: one 147 KB workgroup per CU
@@ -594,6 +557,21 @@ static void wino43_run(const float* src, const float* w, float* dst, const ConvS
         KERNEL_CHECK();
     }
     if (stats) stats->splits = a.stats ? a.tblocks : 0;
+}
+
+// bcnn_hip_conv_prepack: the 36-position pack this layer's forward (dx_mode 0, raw form) / data-gradient (1) kernel will ask
+// prepack_take for; false when the layer does not run here
+bool wino43_pack_plan(const ConvShape& s, int dx_mode, WinoPackJob* job, size_t* floats) {
+    const int J = dx_mode ? s.F : s.C, M = dx_mode ? s.C : s.F;
+    if (!wino43_wanted(s, J, M)) return false;
+    job->w = nullptr; job->u = nullptr;
+    job->F = s.F; job->C = s.C; job->dx_mode = dx_mode;
+    job->Jpad = (J + W4_KC - 1) / W4_KC * W4_KC;
+    job->Mpad = (M + W4_BF - 1) / W4_BF * W4_BF;
+    job->blocks = (int)ceil_div((long long)job->Jpad * job->Mpad, 256);
+    job->npos = W4_NP;
+    *floats = (size_t)W4_NP * job->Jpad * job->Mpad;
+    return true;
 }
 
 static double w43_flops(const ConvShape& s) { return 2.0 * 36.0 * ((double)s.N * ((s.H + 3) / 4) * ((s.W + 3) / 4)) * s.C * s.F; }

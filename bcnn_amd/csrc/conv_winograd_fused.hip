@@ -23,6 +23,7 @@
 // (PREDICT mode there; here also TRAIN forward / dX, inside the 1e-4 parity bar).
 #include "conv_common.h"
 #include "lds_dma.h"
+#include "wino43_pack.h"
 
 namespace bcnn_hip {
 
@@ -959,7 +960,8 @@ __global__ __launch_bounds__(256) void wino_pack_weights_kernel(const float* __r
 __global__ __launch_bounds__(256) void wino_pack_weights_multi_kernel(const WinoPackJob* __restrict__ jobs) {
     const WinoPackJob j = jobs[blockIdx.y];
     if ((int)blockIdx.x >= j.blocks) return;
-    wino_pack_one(j.w, j.u, j.F, j.C, j.dx_mode, j.Jpad, j.Mpad, blockIdx.x * 256 + threadIdx.x);
+    if (j.npos == 36) wino43_pack_one(j.w, j.u, j.F, j.C, j.dx_mode, j.Jpad, j.Mpad, blockIdx.x * 256 + threadIdx.x);
+    else wino_pack_one(j.w, j.u, j.F, j.C, j.dx_mode, j.Jpad, j.Mpad, blockIdx.x * 256 + threadIdx.x);
 }
 
 // ---- host side ------------------------------------------------------------------------------------------
@@ -1134,12 +1136,16 @@ static void wino_fused_run(const float* src, const float* w, float* dst, const C
 // prepack_take for; false when the layer does not run on wino_fused_kernel
 bool wino_fused_pack_plan(const ConvShape& s, int dx_mode, WinoPackJob* job, size_t* floats) {
     const int J = dx_mode ? s.F : s.C, M = dx_mode ? s.C : s.F;
+    // the F(4x4,3x3) kernel is asked first by both passes (its forward only in the raw form: a layer without a batch-norm
+    // behind it then packs for itself, like every layer whose planned kernel does not run)
+    if (wino43_pack_plan(s, dx_mode, job, floats)) return true;
     if (!wino_fused_wanted(s, J, M) || wino_bf16_parts(J) != 0) return false;
     job->w = nullptr; job->u = nullptr;
     job->F = s.F; job->C = s.C; job->dx_mode = dx_mode;
     job->Jpad = (J + WF_KC - 1) / WF_KC * WF_KC;
     job->Mpad = (M + WF_BF - 1) / WF_BF * WF_BF;
     job->blocks = (int)ceil_div((long long)job->Jpad * job->Mpad, 256);
+    job->npos = 16;
     *floats = (size_t)16 * job->Jpad * job->Mpad;
     return true;
 }
