@@ -59,7 +59,7 @@ def cls(pred, phase=None):
     ks = [key for key in rows if pred(key[0]) and (phase is None or key[1] == phase)]
     # launches of the class = its main kernels (one per layer call); helpers (packing, transforms, finalize) only add bytes.
     # The three-kernel Winograd dW of a layer is counted through its dy transform (its GEMM is a conv_dw_dma launch).
-    main = [key for key in ks if "wino_dy_transform" in key[0] or not any(t in key[0] for t in ("finalize", "cache_prefetch", "pack_weights", "pack_kernel", "transform", "finish", "accumulate", "bn_stats", "bn_bwd_finalize"))]
+    main = [key for key in ks if "wino_dy_transform" in key[0] or not any(t in key[0] for t in ("finalize", "cache_prefetch", "pack_weights", "pack_kernel", "transform", "finish", "fixup", "accumulate", "bn_stats", "bn_bwd_finalize", "bnfold"))]
     launches = sum(rows[key]["launches_per_step"] for key in main)
     tot = sum(rows[key]["hbm_bytes_per_step"] for key in ks)
     return {"kernels": sorted(set(key[0][:100] for key in ks)), "phase": phase or "any", "launches_per_step": launches, "hbm_bytes_per_step": tot,
@@ -74,8 +74,8 @@ out = {
    "conv_dw": cls(lambda k: ("conv_dw" in k) and "wino" not in k),
    "conv_fwd": cls(lambda k: "conv_fwd_direct" in k or "conv_fwd_window" in k or "conv_fwd_stem" in k or "cache_prefetch" in k or "conv_igemm" in k or "conv_pack_weights" in k or "dma_pack" in k, "fwd"),
    "conv_dx": cls(lambda k: "conv_igemm" in k or "conv_pack_weights" in k or "dma_pack" in k or "conv_dx" in k, "bwd"),
-   "conv_fwd_winograd": cls(lambda k: "wino_fused_kernel" in k or "wino_pack_weights" in k or "wino_pack" in k, "fwd"),
-   "conv_dx_winograd": cls(lambda k: "wino_fused_kernel" in k or "wino_pack_weights" in k or "wino_pack" in k, "bwd"),
+   "conv_fwd_winograd": cls(lambda k: "wino_fused_kernel" in k or "wino43_kernel" in k or "wino_tail_fixup" in k or "wino43_tail_fixup" in k or "wino_pack_weights" in k or "wino_pack" in k or "wino43_pack" in k, "fwd"),
+   "conv_dx_winograd": cls(lambda k: "wino_fused_kernel" in k or "wino43_kernel" in k or "wino_tail_fixup" in k or "wino43_tail_fixup" in k or "wino_pack_weights" in k or "wino_pack" in k or "wino43_pack" in k, "bwd"),
    "conv_dw_winograd": cls(lambda k: "wino_dw" in k or "wino_input_transform" in k or "wino_dy_transform" in k),
    "bn_fwd": cls(lambda k: "BnApplyBody" in k or "bn_stats" in k or "StatsF" in k or "bn_fwd" in k, "fwd"),
    "bn_bwd": cls(lambda k: "BnBwd" in k or "bn_bwd" in k or "BwdSumsF" in k),

@@ -1,6 +1,6 @@
 #!/bin/bash
 # SQ counters of EVERY kernel of a bench.py step, aggregated per kernel name: vector-ALU issue share, LDS bank conflicts,
-# wait shares. One rocprofv3 --pmc pass per counter group. usage: sq_step.sh [workload]  -> gpurun_out/r04_sq_step_<workload>.txt
+# wait shares. One rocprofv3 --pmc pass per counter group. usage: sq_step.sh [workload]  -> gpurun_out/${ROUND:-r05}_sq_step_<workload>.txt
 WL=${1:-resnet18}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/sqstep_$WL; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
@@ -12,7 +12,7 @@ for G in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE" \
   i=$((i+1))
   timeout 400 rocprofv3 --kernel-trace --pmc $G --output-format csv -d $O/a$i -- python3 $R/bench.py --workload $WL --steps 2 --warmup 1 --no-cpu-baseline --no-side-workloads > $O/a$i.log 2>&1 || tail -3 $O/a$i.log
 done
-python3 - <<PY > $R/gpurun_out/r04_sq_step_$WL.txt
+python3 - <<PY > $R/gpurun_out/${ROUND:-r05}_sq_step_$WL.txt
 import csv, glob, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
@@ -38,4 +38,4 @@ for k in acc:
 for tot, k, n, d, valu, mfma, conf, wait, vpw in sorted(rows, reverse=True):
     print("%-88s %6d %9.1f %6.2f %6.2f %7.2f %8.2f %8.0f" % (k, n, d, valu, mfma, conf, wait, vpw))
 PY
-cat $R/gpurun_out/r04_sq_step_$WL.txt
+cat $R/gpurun_out/${ROUND:-r05}_sq_step_$WL.txt
