@@ -164,7 +164,11 @@ __global__ __launch_bounds__(64 * W4_NW, 3) void wino43_kernel(const Wino43Args 
             const int ih = 4 * th - 1 + i;
             const bool row_ok = tile_ok && (unsigned)ih < (unsigned)a.H;
             const unsigned row = vbase + (unsigned)i * row_bytes;
+#ifdef W43_ABL_HITLOAD   // timing only: the same instructions against one cache-resident kilobyte
+            const buf_f32x4 v = buffer_load_f32x4(rs_src, (int)(row_ok ? (unsigned)lane * 16u + (unsigned)i * 1024u : kOOB), 0, 0);
+#else
             const buf_f32x4 v = buffer_load_f32x4(rs_src, (int)(row_ok ? row : kOOB), (int)soff, 0);
+#endif
             p[i][0] = v[0];
             p[i][1] = (RAG && ncols < 2) ? 0.f : v[1];
             p[i][2] = (RAG && ncols < 3) ? 0.f : v[2];

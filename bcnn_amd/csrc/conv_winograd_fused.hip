@@ -1193,14 +1193,15 @@ bool conv_backward_data_winograd_fused(const float* w, const float* dy, float* d
 // dw in a fixed order (deterministic; keeps the `+=` onto the momentum carry, bcnn_conv_layer.c:547-553).
 // =============================================================================================================
 constexpr int WD_KT = 8;                 // tiles per chunk
-// LDS rows are the 8 tiles of a chunk, unpadded, with the tile index XOR-swizzled by the channel: element (xi, ch, t)
-// sits at (xi * 64 + ch) * 8 + (t ^ 2 * ((ch >> 3) & 3)). Both access shapes then touch 64 different banks: the transform's
-// writes (a wave's lanes = 8 tiles x 8 consecutive channels: the swizzle is wave-uniform, ch * 8 + t covers 64 floats) and
-// the MFMA fragment reads (lanes = 32 consecutive channels x 2 tiles 2 ks, 2 ks + 1: the four channels that share
-// ch mod 8 differ in (ch >> 3) & 3 and so in bits 1-2 of their swizzled tile). The padded 9-float rows of round 3 were
-// conflict-free for the reads of ONE half-wave only: 25 of the 32 lane pairs (l, l + 32) met in a bank (9 (k - j) = 1 mod 64
-// has the solution k = j - 7), which rocprofv3 counted as bank conflicts in 33 % of the LDS-active cycles; and they took
-// 147 KB where this takes 128.
+// LDS rows are the 8 tiles of a chunk, unpadded, with the tile index XOR-swizzled by the channel: element (xi, ch, t) sits
+// at (xi * 64 + ch) * 8 + (t ^ swz(ch)), swz(ch) = 2 * ((ch >> 3) & 3) + ((ch >> 2) & 1). ds_read_b32 / ds_write_b32 are
+// serviced per 32-lane half with bank = (address / 4) mod 32 (MI355X_MICROARCH.md, LDS): the transform's writes (a half-wave =
+// 8 tiles x 4 consecutive channels with one value of (ch >> 2) & 1 and of (ch >> 3) & 3: ch * 8 + t' covers 32 consecutive
+// floats) and the MFMA fragment reads (a half-wave = channels l31 = a + 8 b, one tile 2 ks + lhi: bank 8 (a & 3) + (t ^ swz),
+// and the eight combinations of (a >> 2, b) give eight different swz) both touch 32 different banks. Round 4's swizzle
+// (2 * ((ch >> 3) & 3) alone, reasoned on 64 banks) left channels a and a + 4 of a fragment read on one bank: the 2-way
+// conflict rocprofv3 kept counting as 33 % of the kernel's LDS cycles (profiles/r04_sq_step_resnet18.txt). The padded 9-float
+// rows of round 3 took 147 KB where this takes 128.
 constexpr int WD_ROW = WD_KT;            // LDS row: the chunk's 8 tiles
 constexpr int WD_OP = 16 * 64 * WD_ROW;  // floats per operand and stage
 
@@ -1330,7 +1331,7 @@ __global__ __launch_bounds__(512, 2) void wino_dw_fused_kernel(const WinoDwArgs 
     };
     auto write_items = [&](int stage) {
         assemble();
-        float* pm = lds + stage * 2 * WD_OP + ch * WD_ROW + (tl ^ (2 * (wid & 3)));  // (ch >> 3) & 3 == wid & 3
+        float* pm = lds + stage * 2 * WD_OP + ch * WD_ROW + (tl ^ (2 * (wid & 3) + lhi));  // (ch >> 3) & 3 == wid & 3, (ch >> 2) & 1 == lhi
         float* pv = pm + WD_OP;
         // dM = A g A^T, A = [1 0; 1 1; 1 -1; 0 -1]
         float q[4][2];
@@ -1382,7 +1383,7 @@ __global__ __launch_bounds__(512, 2) void wino_dw_fused_kernel(const WinoDwArgs 
     // has MFMAs to issue (the arrangement of wino_fused_kernel). The items a wave transforms in chunk kc (for chunk kc + 1)
     // were requested during chunk kc - 1, right after the previous transform freed the registers: a whole chunk of lead.
     const bool early = wid < 4;
-    const unsigned rd0 = (unsigned)(((2 * wid) * 64 + l31) * WD_ROW + lhi + 2 * ((l31 >> 3) & 3));  // fragment reads, see WD_ROW
+    const unsigned rd0 = (unsigned)(((2 * wid) * 64 + l31) * WD_ROW + (lhi ^ ((l31 >> 2) & 1)) + 2 * ((l31 >> 3) & 3));  // fragment reads, see WD_ROW
     if (nchunks > 0) {
         load_items();
         write_items(0);
