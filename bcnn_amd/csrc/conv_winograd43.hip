@@ -25,6 +25,11 @@
 #include "lds_dma.h"
 #include "wino43_pack.h"
 
+// Timing experiments (tools/exp/variant.sh NAME conv_winograd43 "-DW43_ABL_..."; normal builds define none of them; results
+// are wrong): W43_ABL_NOXFORM (no input transform arithmetic / V writes), NOEPI (no output transform, stores, statistics),
+// NOMFMA, NODMA (U slab only for chunk 0), NOBAR (no barrier in the K loop), NOLDSRD (no fragment reads), NOLOAD (patch requests
+// only for chunk 0), HITLOAD (the patch requests against one cache-resident kilobyte). DESIGN.md section 4.9 has the table.
+
 namespace bcnn_hip {
 
 constexpr int W4_BT = 32;   // tiles per workgroup unit
@@ -129,6 +134,7 @@ __global__ __launch_bounds__(64 * W4_NW, 3) void wino43_kernel(const Wino43Args 
     int kb = 0, nchunks = nch, slot = -1, m0 = 0, tb = 0, th = 0, ncols = 4, nrows = 4;
     bool tile_ok = false, pad_l = false, pad_r = false, edge = false;
     unsigned vbase = 0, edge_delta = 0, o00 = kOOB;
+    unsigned v_top = kOOB, v_mid = kOOB, v_bot = kOOB, e_top = kOOB, e_mid = kOOB, e_bot = kOOB;  // !RAG: per-item row offsets
     auto start_item = [&](int it) {
         int unit;
         if (it < nreg) { unit = (int)blockIdx.x + it * (int)gridDim.x; kb = 0; nchunks = nch; slot = -1; }
@@ -151,6 +157,16 @@ __global__ __launch_bounds__(64 * W4_NW, 3) void wino43_kernel(const Wino43Args 
         const bool edge_l = l31 == 0 && !pad_l, edge_r = l31 == 31 && !pad_r;  // neighbour column not in a neighbouring lane
         edge = edge_l || edge_r;
         edge_delta = edge_l ? (unsigned)-4 : 16u;
+        if (!RAG) {  // rows 1..4 of a whole tile always exist; rows 0 and 5 are padding at the top / bottom tile row.
+            // The row step rides in the scalar offset (the range check sees the vector offset only), so a chunk's twelve
+            // requests cost no address arithmetic in the transforming waves' serial section.
+            const unsigned r1 = vbase + row_bytes;
+            const bool top = tile_ok && th > 0, bot = tile_ok && 4 * th + 4 < a.H;
+            v_mid = tile_ok ? r1 : kOOB;  v_top = top ? vbase : kOOB;  v_bot = bot ? r1 : kOOB;
+            e_mid = tile_ok && edge ? r1 + edge_delta : kOOB;
+            e_top = top && edge ? vbase + edge_delta : kOOB;
+            e_bot = bot && edge ? r1 + edge_delta : kOOB;
+        }
         o00 = tile_ok ? (n * (unsigned)a.M * (unsigned)HW + (unsigned)(4 * th * a.W + 4 * tw)) * 4u : kOOB;
         ncols = a.W - 4 * tw < 4 ? a.W - 4 * tw : 4;  // RAG: own columns / rows that exist
         nrows = a.H - 4 * th < 4 ? a.H - 4 * th : 4;
@@ -158,9 +174,21 @@ __global__ __launch_bounds__(64 * W4_NW, 3) void wino43_kernel(const Wino43Args 
 
     float p[6][4], e[6];  // a patch: own columns and the edge lanes' neighbour column (0.0 elsewhere)
     auto load_patch = [&](int kc) {
+#ifdef W43_ABL_NOLOAD
+        if (kc > 0) return;
+#endif
         const unsigned soff = (unsigned)((kb + kc) * W4_KC + 2 * wid) * (unsigned)HW * 4u;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
+#if !defined(W43_ABL_HITLOAD) && !defined(W43_ABL_ROWADDR)   // ROWADDR: timing only, the per-chunk address arithmetic back
+            if (!RAG) {
+                const unsigned so = i == 0 ? soff : soff + (unsigned)(i - 1) * row_bytes;
+                const buf_f32x4 v = buffer_load_f32x4(rs_src, (int)(i == 0 ? v_top : i == 5 ? v_bot : v_mid), (int)so, 0);
+                p[i][0] = v[0]; p[i][1] = v[1]; p[i][2] = v[2]; p[i][3] = v[3];
+                e[i] = buffer_load_f32(rs_src, (int)(i == 0 ? e_top : i == 5 ? e_bot : e_mid), (int)so, 0);
+                continue;
+            }
+#endif
             const int ih = 4 * th - 1 + i;
             const bool row_ok = tile_ok && (unsigned)ih < (unsigned)a.H;
             const unsigned row = vbase + (unsigned)i * row_bytes;
@@ -177,6 +205,9 @@ __global__ __launch_bounds__(64 * W4_NW, 3) void wino43_kernel(const Wino43Args 
         }
     };
     auto dma_u = [&](int kc, int stage) {  // this wave's positions: W4_PW x (8 rows of 32 floats)
+#ifdef W43_ABL_NODMA
+        if (kc > 0) return;
+#endif
 #pragma unroll
         for (int q = 0; q < W4_PW; ++q) {
             const int xi = W4_PW * wid + q;
@@ -185,6 +216,15 @@ __global__ __launch_bounds__(64 * W4_NW, 3) void wino43_kernel(const Wino43Args 
         }
     };
     auto write_v = [&](int stage) {  // B^T d B -> V[xi][2 wid + lhi][l31]
+#ifdef W43_ABL_NOXFORM
+        {
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) sum += p[i][0] + p[i][1] + p[i][2] + p[i][3] + e[i];
+            if (sum == 123.456f) lds[stage * W4_STAGE + W4_OP + lane] = sum;
+            return;
+        }
+#endif
         float tt[6][6];  // columns first: tt[.][j] = B^T d[.][j]
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
@@ -232,7 +272,10 @@ __global__ __launch_bounds__(64 * W4_NW, 3) void wino43_kernel(const Wino43Args 
             const int cur = kc & 1;
             // U(kc) is older than the 12 patch requests of chunk kc + 1, which may fly on
             if (xform && kc + 1 < nchunks) dma_wait_n<12>(); else dma_wait();
-            lds_barrier();  // stage cur holds chunk kc; the other stage's readers (chunk kc - 1, or the epilogue before) are done
+#ifndef W43_ABL_NOBAR
+            lds_barrier();  // stage cur holds chunk kc;
+#endif
+            // the other stage's readers (chunk kc - 1, or the epilogue before) are done
             if (kc + 1 < nchunks) dma_u(kc + 1, cur ^ 1);
             __builtin_amdgcn_sched_barrier(0);
             const float* us = lds + cur * W4_STAGE + (W4_PW * wid) * W4_KC * 32 + lhi * 32 + l31;
@@ -242,8 +285,12 @@ __global__ __launch_bounds__(64 * W4_NW, 3) void wino43_kernel(const Wino43Args 
                 float af[W4_PW], bf[W4_PW];
 #pragma unroll
                 for (int j = 0; j < W4_PW; ++j) {
+#ifdef W43_ABL_NOLDSRD
+                    af[j] = (float)(kc + j); bf[j] = (float)(ks + j);
+#else
                     af[j] = us[(j * W4_KC + 2 * ks) * 32];
                     bf[j] = vs[(j * W4_KC + 2 * ks) * 32];
+#endif
                 }
                 if (kc == 0 && ks == 0) {
                     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -251,7 +298,11 @@ __global__ __launch_bounds__(64 * W4_NW, 3) void wino43_kernel(const Wino43Args 
                     for (int j = 0; j < W4_PW; ++j) acc[j] = mfma32(af[j], bf[j], zero);
                 } else {
 #pragma unroll
+#ifndef W43_ABL_NOMFMA
                     for (int j = 0; j < W4_PW; ++j) acc[j] = mfma32(af[j], bf[j], acc[j]);
+#else
+                    for (int j = 0; j < W4_PW; ++j) acc[j][0] += af[j] * bf[j];
+#endif
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -269,6 +320,22 @@ __global__ __launch_bounds__(64 * W4_NW, 3) void wino43_kernel(const Wino43Args 
         const bool e_tile_ok = tile_ok;
         const bool has_next = it + 1 < nitems;
         if (has_next) start_item(it + 1);
+#ifdef W43_ABL_NOEPI
+        {
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < W4_PW; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sum += acc[j][r];
+            if (sum == 123.456f) a.dst[0] = sum;
+            lds_barrier();
+            if (has_next) {
+                dma_u(0, 0);
+                if (xform) { load_patch(0); write_v(0); if (nchunks > 1) load_patch(1); }
+            }
+            continue;
+        }
+#endif
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph) {
             lds_barrier();  // ph 0: the K loop's last readers of both stages are done; ph 1: the first half's readers of S
