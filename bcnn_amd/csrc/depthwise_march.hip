@@ -20,11 +20,16 @@
 //   * results go straight from registers to global memory;
 //   * lanes of a wave that do not fit a row (64 mod W/V) idle; a wave holds 64 / (W/V) independent bands, which may lie in
 //     different planes, so small planes (14 x 14: nine per wave, 7 x 7 likewise) fill waves as well as large ones.
+// Round 5: every memory instruction is straight-line code on buffer descriptors (dwm_ld); a wave that kept its nine channels
+// and marched through several images of them as one band (constants fetched and sums flushed once per run instead of once per
+// 14 rows) was built and measured at 2 ... 16 images per wave, before and after that change: never faster (14 x 14 backward
+// 128 against 120 us), and removed again.
 // Tap order and the separate multiply / add roundings are the reference's (forward and data gradient: bit-exact); the
 // reductions (weight / bias gradient, batch-norm sums) are two-level in a fixed order: one partial per band, summed
 // across the lanes of a band through a per-wave LDS slab in lane order, then over bands in double by the finalize kernels.
 #include "bn_math.h"
 #include "depthwise.h"
+#include "lds_dma.h"
 
 #include <initializer_list>
 
@@ -44,6 +49,9 @@ namespace {
 #endif
 #ifndef DWM_BWD_PF_SMALL
 #define DWM_BWD_PF_SMALL 4  // backward, lanes of 2 / 1 columns: rows requested ahead
+#endif
+#ifndef DWM_BWD_PF_WIDE
+#define DWM_BWD_PF_WIDE 1  // backward, lanes of 4 columns: rows requested ahead
 #endif
 #ifndef DWM_ROWS
 #define DWM_ROWS 14  // rows a band marches (target; the plan evens bands out)
@@ -68,7 +76,7 @@ inline bool dwm_shape_ok(const DwShape& s) {
     if (s.N < 1 || s.C < 1 || s.H < 1 || s.W < 1) return false;
     const int V = dwm_width(s);
     if (V == 0 || s.W / V > 64) return false;
-    if ((long long)s.N * s.C * s.H * s.W >= 0x3fffffffLL) return false;  // byte offsets are 32-bit
+    if ((long long)s.N * s.C * s.H * s.W >= 0x1fffffffLL) return false;  // byte offsets below kOOB (2 GiB), lds_dma.h
     return true;
 }
 
@@ -88,6 +96,9 @@ inline DwmGeom dwm_plan(const DwShape& s) {
     g.bands = (long long)s.N * s.C * g.BPP;
     return g;
 }
+
+// slots per channel of the per-band partial sums
+inline int dwm_splits(const DwShape& s, const DwmGeom& g) { return s.N * g.BPP; }
 
 // Which band a lane group works on, and in which direction it marches. Planes cut into several bands (BPP > 1): the waves
 // come in pairs -- the even wave takes even bands and marches DOWN, the odd wave takes the odd bands of the same planes and
@@ -149,36 +160,49 @@ __device__ __forceinline__ float dwm_from(int addr, float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v)));
 }
 
-// V floats of a row. Addresses are a uniform base plus a 32-bit byte offset per lane (one add per row and stream).
+// V floats of a row, through raw buffer descriptors (lds_dma.h): a lane that must not read / write hands in an out-of-range
+// offset instead of sitting out a branch -- it gets 0.0, its store is dropped. That is not about the branch's cost: every
+// memory instruction under divergent control flow is given a skip branch by the compiler, and with a skipped request on some
+// path its waitcnt pass can no longer count how many requests are younger than the one it needs; it then waits for ALL of
+// them (`s_waitcnt vmcnt(0)`), which is what these kernels did in every step until round 5: rows "requested PF steps ahead"
+// were drained at the next use of any loaded value. Straight-line requests are counted (vmcnt(N)), the lead is real.
 template <int V>
 struct Vals {
     float v[V];
 };
+// 16-byte store: inline assembly carrying its own wait states (lds_dma.h explains why there is no intrinsic wrapper)
+__device__ __forceinline__ void buffer_store_f32x4(const buf_f32x4 v, rsrc_i4 rs, unsigned voff) {
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" : : "v"(v), "v"(voff), "s"(rs) : "memory");
+}
 template <int V>
-__device__ __forceinline__ Vals<V> dwm_ld(const float* base, unsigned byte_off, bool ok) {
+__device__ __forceinline__ Vals<V> dwm_ld(rsrc_i4 rs, unsigned byte_off, bool ok) {
     Vals<V> o;
-#pragma unroll
-    for (int i = 0; i < V; ++i) o.v[i] = 0.f;
-    if (ok) {
-        const char* p = reinterpret_cast<const char*>(base) + byte_off;
-        if constexpr (V == 4) {
-            const float4 t = *reinterpret_cast<const float4*>(p);
-            o.v[0] = t.x; o.v[1] = t.y; o.v[2] = t.z; o.v[3] = t.w;
-        } else if constexpr (V == 2) {
-            const float2 t = *reinterpret_cast<const float2*>(p);
-            o.v[0] = t.x; o.v[1] = t.y;
-        } else {
-            o.v[0] = *reinterpret_cast<const float*>(p);
-        }
+    const int vo = (int)(ok ? byte_off : kOOB);
+    if constexpr (V == 4) {
+        const buf_f32x4 t = buffer_load_f32x4(rs, vo, 0, 0);
+        o.v[0] = t[0]; o.v[1] = t[1]; o.v[2] = t[2]; o.v[3] = t[3];
+    } else if constexpr (V == 2) {
+        const buf_f32x2 t = buffer_load_f32x2(rs, vo, 0, 0);
+        o.v[0] = t[0]; o.v[1] = t[1];
+    } else {
+        o.v[0] = buffer_load_f32(rs, vo, 0, 0);
     }
     return o;
 }
+// V == 0 (compile-time "never"): nothing requested
 template <int V>
-__device__ __forceinline__ void dwm_st(float* base, unsigned byte_off, const Vals<V>& o) {
-    char* p = reinterpret_cast<char*>(base) + byte_off;
-    if constexpr (V == 4) *reinterpret_cast<float4*>(p) = make_float4(o.v[0], o.v[1], o.v[2], o.v[3]);
-    else if constexpr (V == 2) *reinterpret_cast<float2*>(p) = make_float2(o.v[0], o.v[1]);
-    else *reinterpret_cast<float*>(p) = o.v[0];
+__device__ __forceinline__ Vals<V> dwm_zero() {
+    Vals<V> o;
+#pragma unroll
+    for (int i = 0; i < V; ++i) o.v[i] = 0.f;
+    return o;
+}
+template <int V>
+__device__ __forceinline__ void dwm_st(rsrc_i4 rs, unsigned byte_off, const Vals<V>& o, bool ok) {
+    const unsigned vo = ok ? byte_off : kOOB;
+    if constexpr (V == 4) buffer_store_f32x4(buf_f32x4{o.v[0], o.v[1], o.v[2], o.v[3]}, rs, vo);
+    else if constexpr (V == 2) buffer_store_f32x2(buf_f32x2{o.v[0], o.v[1]}, rs, (int)vo, 0, 0);
+    else buffer_store_f32(o.v[0], rs, (int)vo, 0, 0);
 }
 
 // a row of the window: the lane's V values between the neighbours' (index 0 = left neighbour ... V + 1 = right neighbour)
@@ -192,6 +216,9 @@ __device__ __forceinline__ Row<V> dwm_row(const Vals<V>& x, const DwmLane& m) {
 #pragma unroll
     for (int i = 0; i < V; ++i) r.v[1 + i] = x.v[i];
     r.v[0] = r.v[V + 1] = 0.f;
+#ifdef DWM_ABL_NOPERM   // timing only (tools/exp/variant.sh NAME depthwise_march "-DDWM_ABL_..."): wrong results
+    return r;
+#endif
     if (LEFT) {
         const float l = dwm_from(m.addr_l, x.v[V - 1]);
         r.v[0] = m.first ? 0.f : l;
@@ -224,6 +251,9 @@ __device__ __forceinline__ DwmBnInC dwm_bnin_consts(const DwBnIn& in, int c) {
     return k;
 }
 __device__ __forceinline__ float dwm_bnin(float x, const DwmBnInC& k, int act) {
+#ifdef DWM_ABL_NOBNIN
+    return x;
+#endif
     float v = bn_div(__fsub_rn(x, k.mean), k.rs);
     v = __fmul_rn(v, k.sc);
     if (k.any_sc0 && k.sc0) v = 0.f;  // wave-uniform first: no channel of a trained net has a scale of exactly 0
@@ -268,7 +298,8 @@ struct DwmFwdArgs {
     float* y;
     float* stats;  // NULL: none; [C][splits][2], splits = N * BPP
     DwBnIn in;
-    int C, H, W, OH, OW, act;
+    int N, C, H, W, OH, OW, act;
+    unsigned xbytes, ybytes;  // sizes of x and y (buffer descriptors)
     DwmGeom g;
 };
 
@@ -296,8 +327,9 @@ __global__ __launch_bounds__(256) void dwm_fwd_kernel(const DwmFwdArgs a) {
     unsigned yo = (((unsigned)m.p * a.OH + rf) * a.OW + m.cg * OV) * 4u;
     const unsigned ystep = m.up ? 0u - yrow : yrow;
     float s1 = 0.f, s2 = 0.f;
+    const rsrc_i4 rx = make_rsrc(a.x, a.xbytes), ry = make_rsrc(a.y, a.ybytes);
     auto in_row = [&](int r) -> bool { return m.on && r >= 0 && r < a.H; };
-    auto fetch = [&](int r) -> Vals<V> { return dwm_ld<V>(a.x, xbase + (unsigned)r * xrow, in_row(r)); };
+    auto fetch = [&](int r) -> Vals<V> { return dwm_ld<V>(rx, xbase + (unsigned)r * xrow, in_row(r)); };
     auto prep = [&](Vals<V> v, int r) -> Row<V> {
         if (BNIN && in_row(r)) v = dwm_bnin_v<V>(v, kin, in_act);
         return dwm_row<V, true, S == 1>(v, m);
@@ -317,8 +349,8 @@ __global__ __launch_bounds__(256) void dwm_fwd_kernel(const DwmFwdArgs a) {
             for (int kw = 0; kw < 3; ++kw) acc = __fadd_rn(acc, __fmul_rn(w[6 + kw], Cr.v[S * c + kw]));
             o.v[c] = finish(acc);
         }
+        dwm_st<OV>(ry, yo, o, valid);
         if (valid) {
-            dwm_st<OV>(a.y, yo, o);
 #pragma unroll
             for (int c = 0; c < OV; ++c) {
                 s1 += o.v[c];
@@ -339,13 +371,12 @@ __global__ __launch_bounds__(256) void dwm_fwd_kernel(const DwmFwdArgs a) {
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
                 const int k = i0 + u;
-                const Vals<V> cur = ring[u];
-                ring[u] = fetch(step_row(k + 1 + PF));
-                const Row<V> Nx = prep(cur, step_row(k + 1));
+                const Row<V> Nx = prep(ring[u], step_row(k + 1));
                 if (m.up) emit(Nx, Q, P, k < nrows);
                 else emit(P, Q, Nx, k < nrows);
                 P = Q;
                 Q = Nx;
+                ring[u] = fetch(step_row(k + 1 + PF));  // last: into the registers of the row just used
             }
         }
     } else {
@@ -364,13 +395,12 @@ __global__ __launch_bounds__(256) void dwm_fwd_kernel(const DwmFwdArgs a) {
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
                 const int k = i0 + u;
-                const Vals<V> c0 = ring0[u], c1 = ring1[u];
-                ring0[u] = fetch(mid_row(k + PF));
-                ring1[u] = fetch(far_row(k + PF));
-                const Row<V> Md = prep(c0, mid_row(k)), Fr = prep(c1, far_row(k));
+                const Row<V> Md = prep(ring0[u], mid_row(k)), Fr = prep(ring1[u], far_row(k));
                 if (m.up) emit(Fr, Md, Nr, k < nrows);
                 else emit(Nr, Md, Fr, k < nrows);
                 Nr = Fr;
+                ring0[u] = fetch(mid_row(k + PF));
+                ring1[u] = fetch(far_row(k + PF));
             }
         }
     }
@@ -403,7 +433,8 @@ struct DwmBwdArgs {
     DwBnBwd bn;
     DwBnIn in;
     float fM, rfM;
-    int C, H, W, OH, OW, act, overwrite, write_back;
+    int N, C, H, W, OH, OW, act, overwrite, write_back;
+    unsigned xbytes, ybytes;  // sizes of x / dx and of y / dy / dz (buffer descriptors)
     DwmGeom g;
 };
 
@@ -416,7 +447,10 @@ struct DwmBnC {
 // PF: rows requested ahead of their use. 1 where a lane's rows are 16 bytes wide (the window already fills the register
 // budget of three waves per SIMD); small planes -- whole 14 x 14 / 7 x 7 planes per band, 8- and 4-byte rows, a few hundred
 // vector instructions per step -- were latency bound at 1 (waves 78 % waiting, 2.7 TB/s): they request PF = 4 rows ahead.
-template <int S, int V, bool BN, bool BNIN, bool RELU, int PF>
+// OVW: dx is written, not added to (the executor's no-fill mode), compiled in: as a run-time flag the skipped read of dx still
+// left its `s_waitcnt vmcnt(0)` in every step, which drained the rows requested ahead -- the kernels ran with no lead at all
+// whatever PF said (round 5; found in the ISA after no ablation of arithmetic, exchanges or stores moved the time).
+template <int S, int V, bool BN, bool BNIN, bool RELU, int PF, bool OVW>
 __global__ __launch_bounds__(256, V == 4 ? DWM_BWD_WAVES : DWM_BWD_WAVES_SMALL) void dwm_bwd_kernel(const DwmBwdArgs a) {
     __shared__ float red[4][kDwmPart * kSlab];
     const int act = RELU ? BCNN_HIP_ACT_RELU : a.act, in_act = RELU ? BCNN_HIP_ACT_RELU : a.in.act;
@@ -444,6 +478,8 @@ __global__ __launch_bounds__(256, V == 4 ? DWM_BWD_WAVES : DWM_BWD_WAVES_SMALL) 
     const unsigned xrow = (unsigned)a.W * 4u, grow = (unsigned)a.OW * 4u;  // bytes per row
     const unsigned xbase = ((unsigned)m.p * a.H * a.W + m.cg * V) * 4u, gbase = ((unsigned)m.p * a.OH * a.OW + m.cg * GV) * 4u;
     const float* gsrc = BN ? a.bn.dz : a.dy;
+    const rsrc_i4 rx = make_rsrc(a.x, a.xbytes), rdx = make_rsrc(a.dx, a.xbytes), rg = make_rsrc(gsrc, a.ybytes),
+                  ryy = make_rsrc(a.y, a.ybytes), rdy = make_rsrc(a.dy, a.ybytes);
     const bool need_y = BN || act != BCNN_HIP_ACT_NONE;
     const bool wb = !BN && a.write_back && act != BCNN_HIP_ACT_NONE;
     // gradient rows [r0, r1) are the band's own; stride 1: the same rows of x / dx, stride 2: x / dx rows [2 r0, min(2 r1, H))
@@ -456,6 +492,9 @@ __global__ __launch_bounds__(256, V == 4 ? DWM_BWD_WAVES : DWM_BWD_WAVES_SMALL) 
     // bn_bwd_one of bn_math.h (bcnn_batchnorm_layer.c:292-296) with the per-channel constants folded, then act'(y)
     auto gval = [&](float gin, float yv) -> float {
         float g = gin;
+#ifdef DWM_ABL_NOGVAL
+        return g + yv;
+#endif
         if (BN) {
             g = __fmul_rn(g, kb.sc);
             if (kb.any_sc0 && kb.sc0) g = 0.f;
@@ -475,19 +514,20 @@ __global__ __launch_bounds__(256, V == 4 ? DWM_BWD_WAVES : DWM_BWD_WAVES_SMALL) 
         Raw q;
         const bool ok = g_row_ok(r);
         const unsigned off = gbase + (unsigned)r * grow;
-        q.g = dwm_ld<GV>(gsrc, off, ok);
-        q.y = dwm_ld<GV>(a.y, off, ok && need_y);
+        q.g = dwm_ld<GV>(rg, off, ok);
+        q.y = dwm_ld<GV>(ryy, off, ok && need_y);
         return q;
     };
     auto make_g = [&](const Raw& q, int r) -> Row<GV> {
         Vals<GV> g;
 #pragma unroll
         for (int i = 0; i < GV; ++i) g.v[i] = 0.f;
-        if (g_row_ok(r)) {
+        const bool ok = g_row_ok(r);
+        if (ok) {
 #pragma unroll
             for (int i = 0; i < GV; ++i) g.v[i] = gval(q.g.v[i], q.y.v[i]);
-            if (wb && r >= r0 && r < r1) dwm_st<GV>(a.dy, gbase + (unsigned)r * grow, g);
         }
+        if (!BN) dwm_st<GV>(rdy, gbase + (unsigned)r * grow, g, ok && wb && r >= r0 && r < r1);
         return dwm_row<GV, S == 1, true>(g, m);
     };
     // the sums of the producer's batch-norm backward over what this lane just stored
@@ -506,22 +546,10 @@ __global__ __launch_bounds__(256, V == 4 ? DWM_BWD_WAVES : DWM_BWD_WAVES_SMALL) 
         // the rows of x / dx the band owns, one per step; A / B / Cr of `body`: the gradient rows above, at and below it
         unsigned xo = xbase + (unsigned)rf * xrow;
         const unsigned xstep = m.up ? 0u - xrow : xrow;
-        auto body = [&](const Row<V>& A, const Row<V>& B, const Row<V>& Cr, const Vals<V>& xraw) {
-            Vals<V> xv = xraw;
-            if (BNIN) xv = dwm_bnin_v<V>(xraw, kin, in_act);
-            // weight gradient from the rows of x this band owns: x[r][j] meets g[r - kh + 1][j - kw + 1]
-#pragma unroll
-            for (int c = 0; c < V; ++c) {
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    acc[0 + kw] = __fmaf_rn(xv.v[c], Cr.v[c + 2 - kw], acc[0 + kw]);
-                    acc[3 + kw] = __fmaf_rn(xv.v[c], B.v[c + 2 - kw], acc[3 + kw]);
-                    acc[6 + kw] = __fmaf_rn(xv.v[c], A.v[c + 2 - kw], acc[6 + kw]);
-                }
-                acc[9] += B.v[c + 1];
-            }
+        // `valid`: the lane has a row at this step (memory instructions stay outside divergent control flow, see dwm_ld)
+        auto body = [&](const Row<V>& A, const Row<V>& B, const Row<V>& Cr, const Vals<V>& xraw, bool valid) {
             // data gradient, taps in the reference's scatter order: descending kh, descending kw
-            Vals<V> d = dwm_ld<V>(a.dx, xo, !a.overwrite);
+            Vals<V> d = OVW ? dwm_zero<V>() : dwm_ld<V>(rdx, xo, valid);
 #pragma unroll
             for (int c = 0; c < V; ++c) {
                 float v = d.v[c];
@@ -533,8 +561,32 @@ __global__ __launch_bounds__(256, V == 4 ? DWM_BWD_WAVES : DWM_BWD_WAVES_SMALL) 
                 for (int kw = 2; kw >= 0; --kw) v = __fadd_rn(v, __fmul_rn(w[0 + kw], Cr.v[c + 2 - kw]));
                 d.v[c] = v;
             }
-            dwm_st<V>(a.dx, xo, d);
+#ifdef DWM_ABL_NOSTORE
+            dwm_st<V>(rdx, xo, d, valid && d.v[0] == 123.456f);
+#else
+            dwm_st<V>(rdx, xo, d, valid);
+#endif
+            if (!valid) return;
+            Vals<V> xv = xraw;
+            if (BNIN) xv = dwm_bnin_v<V>(xraw, kin, in_act);
+            // weight gradient from the rows of x this band owns: x[r][j] meets g[r - kh + 1][j - kw + 1]
+#ifdef DWM_ABL_NODW
+            acc[0] += xv.v[0];
+#else
+#pragma unroll
+            for (int c = 0; c < V; ++c) {
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    acc[0 + kw] = __fmaf_rn(xv.v[c], Cr.v[c + 2 - kw], acc[0 + kw]);
+                    acc[3 + kw] = __fmaf_rn(xv.v[c], B.v[c + 2 - kw], acc[3 + kw]);
+                    acc[6 + kw] = __fmaf_rn(xv.v[c], A.v[c + 2 - kw], acc[6 + kw]);
+                }
+                acc[9] += B.v[c + 1];
+            }
+#endif
+#ifndef DWM_ABL_NOSUMS
             if (sums) in_sums(d, xv, xraw);
+#endif
         };
         auto step_row = [&](int st) -> int { return st <= nrows ? rf + dir * st : -1; };
         Row<V> P = make_g(fetch_g(rf - dir), rf - dir), Q = make_g(fetch_g(step_row(0)), step_row(0));
@@ -543,21 +595,19 @@ __global__ __launch_bounds__(256, V == 4 ? DWM_BWD_WAVES : DWM_BWD_WAVES_SMALL) 
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
             gring[u] = fetch_g(step_row(1 + u));
-            xring[u] = dwm_ld<V>(a.x, xo + (unsigned)u * xstep, m.on && u < nrows);
+            xring[u] = dwm_ld<V>(rx, xo + (unsigned)u * xstep, m.on && u < nrows);
         }
         for (int k0 = 0; k0 < a.g.len; k0 += PF) {
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
                 const int k = k0 + u;
-                const Raw gc = gring[u];
-                const Vals<V> xraw = xring[u];
+                // a slot's next request goes out right AFTER its last use: the rows just used are dead, the new ones land in
+                // the same registers and nothing has to be copied (and waited for) at the loop's back edge
+                const Row<V> Nx = make_g(gring[u], step_row(k + 1));
                 gring[u] = fetch_g(step_row(k + 1 + PF));
-                xring[u] = dwm_ld<V>(a.x, xo + (unsigned)PF * xstep, m.on && k + PF < nrows);
-                const Row<V> Nx = make_g(gc, step_row(k + 1));
-                if (k < nrows) {
-                    if (m.up) body(Nx, Q, P, xraw);
-                    else body(P, Q, Nx, xraw);
-                }
+                if (m.up) body(Nx, Q, P, xring[u], k < nrows);
+                else body(P, Q, Nx, xring[u], k < nrows);
+                xring[u] = dwm_ld<V>(rx, xo + (unsigned)PF * xstep, m.on && k + PF < nrows);
                 xo += xstep;
                 P = Q;
                 Q = Nx;
@@ -569,14 +619,28 @@ __global__ __launch_bounds__(256, V == 4 ? DWM_BWD_WAVES : DWM_BWD_WAVES_SMALL) 
         // row is r + 1 and r is carried, marching up r is new and r + 1 carried
         unsigned xo = xbase + (unsigned)(2 * rf) * xrow;
         const unsigned xstep = m.up ? 0u - 2u * xrow : 2u * xrow;
-        auto body = [&](const Row<GV>& Bg, const Row<GV>& Cg, const Vals<V>& xr0, const Vals<V>& xr1, bool odd_ok) {
-            Vals<V> x0 = xr0, x1 = xr1;
-            if (BNIN) x0 = dwm_bnin_v<V>(xr0, kin, in_act);
-            if (BNIN && odd_ok) x1 = dwm_bnin_v<V>(xr1, kin, in_act);
-            Vals<V> d0 = dwm_ld<V>(a.dx, xo, !a.overwrite), d1 = dwm_ld<V>(a.dx, xo + xrow, !a.overwrite && odd_ok);
+        // `valid` / `odd_ok`: the lane has rows 2r / 2r + 1 at this step (memory instructions stay outside divergent control flow)
+        auto body = [&](const Row<GV>& Bg, const Row<GV>& Cg, const Vals<V>& xr0, const Vals<V>& xr1, bool valid, bool odd_ok) {
+            Vals<V> d0 = OVW ? dwm_zero<V>() : dwm_ld<V>(rdx, xo, valid), d1 = OVW ? dwm_zero<V>() : dwm_ld<V>(rdx, xo + xrow, odd_ok);
 #pragma unroll
             for (int j = 0; j < GV; ++j) {
                 // the 2 x 2 input block under gradient column j: g00 = g[r][j], g01 = g[r][j + 1], g10 / g11 one row down
+                const float g00 = Bg.v[1 + j], g01 = Bg.v[2 + j], g10 = Cg.v[1 + j], g11 = Cg.v[2 + j];
+                // data gradient: the four parity classes meet 1, 2, 2 and 4 taps, in the reference's scatter order
+                d0.v[2 * j] = __fadd_rn(d0.v[2 * j], __fmul_rn(w[4], g00));
+                d0.v[2 * j + 1] = __fadd_rn(__fadd_rn(d0.v[2 * j + 1], __fmul_rn(w[5], g00)), __fmul_rn(w[3], g01));
+                d1.v[2 * j] = __fadd_rn(__fadd_rn(d1.v[2 * j], __fmul_rn(w[7], g00)), __fmul_rn(w[1], g10));
+                d1.v[2 * j + 1] = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(d1.v[2 * j + 1], __fmul_rn(w[8], g00)),
+                                                                __fmul_rn(w[6], g01)), __fmul_rn(w[2], g10)), __fmul_rn(w[0], g11));
+            }
+            dwm_st<V>(rdx, xo, d0, valid);
+            dwm_st<V>(rdx, xo + xrow, d1, odd_ok);
+            if (!valid) return;
+            Vals<V> x0 = xr0, x1 = xr1;
+            if (BNIN) x0 = dwm_bnin_v<V>(xr0, kin, in_act);
+            if (BNIN && odd_ok) x1 = dwm_bnin_v<V>(xr1, kin, in_act);
+#pragma unroll
+            for (int j = 0; j < GV; ++j) {
                 const float g00 = Bg.v[1 + j], g01 = Bg.v[2 + j], g10 = Cg.v[1 + j], g11 = Cg.v[2 + j];
                 const float xe0 = x0.v[2 * j], xe1 = x0.v[2 * j + 1], xo0 = x1.v[2 * j], xo1 = x1.v[2 * j + 1];
                 // weight gradient from the owned x: even row meets kh = 1 of g[r]; odd row kh = 2 of g[r] and kh = 0 of
@@ -591,15 +655,7 @@ __global__ __launch_bounds__(256, V == 4 ? DWM_BWD_WAVES : DWM_BWD_WAVES_SMALL) 
                 acc[0] = __fmaf_rn(xo1, g11, acc[0]);
                 acc[2] = __fmaf_rn(xo1, g10, acc[2]);
                 acc[9] += g00;
-                // data gradient: the four parity classes meet 1, 2, 2 and 4 taps, in the reference's scatter order
-                d0.v[2 * j] = __fadd_rn(d0.v[2 * j], __fmul_rn(w[4], g00));
-                d0.v[2 * j + 1] = __fadd_rn(__fadd_rn(d0.v[2 * j + 1], __fmul_rn(w[5], g00)), __fmul_rn(w[3], g01));
-                d1.v[2 * j] = __fadd_rn(__fadd_rn(d1.v[2 * j], __fmul_rn(w[7], g00)), __fmul_rn(w[1], g10));
-                d1.v[2 * j + 1] = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(d1.v[2 * j + 1], __fmul_rn(w[8], g00)),
-                                                                __fmul_rn(w[6], g01)), __fmul_rn(w[2], g10)), __fmul_rn(w[0], g11));
             }
-            dwm_st<V>(a.dx, xo, d0);
-            if (odd_ok) dwm_st<V>(a.dx, xo + xrow, d1);
             if (sums) {
                 in_sums(d0, x0, xr0);
                 if (odd_ok) in_sums(d1, x1, xr1);
@@ -614,25 +670,22 @@ __global__ __launch_bounds__(256, V == 4 ? DWM_BWD_WAVES : DWM_BWD_WAVES_SMALL) 
         for (int u = 0; u < PF; ++u) {
             gring[u] = fetch_g(new_row(u));
             const bool on = m.on && u < nrows;
-            xring0[u] = dwm_ld<V>(a.x, xo + (unsigned)u * xstep, on);
-            xring1[u] = dwm_ld<V>(a.x, xo + (unsigned)u * xstep + xrow, on && 2 * (rf + dir * u) + 1 < a.H);
+            xring0[u] = dwm_ld<V>(rx, xo + (unsigned)u * xstep, on);
+            xring1[u] = dwm_ld<V>(rx, xo + (unsigned)u * xstep + xrow, on && 2 * (rf + dir * u) + 1 < a.H);
         }
         for (int k0 = 0; k0 < a.g.len; k0 += PF) {
 #pragma unroll
             for (int u = 0; u < PF; ++u) {
                 const int k = k0 + u, r = rf + dir * k;
                 const bool valid = k < nrows, odd_ok = valid && 2 * r + 1 < a.H;
-                const Raw gc = gring[u];
-                const Vals<V> xr0 = xring0[u], xr1 = xring1[u];
+                // a slot's next request goes out right after its last use (into the same registers)
+                const Row<GV> Nw = make_g(gring[u], new_row(k));
                 gring[u] = fetch_g(new_row(k + PF));
+                if (m.up) body(Nw, X, xring0[u], xring1[u], valid, odd_ok);
+                else body(X, Nw, xring0[u], xring1[u], valid, odd_ok);
                 const bool more = m.on && k + PF < nrows;
-                xring0[u] = dwm_ld<V>(a.x, xo + (unsigned)PF * xstep, more);
-                xring1[u] = dwm_ld<V>(a.x, xo + (unsigned)PF * xstep + xrow, more && 2 * (r + dir * PF) + 1 < a.H);
-                const Row<GV> Nw = make_g(gc, new_row(k));
-                if (valid) {
-                    if (m.up) body(Nw, X, xr0, xr1, odd_ok);
-                    else body(X, Nw, xr0, xr1, odd_ok);
-                }
+                xring0[u] = dwm_ld<V>(rx, xo + (unsigned)PF * xstep, more);
+                xring1[u] = dwm_ld<V>(rx, xo + (unsigned)PF * xstep + xrow, more && 2 * (r + dir * PF) + 1 < a.H);
                 xo += xstep;
                 X = Nw;
             }
@@ -671,7 +724,7 @@ bool depthwise_march_ok(const DwShape& s) {
 size_t depthwise_march_splits(const DwShape& s) {
     if (!depthwise_march_ok(s)) return 0;
     const DwmGeom g = dwm_plan(s);
-    return (size_t)s.N * g.BPP;
+    return (size_t)dwm_splits(s, g);
 }
 
 bool depthwise_forward_march(const float* x, const float* w, const float* bias, float* y, const DwShape& s, int act,
@@ -682,8 +735,9 @@ bool depthwise_forward_march(const float* x, const float* w, const float* bias, 
     a.g = dwm_plan(s);
     if (!dwm_aligned(a.g.V, {x}) || !dwm_aligned(s.stride == 1 ? a.g.V : a.g.V / 2, {y})) return false;
     a.x = x; a.w = w; a.bias = bias; a.y = y; a.stats = nullptr;
-    a.C = s.C; a.H = s.H; a.W = s.W; a.OH = s.OH; a.OW = s.OW; a.act = act;
-    const int splits = s.N * a.g.BPP;
+    a.N = s.N; a.C = s.C; a.H = s.H; a.W = s.W; a.OH = s.OH; a.OW = s.OW; a.act = act;
+    a.xbytes = (unsigned)((size_t)s.N * s.C * s.H * s.W * 4); a.ybytes = (unsigned)((size_t)s.N * s.C * s.OH * s.OW * 4);
+    const int splits = dwm_splits(s, a.g);
     if (stats) {
         stats->splits = 0;
         if (stats->partials && stats->capacity >= (size_t)s.C * splits * 2) {
@@ -756,13 +810,14 @@ bool depthwise_backward_march(const float* x, const float* w, const float* y, fl
     DwmBwdArgs a;
     a.g = dwm_plan(s);
     a.x = x; a.w = w; a.y = y; a.dy = dy; a.dx = dx;
-    a.C = s.C; a.H = s.H; a.W = s.W; a.OH = s.OH; a.OW = s.OW; a.act = act;
+    a.N = s.N; a.C = s.C; a.H = s.H; a.W = s.W; a.OH = s.OH; a.OW = s.OW; a.act = act;
     a.overwrite = overwrite; a.write_back = write_back;
+    a.xbytes = (unsigned)((size_t)s.N * s.C * s.H * s.W * 4); a.ybytes = (unsigned)((size_t)s.N * s.C * s.OH * s.OW * 4);
     a.fM = (float)((long long)s.N * s.OH * s.OW);
     a.rfM = 1.0f / a.fM;  // host division: IEEE, round to nearest
     a.bn = bn ? *bn : DwBnBwd{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     a.in = in ? *in : DwBnIn{nullptr, nullptr, nullptr, nullptr, 0};
-    const int splits = s.N * a.g.BPP;
+    const int splits = dwm_splits(s, a.g);
     a.partials = reduce_scratch((size_t)s.C * splits * kDwmPart);
     a.in_sums = nullptr;
     // the sums of the producer's batch-norm backward are of the COMPLETE gradient: only when this kernel is its sole writer,
@@ -776,13 +831,18 @@ bool depthwise_backward_march(const float* x, const float* w, const float* y, fl
     hipStream_t st = current_stream();
     bool relu = act == BCNN_HIP_ACT_RELU && (!in || in->act == BCNN_HIP_ACT_RELU);
     if (BCNN_EXP_ENV("BCNN_HIP_DWM_NORELU")) relu = false;  // A/B switch (experiment build only)
-#define DWM_LAUNCH_R(SV, VV, RV)                                                                                    \
+#define DWM_LAUNCH_O(SV, VV, RV, OV)                                                                                \
     do {                                                                                                            \
-        constexpr int PFV = (VV) == 4 ? 1 : DWM_BWD_PF_SMALL;                                                       \
-        if (bn && in) dwm_bwd_kernel<SV, VV, true, true, RV, PFV><<<blocks, 256, 0, st>>>(a);                       \
-        else if (bn) dwm_bwd_kernel<SV, VV, true, false, RV, PFV><<<blocks, 256, 0, st>>>(a);                       \
-        else if (in) dwm_bwd_kernel<SV, VV, false, true, RV, PFV><<<blocks, 256, 0, st>>>(a);                       \
-        else dwm_bwd_kernel<SV, VV, false, false, RV, PFV><<<blocks, 256, 0, st>>>(a);                              \
+        constexpr int PFV = (VV) == 4 ? DWM_BWD_PF_WIDE : DWM_BWD_PF_SMALL;                                         \
+        if (bn && in) dwm_bwd_kernel<SV, VV, true, true, RV, PFV, OV><<<blocks, 256, 0, st>>>(a);                   \
+        else if (bn) dwm_bwd_kernel<SV, VV, true, false, RV, PFV, OV><<<blocks, 256, 0, st>>>(a);                   \
+        else if (in) dwm_bwd_kernel<SV, VV, false, true, RV, PFV, OV><<<blocks, 256, 0, st>>>(a);                   \
+        else dwm_bwd_kernel<SV, VV, false, false, RV, PFV, OV><<<blocks, 256, 0, st>>>(a);                          \
+    } while (0)
+#define DWM_LAUNCH_R(SV, VV, RV)                       \
+    do {                                               \
+        if (overwrite) DWM_LAUNCH_O(SV, VV, RV, true); \
+        else DWM_LAUNCH_O(SV, VV, RV, false);          \
     } while (0)
 #define DWM_LAUNCH(SV, VV)                     \
     do {                                       \
@@ -799,6 +859,7 @@ bool depthwise_backward_march(const float* x, const float* w, const float* y, fl
     }
 #undef DWM_LAUNCH
 #undef DWM_LAUNCH_R
+#undef DWM_LAUNCH_O
     KERNEL_CHECK();
     dwl_finalize_launch(a.partials, splits, s.C, dw, dbias, st);
     return true;

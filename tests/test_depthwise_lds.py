@@ -55,6 +55,9 @@ SHAPES = [
     (3, 5, 33, 6, 1, ACT_LRELU),
     (3, 5, 33, 6, 2, ACT_RELU),
     (2, 7, 30, 5, 1, ACT_RELU),
+    # small planes in numbers that take several rounds of resident waves (3300 / 3334 waves of nine planes)
+    (55, 540, 14, 14, 1, ACT_RELU),
+    (300, 100, 7, 7, 1, ACT_RELU),
 ]
 
 
@@ -147,7 +150,7 @@ def test_non_finite_inputs_stay_in_their_own_pixels():
 # two separate workers
 # ---------------------------------------------------------------------------------------------------
 PAIR_SHAPES = [(4, 8, 112, 112, 1), (4, 8, 112, 112, 2), (3, 6, 56, 56, 1), (5, 7, 28, 28, 2), (6, 37, 14, 14, 1),
-               (6, 37, 14, 14, 2), (8, 50, 7, 7, 1), (2, 3, 33, 35, 1), (2, 5, 9, 13, 2)]
+               (6, 37, 14, 14, 2), (8, 50, 7, 7, 1), (2, 3, 33, 35, 1), (2, 5, 9, 13, 2), (300, 100, 7, 7, 1)]
 
 
 @pytest.mark.parametrize("shape", PAIR_SHAPES, ids=lambda s: "n%d_c%d_%dx%d_s%d" % s)
@@ -211,3 +214,4 @@ def test_depthwise_batchnorm_pair_shares_work_without_changing_results(shape):
         b = backward(True, overwrite)
         for u, v in zip(a, b):
             assert torch.equal(u.view(torch.int32), v.view(torch.int32))
+
