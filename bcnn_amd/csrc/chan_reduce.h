@@ -100,14 +100,17 @@ inline void launch_chan_reduce(const F& f, int C, int HW, long long M, int split
 // grid-stride loop with 32-bit index math. Body: __device__ void operator()(unsigned off, int c, int cnt)
 // processes cnt (1..4) consecutive elements starting at `off` (cnt == 4 => 16-byte aligned when
 // HW % 4 == 0 and the tensor base is 16-byte aligned).
+#ifndef PLANE_MAP_ITERS
+#define PLANE_MAP_ITERS 4  // float4 groups per thread (a workgroup's chunk is 1024 x that many elements)
+#endif
 template <class Body>
 __global__ __launch_bounds__(256) void plane_map_kernel(const Body body, int C, int HW, int chunks) {
     const int plane = blockIdx.x / chunks, chunk = blockIdx.x - plane * chunks;
     const int c = plane % C;
     const unsigned base = (unsigned)plane * (unsigned)HW;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int i = chunk * 4096 + it * 1024 + threadIdx.x * 4;
+    for (int it = 0; it < PLANE_MAP_ITERS; ++it) {
+        const int i = chunk * (1024 * PLANE_MAP_ITERS) + it * 1024 + threadIdx.x * 4;
         if (i < HW) body(base + i, c, (HW - i) >= 4 ? 4 : (HW - i));
     }
 }
@@ -160,7 +163,7 @@ inline void launch_chan_map(const Body& body, int N, int C, int HW) {
     const long long total = (long long)N * C * HW;
     if (total == 0) return;
     if (HW >= 1024) {
-        const int chunks = (HW + 4095) / 4096;
+        const int chunks = (HW + 1024 * PLANE_MAP_ITERS - 1) / (1024 * PLANE_MAP_ITERS);
         plane_map_kernel<Body><<<(unsigned)(N * C * chunks), 256, 0, current_stream()>>>(body, C, HW, chunks);
     } else {
         const int blocks = stream_grid((size_t)(total / 4 + 1), 256);

@@ -23,7 +23,7 @@
 
 // Timing experiments (tools/exp/win_variants.sh builds the file with -DWABL_*; normal builds define none of them):
 // WABL_NOSTORE / WABL_NOMFMA (forward), WABL_FWD_R (strip height), WABL_NW (multiplying waves), WABL_NBUF, WABL_PREFETCH, ROWS_TM,
-// ROWS_INTERLEAVE, DY_DMA_PLAIN (dW).
+// ROWS_INTERLEAVE, DY_DMA_PLAIN, ROWS_ABL_NODMA / ROWS_ABL_NOMFMA (dW; timing only).
 #ifndef WABL_FWD_R
 #define WABL_FWD_R 4  // output rows per strip (round 5: the loader wave hides the fill, so the halo rows of short strips cost nothing;
 #endif                // forward-only loops 0.275 ms with 4 rows against 0.293 with 8, inside the fwd / dW alternation 0.305 / 0.31)
@@ -808,7 +808,11 @@ __global__ __launch_bounds__(256 * TM, 1) void conv_dw_rows_kernel(const ConvRow
     for (int r = r0; r < r1; ++r) {
         const int buf = (r - r0) & 1;
         const int nn = (r + 1) / s.OH, noh = (r + 1) - nn * s.OH;  // the row requested during this one
+#ifdef ROWS_ABL_NODMA   // timing only: every row multiplies what the first request left in LDS
+        const int kend = 0;
+#else
         const int kend = (r + 1 < r1) ? NREQ : 0;
+#endif
         int k = 0;
 #ifdef ROWS_BURST
         while (k < kend) { request(k, nn, noh, buf ^ 1); ++k; }
@@ -827,11 +831,16 @@ __global__ __launch_bounds__(256 * TM, 1) void conv_dw_rows_kernel(const ConvRow
             float bvA[4], bvB[4];
             read_window(avA, bvA);
             int w = slot;
+#ifdef ROWS_ABL_NOMFMA  // timing only
+#define ROWS_MFMA(ca, cb) _Pragma("unroll") for (int e = 0; e < 4; ++e) acc[e] += ca[e] * cb[e];
+#else
+#define ROWS_MFMA(ca, cb) _Pragma("unroll") for (int e = 0; e < 4; ++e) acc = mfma32(ca[e], cb[e], acc);
+#endif
 #define ROWS_STAGE(ca, cb, na, nb)                                                                 \
             {                                                                                      \
                 const bool more = (w + 4 < nwin); /* uniform */                                    \
                 if (more) read_window(na, nb);                                                     \
-                _Pragma("unroll") for (int e = 0; e < 4; ++e) acc = mfma32(ca[e], cb[e], acc);     \
+                ROWS_MFMA(ca, cb)                                                                  \
                 /* two requests for the next row in the shadow of the last MFMA */                 \
                 if (k < kend) { request(k, nn, noh, buf ^ 1); ++k; }                               \
                 if (k < kend) { request(k, nn, noh, buf ^ 1); ++k; }                               \
@@ -843,6 +852,7 @@ __global__ __launch_bounds__(256 * TM, 1) void conv_dw_rows_kernel(const ConvRow
                 ROWS_STAGE(avB, bvB, avA, bvA)
             }
 #undef ROWS_STAGE
+#undef ROWS_MFMA
         }
         while (k < kend) { request(k, nn, noh, buf ^ 1); ++k; }  // narrow rows: fewer windows than requests
         dma_wait();     // this wave's requests for row r + 1 have landed ...
