@@ -49,6 +49,9 @@
 #ifndef ROWS_TM
 #define ROWS_TM 1
 #endif
+#ifndef ROWS_NS
+#define ROWS_NS 2  // stages of the dW row ring (2: two workgroups per CU; more: one, rows requested ROWS_NS - 1 ahead)
+#endif
 #ifndef ROWS_INTERLEAVE
 #define ROWS_BURST 1
 #endif
@@ -724,11 +727,11 @@ __global__ __launch_bounds__(256 * TM, 1) void conv_dw_rows_kernel(const ConvRow
     constexpr int NF = 32 * TM, NW = 4 * TM;        // filters per workgroup, waves (4 per block of 32 filters)
     constexpr int DYS = NF * PD, XS = CG * 3 * PX;  // floats per stage
     constexpr int XREQ = (CG * 3 + NW - 1) / NW, NREQ = 8 + XREQ;  // LDS-DMA instructions per wave and row
-    constexpr int RED = TM * 3 * 32 * 33;
+    constexpr int RED = TM * 3 * 32 * 33, NS = (PD > 228 && ROWS_NS > 3) ? 3 : ROWS_NS;  // the wide pitch has room for three
     static_assert(2 * DYS >= RED, "the final reduction aliases the dy stages");
-    __shared__ __attribute__((aligned(16))) float lds[2 * DYS + 2 * XS + 16];
-    float* xS = lds + 2 * DYS;
-    float* cst = xS + 2 * XS;  // eight ones, eight zeros
+    __shared__ __attribute__((aligned(16))) float lds[NS * DYS + NS * XS + 16];
+    float* xS = lds + NS * DYS;
+    float* cst = xS + NS * XS;  // eight ones, eight zeros
     const ConvShape& s = a.s;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -740,7 +743,7 @@ __global__ __launch_bounds__(256 * TM, 1) void conv_dw_rows_kernel(const ConvRow
     const rsrc_i4 rdy = make_rsrc(a.dy, (unsigned)((long long)s.N * s.F * s.OHOW * 4));
 
     // the input stages' padding columns are never written again: zero them (and everything else) once
-    for (int i = tid; i < 2 * XS; i += 256 * TM) xS[i] = 0.f;
+    for (int i = tid; i < NS * XS; i += 256 * TM) xS[i] = 0.f;
     if (tid < 16) cst[tid] = tid < 8 ? 1.0f : 0.0f;
     __syncthreads();
 
@@ -751,8 +754,8 @@ __global__ __launch_bounds__(256 * TM, 1) void conv_dw_rows_kernel(const ConvRow
     unsigned b_lane, b_step;  // taps follow the window, the constant columns do not
     {
         const int c = l31 / 9, r9 = l31 - c * 9, kr = r9 / 3, kc = r9 - kr * 3;
-        b_lane = tap ? (unsigned)((2 * DYS + (c * 3 + kr) * PX + kc + (kWinOrg - s.pad) + 4 * hi) * 4)
-                     : (unsigned)((2 * DYS + 2 * XS + ((l31 == K && a.bias_col) ? 0 : 8)) * 4);
+        b_lane = tap ? (unsigned)((NS * DYS + (c * 3 + kr) * PX + kc + (kWinOrg - s.pad) + 4 * hi) * 4)
+                     : (unsigned)((NS * DYS + NS * XS + ((l31 == K && a.bias_col) ? 0 : 8)) * 4);
         b_step = tap ? 1u : 0u;
     }
     const char* ldsb = reinterpret_cast<const char*>(lds);
@@ -785,7 +788,7 @@ __global__ __launch_bounds__(256 * TM, 1) void conv_dw_rows_kernel(const ConvRow
             const bool ok = (unsigned)ih < (unsigned)s.H;
             const unsigned soff = __builtin_amdgcn_readfirstlane(
                 ((unsigned)(n * s.C + g * s.Cg + c) * (unsigned)s.HW + (unsigned)((ok ? ih : 0) * s.W)) * 4u);
-            const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((2 * DYS + buf * XS + i * PX + kWinOrg) * 4));
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((NS * DYS + buf * XS + i * PX + kWinOrg) * 4));
             const unsigned voff = ok ? dma_lane : kOOB;
             if (x_lane_on) dma_row_x4(rx, dst, voff, soff);
         }
@@ -799,23 +802,25 @@ __global__ __launch_bounds__(256 * TM, 1) void conv_dw_rows_kernel(const ConvRow
     int r1 = r0 + a.rows_per_block;
     if (r1 > a.total_rows) r1 = a.total_rows;
 
-    if (r0 < r1) {
-        const int n = r0 / s.OH, oh = r0 - n * s.OH;
-        for (int k = 0; k < NREQ; ++k) request(k, n, oh, 0);
-    }
+    for (int q = 0; q < NS - 1; ++q)  // the first NS - 1 rows into stages 0 .. NS - 2
+        if (r0 + q < r1) {
+            const int n = (r0 + q) / s.OH, oh = (r0 + q) - n * s.OH;
+            for (int k = 0; k < NREQ; ++k) request(k, n, oh, q);
+        }
     dma_wait();
     lds_barrier();
+    int buf = 0;
     for (int r = r0; r < r1; ++r) {
-        const int buf = (r - r0) & 1;
-        const int nn = (r + 1) / s.OH, noh = (r + 1) - nn * s.OH;  // the row requested during this one
+        const int nbuf = buf == 0 ? NS - 1 : buf - 1;  // the stage read during row r - 1: free for row r + NS - 1
+        const int nn = (r + NS - 1) / s.OH, noh = (r + NS - 1) - nn * s.OH;  // the row requested during this one
 #ifdef ROWS_ABL_NODMA   // timing only: every row multiplies what the first request left in LDS
         const int kend = 0;
 #else
-        const int kend = (r + 1 < r1) ? NREQ : 0;
+        const int kend = (r + NS - 1 < r1) ? NREQ : 0;
 #endif
         int k = 0;
 #ifdef ROWS_BURST
-        while (k < kend) { request(k, nn, noh, buf ^ 1); ++k; }
+        while (k < kend) { request(k, nn, noh, nbuf); ++k; }
 #endif
         unsigned va = a_lane + (unsigned)(buf * DYS * 4) + (unsigned)(slot * 32);
         unsigned vb = b_lane + b_step * (unsigned)(buf * XS * 4 + slot * 32);
@@ -842,8 +847,8 @@ __global__ __launch_bounds__(256 * TM, 1) void conv_dw_rows_kernel(const ConvRow
                 if (more) read_window(na, nb);                                                     \
                 ROWS_MFMA(ca, cb)                                                                  \
                 /* two requests for the next row in the shadow of the last MFMA */                 \
-                if (k < kend) { request(k, nn, noh, buf ^ 1); ++k; }                               \
-                if (k < kend) { request(k, nn, noh, buf ^ 1); ++k; }                               \
+                if (k < kend) { request(k, nn, noh, nbuf); ++k; }                               \
+                if (k < kend) { request(k, nn, noh, nbuf); ++k; }                               \
                 if (!more) break;                                                                  \
                 w += 4;                                                                            \
             }
@@ -854,9 +859,19 @@ __global__ __launch_bounds__(256 * TM, 1) void conv_dw_rows_kernel(const ConvRow
 #undef ROWS_STAGE
 #undef ROWS_MFMA
         }
-        while (k < kend) { request(k, nn, noh, buf ^ 1); ++k; }  // narrow rows: fewer windows than requests
-        dma_wait();     // this wave's requests for row r + 1 have landed ...
+        while (k < kend) { request(k, nn, noh, nbuf); ++k; }  // narrow rows: fewer windows than requests
+        // this wave's requests for row r + 1 have landed (the rows behind it may fly on: vmcnt retires in order, every row
+        // is NREQ instructions per wave) ...
+        if (NS > 2) {
+            const int ahead = min(r + NS - 1, r1 - 1) - (r + 1);  // rows requested after row r + 1
+            if (NS > 3 && ahead >= 2) dma_wait_n<2 * NREQ>();
+            else if (ahead >= 1) dma_wait_n<NREQ>();
+            else dma_wait();
+        } else {
+            dma_wait();
+        }
         lds_barrier();  // ... and so have everybody's; everybody is done reading stage `buf`
+        buf = buf + 1 == NS ? 0 : buf + 1;
     }
 
     // cross-wave reduction (slots 1..3 -> LDS -> slot 0), then this filter block's rows of the workgroup's partial tile
@@ -1104,7 +1119,7 @@ static void dw_rows_plan(const ConvShape& s, int* rpb, int* blocks) {
     (void)fblocks;
 #else
     // persistent workgroups, one per block of 32 filters: two per CU at the narrow pitch (75 KB of LDS each), one at the wide
-    int b = ((window_pitch(s) == 232 ? 2 : 1) * kCUs) / fblocks;
+    int b = ((window_pitch(s) == 232 && ROWS_NS == 2 ? 2 : 1) * kCUs) / fblocks;
 #endif
     if (b < 1) b = 1;
     if (b > total) b = total;
