@@ -1456,30 +1456,35 @@ __global__ __launch_bounds__(512, 2) void wino_dw_fused_kernel(const WinoDwArgs 
 }
 
 // dw[f][c][3][3] += G^T (sum_sp partial[sp][ob][.][f][c]) G,  G^T = [1 .5 .5 0; 0 .5 -.5 0; 0 .5 .5 1].
-// block = 16 positions x 16 channels c of one f: every thread sums its (xi, f, c) over the splits in order
-// (four independent chains), then 16 threads finish the 4x4 -> 3x3 transform.
+// block = 16 positions x the 64 channels c of one f: a thread sums four consecutive c of its position over the splits in order
+// (four independent chains per element, as before: the same bits) with 16-byte loads -- 16 lanes read 256 contiguous bytes of a
+// split's slab where the one-float version read 64 -- then 64 threads finish the 4x4 -> 3x3 transform.
 __global__ __launch_bounds__(256) void wino_dw_fused_finalize_kernel(const float* __restrict__ partials, int splits,
                                                                      int fblocks, int cblocks, int F, int C,
                                                                      float* __restrict__ dw) {
-    __shared__ float u[16][17];
+    __shared__ float u[16][65];
     const int xi = threadIdx.x >> 4, cq = threadIdx.x & 15;
     const int nob = fblocks * cblocks;
-    const int fl = blockIdx.x & 63, cgrp = (blockIdx.x >> 6) & 3, ob = blockIdx.x >> 8;
-    const int f = (ob % fblocks) * 64 + fl, c = (ob / fblocks) * 64 + cgrp * 16 + cq;
-    const float* p = partials + (size_t)ob * (16 * 64 * 64) + ((size_t)xi * 64 + fl) * 64 + cgrp * 16 + cq;
+    const int fl = blockIdx.x & 63, ob = blockIdx.x >> 6;
+    const float* p = partials + (size_t)ob * (16 * 64 * 64) + ((size_t)xi * 64 + fl) * 64 + cq * 4;
     const size_t stride = (size_t)nob * (16 * 64 * 64);
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+    auto ld = [&](int sp) { return *reinterpret_cast<const float4*>(p + (size_t)sp * stride); };
+    auto add = [](float4& s, const float4& v) { s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; };
     int sp = 0;
     for (; sp + 3 < splits; sp += 4) {
-        const float v0 = p[(size_t)sp * stride], v1 = p[(size_t)(sp + 1) * stride];
-        const float v2 = p[(size_t)(sp + 2) * stride], v3 = p[(size_t)(sp + 3) * stride];
-        s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+        const float4 v0 = ld(sp), v1 = ld(sp + 1), v2 = ld(sp + 2), v3 = ld(sp + 3);
+        add(s0, v0); add(s1, v1); add(s2, v2); add(s3, v3);
     }
-    for (; sp < splits; ++sp) s0 += p[(size_t)sp * stride];
-    u[xi][cq] = (s0 + s1) + (s2 + s3);
+    for (; sp < splits; ++sp) add(s0, ld(sp));
+    u[xi][cq * 4 + 0] = (s0.x + s1.x) + (s2.x + s3.x);
+    u[xi][cq * 4 + 1] = (s0.y + s1.y) + (s2.y + s3.y);
+    u[xi][cq * 4 + 2] = (s0.z + s1.z) + (s2.z + s3.z);
+    u[xi][cq * 4 + 3] = (s0.w + s1.w) + (s2.w + s3.w);
     __syncthreads();
-    if (threadIdx.x < 16 && f < F && c < C) {
-        const int q = threadIdx.x;
+    const int q = threadIdx.x;
+    const int f = (ob % fblocks) * 64 + fl, c = (ob / fblocks) * 64 + q;
+    if (q < 64 && f < F && c < C) {
         float m[4][4];
 #pragma unroll
         for (int k = 0; k < 16; ++k) m[k >> 2][k & 3] = u[k][q];
@@ -1543,6 +1548,7 @@ bool conv_backward_weights_winograd_fused(const float* x, const float* dy, float
                                           size_t workspace_floats) {
     const WinoDwPlan p = wino_dw_fused_plan(s);
     if (!p.ok) return false;
+    if (reinterpret_cast<uintptr_t>(workspace) & 15) return false;  // the finalize kernel reads the slabs 16 bytes at a time
     if (workspace == nullptr || workspace_floats < p.partial_floats) {
         fprintf(stderr, "[bcnn_hip] conv backward: workspace too small (%zu floats given, %zu needed)\n", workspace_floats,
                 p.partial_floats);
@@ -1560,7 +1566,7 @@ bool conv_backward_weights_winograd_fused(const float* x, const float* dy, float
     if (s.W & 1) wino_dw_fused_kernel<true><<<(unsigned)(p.splits * nob), 512, 0, current_stream()>>>(a);
     else wino_dw_fused_kernel<false><<<(unsigned)(p.splits * nob), 512, 0, current_stream()>>>(a);
     KERNEL_CHECK();
-    wino_dw_fused_finalize_kernel<<<(unsigned)(nob * 256), 256, 0, current_stream()>>>(workspace, p.splits, p.fblocks, p.cblocks,
+    wino_dw_fused_finalize_kernel<<<(unsigned)(nob * 64), 256, 0, current_stream()>>>(workspace, p.splits, p.fblocks, p.cblocks,
                                                                                       s.F, s.C, dw);
     KERNEL_CHECK();
     return true;
