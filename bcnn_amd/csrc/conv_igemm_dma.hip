@@ -595,6 +595,7 @@ static bool dma_supported(const ConvShape& s, int M, int J, size_t b_elems) {
 // 128x128 grid lands on 3.06 / 1.53 workgroups per CU: a quarter of the chip idles in the last round).
 static int pick_dma_tile(const DmaArgs& a, int max_cols) {
     static const char* forced = BCNN_EXP_ENV("BCNN_HIP_IGEMM_TILE");  // experiments: 0..4
+    if (forced && a.bs_out != nullptr) return 4;  // batch-norm sums come from the 64 x 64 tile only
     if (forced && forced[0] >= '0' && forced[0] <= '5' && (forced[0] != '5' || (a.J & 1) == 0)) return forced[0] - '0';
     (void)max_cols;
     return 4;

@@ -44,6 +44,9 @@ namespace {
 #define DWM_BWD_WAVES 3  // waves per SIMD the backward kernels are compiled for (register budget 512 / that; at 4 the
                          // 112 x 112 instance spills inside its loop and takes twice the time)
 #endif
+#ifndef DWM_FWD_WAVES
+#define DWM_FWD_WAVES 4  // waves per SIMD the forward kernels are compiled for
+#endif
 #ifndef DWM_BWD_WAVES_SMALL
 #define DWM_BWD_WAVES_SMALL 3  // the same for lanes of 2 / 1 columns
 #endif
@@ -137,7 +140,9 @@ __device__ __forceinline__ bool dwm_map(unsigned wave, int grp, int G, int BPP, 
 __device__ __forceinline__ DwmLane dwm_lane(int L, int G, int BPP, int C, unsigned planes) {
     DwmLane m;
     const int lane = threadIdx.x & 63;
-    const unsigned wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    // (readfirstlane: the compiler cannot see that threadIdx.x >> 6 is wave-uniform, and would run both orientations of the
+    // window under exec masks, each with its own copy of the step's stores)
+    const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));
     m.grp = lane / L;
     m.cg = lane - m.grp * L;
     m.on = dwm_map(wave, m.grp, G, BPP, planes, m.p, m.bi, m.up);
@@ -305,8 +310,10 @@ struct DwmFwdArgs {
 
 // RELU: this layer's activation (and with BNIN the producer's) is ReLU, compiled in: the activation switch on a kernel
 // argument costs a scalar jump table per element otherwise. Other cheap activations take the generic instance.
+// (launch bound: four waves per SIMD, i.e. up to 128 registers. Compiled for the default of eight the allocator split the ring's
+// live ranges and copied three of four slots at the loop's back edge -- copies of loaded values, i.e. a full drain per PF steps.)
 template <int S, int V, bool BNIN, int PF, bool RELU>
-__global__ __launch_bounds__(256) void dwm_fwd_kernel(const DwmFwdArgs a) {
+__global__ __launch_bounds__(256, DWM_FWD_WAVES) void dwm_fwd_kernel(const DwmFwdArgs a) {
     __shared__ float red[4][2 * kSlab];
     const int act = RELU ? BCNN_HIP_ACT_RELU : a.act, in_act = RELU ? BCNN_HIP_ACT_RELU : a.in.act;
     constexpr int OV = S == 1 ? V : V / 2;  // outputs per lane and row
@@ -330,9 +337,21 @@ __global__ __launch_bounds__(256) void dwm_fwd_kernel(const DwmFwdArgs a) {
     const rsrc_i4 rx = make_rsrc(a.x, a.xbytes), ry = make_rsrc(a.y, a.ybytes);
     auto in_row = [&](int r) -> bool { return m.on && r >= 0 && r < a.H; };
     auto fetch = [&](int r) -> Vals<V> { return dwm_ld<V>(rx, xbase + (unsigned)r * xrow, in_row(r)); };
-    auto prep = [&](Vals<V> v, int r) -> Row<V> {
-        if (BNIN && in_row(r)) v = dwm_bnin_v<V>(v, kin, in_act);
-        return dwm_row<V, true, S == 1>(v, m);
+    // (The window row is always made of NEW registers -- a select, or a move the compiler cannot fold. A row that merely renames
+    // the loaded registers keeps them alive for the two steps it spends in the window, the slot's next request then lands
+    // elsewhere, and the ring is rotated by copies at the loop's back edge: copies of loaded values, a drain per PF steps.)
+    auto prep = [&](const Vals<V>& v, int r) -> Row<V> {
+        Vals<V> o;
+        if (BNIN) {
+            const bool ok = in_row(r);
+            const Vals<V> t = dwm_bnin_v<V>(v, kin, in_act);
+#pragma unroll
+            for (int i = 0; i < V; ++i) o.v[i] = ok ? t.v[i] : 0.f;
+        } else {
+#pragma unroll
+            for (int i = 0; i < V; ++i) asm volatile("v_mov_b32 %0, %1" : "=v"(o.v[i]) : "v"(v.v[i]));
+        }
+        return dwm_row<V, true, S == 1>(o, m);
     };
     auto finish = [&](float v) -> float { return act_fwd_cheap(__fadd_rn(v, b), act, 0.f); };
     // A / B / Cr: the rows above, at and below the output row (in image order, whichever way the band is marched)
@@ -372,11 +391,11 @@ __global__ __launch_bounds__(256) void dwm_fwd_kernel(const DwmFwdArgs a) {
             for (int u = 0; u < PF; ++u) {
                 const int k = i0 + u;
                 const Row<V> Nx = prep(ring[u], step_row(k + 1));
+                ring[u] = fetch(step_row(k + 1 + PF));  // right after the slot's last use: into the same registers
                 if (m.up) emit(Nx, Q, P, k < nrows);
                 else emit(P, Q, Nx, k < nrows);
                 P = Q;
                 Q = Nx;
-                ring[u] = fetch(step_row(k + 1 + PF));  // last: into the registers of the row just used
             }
         }
     } else {
@@ -396,11 +415,11 @@ __global__ __launch_bounds__(256) void dwm_fwd_kernel(const DwmFwdArgs a) {
             for (int u = 0; u < PF; ++u) {
                 const int k = i0 + u;
                 const Row<V> Md = prep(ring0[u], mid_row(k)), Fr = prep(ring1[u], far_row(k));
+                ring0[u] = fetch(mid_row(k + PF));  // right after the slots' last use
+                ring1[u] = fetch(far_row(k + PF));
                 if (m.up) emit(Fr, Md, Nr, k < nrows);
                 else emit(Nr, Md, Fr, k < nrows);
                 Nr = Fr;
-                ring0[u] = fetch(mid_row(k + PF));
-                ring1[u] = fetch(far_row(k + PF));
             }
         }
     }
