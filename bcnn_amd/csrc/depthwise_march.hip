@@ -479,19 +479,30 @@ __global__ __launch_bounds__(256, V == 4 ? DWM_BWD_WAVES : DWM_BWD_WAVES_SMALL) 
     float w[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) w[i] = a.w[m.c * 9 + i];
+#ifdef DWM_ABL_NOCONST   // timing only: no dependent constant loads / sqrt / divide chain in the prologue
+#pragma unroll
+    for (int i = 0; i < 9; ++i) w[i] = 0.1f * (float)(i + 1);
+#define DWM_CONST(expr, val) (val)
+#else
+#define DWM_CONST(expr, val) (expr)
+#endif
     DwmBnC kb;
     if (BN) {
-        kb.mean = a.bn.mean[m.c];
-        kb.rs.d = sqrtf(a.bn.var[m.c] + 0.00001f);
-        kb.rs.r = __fdiv_rn(1.0f, kb.rs.d);
-        kb.sc = a.bn.scale[m.c];
+        kb.mean = DWM_CONST(a.bn.mean[m.c], 0.1f);
+        kb.rs.d = DWM_CONST(sqrtf(a.bn.var[m.c] + 0.00001f), 1.25f);
+        kb.rs.r = DWM_CONST(__fdiv_rn(1.0f, kb.rs.d), 0.8f);
+        kb.sc = DWM_CONST(a.bn.scale[m.c], 1.5f);
         kb.sc0 = kb.sc == 0.0f;
         kb.any_sc0 = __builtin_amdgcn_ballot_w64(kb.sc0) != 0;
-        kb.dm_m = __fdiv_rn(a.bn.dmean[m.c], a.fM);
-        kb.dv2 = __fmul_rn(a.bn.dvar[m.c], 2.0f);
+        kb.dm_m = DWM_CONST(__fdiv_rn(a.bn.dmean[m.c], a.fM), 0.001f);
+        kb.dv2 = DWM_CONST(__fmul_rn(a.bn.dvar[m.c], 2.0f), 0.002f);
     }
     DwmBnInC kin;
     if (BNIN) kin = dwm_bnin_consts(a.in, m.c);
+#ifdef DWM_ABL_NOCONST
+    if (BNIN) { kin.mean = 0.1f; kin.sc = 1.5f; kin.b = 0.2f; kin.sc0 = false; kin.any_sc0 = false; kin.rs.d = 1.25f; kin.rs.r = 0.8f; }
+#endif
+#undef DWM_CONST
     const BnDiv fM{a.fM, a.rfM};
     const bool sums = BNIN && a.in_sums != nullptr;
     const unsigned xrow = (unsigned)a.W * 4u, grow = (unsigned)a.OW * 4u;  // bytes per row
@@ -710,6 +721,9 @@ __global__ __launch_bounds__(256, V == 4 ? DWM_BWD_WAVES : DWM_BWD_WAVES_SMALL) 
             }
         }
     }
+#ifdef DWM_ABL_NOEPI   // timing only: no band sums, no partial stores
+    if (acc[0] != 123.456f) return;
+#endif
     const int splits = (int)(a.g.bands / a.C);  // N * BPP
     const unsigned wave = blockIdx.x * 4u + (threadIdx.x >> 6);
     dwm_band_sums<kDwmPart>(acc, red[threadIdx.x >> 6], a.g.L, a.g.G, [&](int q, int i, float t) {
