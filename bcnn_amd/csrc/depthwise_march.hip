@@ -56,6 +56,9 @@ namespace {
 #ifndef DWM_BWD_PF_WIDE
 #define DWM_BWD_PF_WIDE 1  // backward, lanes of 4 columns: rows requested ahead
 #endif
+#ifndef DWM_ROWS_SMALL
+#define DWM_ROWS_SMALL 7  // the same for planes below 56 rows and for stride 2 (see dwm_plan)
+#endif
 #ifndef DWM_ROWS
 #define DWM_ROWS 14  // rows a band marches (target; the plan evens bands out)
 #endif
@@ -89,7 +92,11 @@ inline DwmGeom dwm_plan(const DwShape& s) {
     g.L = s.W / g.V;
     g.G = 64 / g.L;
     const int R = s.OH;
-    int rows = DWM_ROWS;
+    // band length: 14 rows for stride-1 planes of 56 rows and more, 7 for everything else -- measured per MobileNet layer inside
+    // the step (tools/exp/dwm_libs.sh with BCNN_HIP_DWM_ROWS = 5 / 7 / 10 / 14 / 28 / 56): more, shorter waves win on the small
+    // planes and at stride 2 (28 x 28 backward 204 -> 195 us, 14 x 14 backward 116 -> 108, 112 -> 56 backward 382 -> 361), the
+    // 112 x 112 / 56 x 56 stride-1 layers lose 5-20 % below 14 (the halo rows' share), and everything loses above 14.
+    int rows = (s.stride == 1 && s.OH >= 56) ? DWM_ROWS : DWM_ROWS_SMALL;
 #ifdef BCNN_HIP_EXPERIMENT
     if (const char* e = getenv("BCNN_HIP_DWM_ROWS")) rows = atoi(e) > 0 ? atoi(e) : rows;
 #endif
