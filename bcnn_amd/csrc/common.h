@@ -53,10 +53,13 @@ constexpr int kXCDs = 8;
 
 inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+#ifndef STREAM_GRID_PER_CU
+#define STREAM_GRID_PER_CU 8
+#endif
 // grid for a grid-stride streaming kernel: enough blocks to fill the chip, capped (guide G11).
 inline int stream_grid(size_t work_items, int block) {
     size_t need = (work_items + block - 1) / block;
-    size_t cap = (size_t)kCUs * 8;
+    size_t cap = (size_t)kCUs * STREAM_GRID_PER_CU;
     if (need < 1) need = 1;
     return (int)(need < cap ? need : cap);
 }
