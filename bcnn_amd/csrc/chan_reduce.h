@@ -15,11 +15,14 @@ namespace bcnn_hip {
 #ifndef CHAN_WG_PER_CU
 #define CHAN_WG_PER_CU 4
 #endif
+#ifndef CHAN_MIN_ELEMS
+#define CHAN_MIN_ELEMS 4096
+#endif
 inline int chan_splits(int channels, long long per_channel) {
     // aim for >= ~4 workgroups per CU overall (16 measured no faster: tools/exp/bn_trace.sh), but keep >= 4096
     // elements per workgroup
     long long want = ((long long)CHAN_WG_PER_CU * kCUs + channels - 1) / channels;
-    long long maxs = (per_channel + 4095) / 4096;
+    long long maxs = (per_channel + CHAN_MIN_ELEMS - 1) / CHAN_MIN_ELEMS;
     if (want > maxs) want = maxs;
     if (want < 1) want = 1;
     if (want > 1024) want = 1024;
