@@ -13,6 +13,14 @@
 
 namespace bcnn_hip {
 
+#ifdef NT_STORES   // experiment: streaming stores for the sweeps' results
+#define BN_ST4(p, v) do { typedef float f4_ __attribute__((ext_vector_type(4))); const f4_ t_ = {(v).x, (v).y, (v).z, (v).w}; \
+                          __builtin_nontemporal_store(t_, reinterpret_cast<f4_*>(p)); } while (0)
+#else
+#define BN_ST4(p, v) (*reinterpret_cast<float4*>(p) = (v))
+#endif
+
+
 // ---- per-channel constants of an apply sweep ---------------------------------------------------------------------
 // The apply bodies need, per channel, sqrt(var + eps), its correctly rounded reciprocal, dmean / M ...: two square roots
 // and up to four IEEE divisions. Evaluated inside the map kernels (once per 16 bytes in the flat kernel, whose lanes
@@ -209,7 +217,7 @@ struct BnApplyBody {
                 yv.x = act_fwd_cheap(yv.x, a.act2, 0.f); yv.y = act_fwd_cheap(yv.y, a.act2, 0.f);
                 yv.z = act_fwd_cheap(yv.z, a.act2, 0.f); yv.w = act_fwd_cheap(yv.w, a.act2, 0.f);
             }
-            *reinterpret_cast<float4*>(a.y + off) = yv;
+            BN_ST4(a.y + off, yv);
         } else {
             for (int k = 0; k < cnt; ++k) {
                 const float xv = a.x[off + k];
@@ -413,8 +421,8 @@ struct BnBwdApplyBody {
             o.y = bn_bwd_one(g.y, yv.y, xv.y, mean, rs, sc, dmm, dv, fM, a.act);
             o.z = bn_bwd_one(g.z, yv.z, xv.z, mean, rs, sc, dmm, dv, fM, a.act);
             o.w = bn_bwd_one(g.w, yv.w, xv.w, mean, rs, sc, dmm, dv, fM, a.act);
-            if (!a.keep_dy) *reinterpret_cast<float4*>(a.dy + off) = o;
-            if (a.dx) *reinterpret_cast<float4*>(a.dx + off) = o;
+            if (!a.keep_dy) BN_ST4(a.dy + off, o);
+            if (a.dx) BN_ST4(a.dx + off, o);
         } else {
             for (int k = 0; k < cnt; ++k) {
                 const float xk = a.x[off + k];

@@ -508,7 +508,11 @@ __global__ __launch_bounds__(64 * WM * WN, ABL_LB) void conv_igemm_dma_kernel(co
 #ifdef ABL_NOSTORE
                 if (o == 123.456f)
 #endif
+#ifdef NT_STORES   // experiment: the result tensor as a streaming store (tools/micro/mall_probe.hip)
+                __builtin_nontemporal_store(o, &a.out[off0 + (unsigned)mr * o_row_stride]);
+#else
                 a.out[off0 + (unsigned)mr * o_row_stride] = o;
+#endif
             }
         }
     }

@@ -184,7 +184,11 @@ struct Vals {
 };
 // 16-byte store: inline assembly carrying its own wait states (lds_dma.h explains why there is no intrinsic wrapper)
 __device__ __forceinline__ void buffer_store_f32x4(const buf_f32x4 v, rsrc_i4 rs, unsigned voff) {
+#ifdef NT_STORES
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen nt\n\ts_nop 1" : : "v"(v), "v"(voff), "s"(rs) : "memory");
+#else
     asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" : : "v"(v), "v"(voff), "s"(rs) : "memory");
+#endif
 }
 template <int V>
 __device__ __forceinline__ Vals<V> dwm_ld(rsrc_i4 rs, unsigned byte_off, bool ok) {
@@ -209,12 +213,17 @@ __device__ __forceinline__ Vals<V> dwm_zero() {
     for (int i = 0; i < V; ++i) o.v[i] = 0.f;
     return o;
 }
+#ifdef NT_STORES
+#define DWM_STORE_AUX 2
+#else
+#define DWM_STORE_AUX 0
+#endif
 template <int V>
 __device__ __forceinline__ void dwm_st(rsrc_i4 rs, unsigned byte_off, const Vals<V>& o, bool ok) {
     const unsigned vo = ok ? byte_off : kOOB;
     if constexpr (V == 4) buffer_store_f32x4(buf_f32x4{o.v[0], o.v[1], o.v[2], o.v[3]}, rs, vo);
-    else if constexpr (V == 2) buffer_store_f32x2(buf_f32x2{o.v[0], o.v[1]}, rs, (int)vo, 0, 0);
-    else buffer_store_f32(o.v[0], rs, (int)vo, 0, 0);
+    else if constexpr (V == 2) buffer_store_f32x2(buf_f32x2{o.v[0], o.v[1]}, rs, (int)vo, 0, DWM_STORE_AUX);
+    else buffer_store_f32(o.v[0], rs, (int)vo, 0, DWM_STORE_AUX);
 }
 
 // a row of the window: the lane's V values between the neighbours' (index 0 = left neighbour ... V + 1 = right neighbour)
