@@ -47,6 +47,11 @@ struct KTimer {
     ~KTimer();
 };
 
+// Dispatch trace (bcnn_hip_trace_*, off by default): dispatchers name the kernel family they launch. runtime.hip
+extern thread_local bool g_trace_on;
+void trace_kernel_slow(const char* name);
+inline void trace_kernel(const char* name) { if (g_trace_on) trace_kernel_slow(name); }
+
 constexpr int kWave = 64;      // CDNA wavefront
 constexpr int kCUs = 256;      // MI355X
 constexpr int kXCDs = 8;

@@ -370,6 +370,7 @@ static void conv_forward_impl(const float* x, const float* w, const float* bias,
         // constant W b is left out of the stored pre-normalisation values -- the batch-norm behind subtracts the batch mean,
         // so every later use (apply, backward, the consumers that normalise on the fly) sees raw - mean either way -- and
         // is added where it is visible: the running mean.
+        trace_kernel("bnfold:fwd");
         mean_shift = fold_rowconst(fold, w, c, f);
         KTimer kt(K_CONV_FWD, 2.0 * (double)s.total_q * s.Mg * s.K * s.groups,
                   4.0 * ((double)s.N * s.C * s.HW + (double)s.F * s.K + (double)s.N * s.F * s.OHOW));
@@ -502,6 +503,7 @@ static void conv_backward_impl(const float* x, const float* w, const float* bias
     if (fold.mean) {
         // (the term b (x) sum_q dy of the exact derivative is left out: dy here is the gradient of a batch-norm's input, whose
         // sum over the batch is zero up to rounding -- in the reference too, where it multiplies the same b)
+        trace_kernel("bnfold:dw");
         if (!conv_backward_weights_dma_timed(x, dy, dw, s, workspace, workspace_elems, &fold)) {
             fprintf(stderr, "[bcnn_hip] conv backward: the LDS-DMA weight-gradient kernel refused a folded layer\n");
             exit(1);

@@ -388,6 +388,7 @@ bool conv_backward_weights_dma(const float* x, const float* dy, float* dw, const
     a.b_row_stride = s.pointwise ? s.OHOW : s.HW;
     dim3 grid((unsigned)(p.mtiles * p.ntiles * p.kk2 * p.qsplits), (unsigned)s.groups);
     const unsigned threads = (unsigned)kDwTiles[p.cfg].threads;
+    trace_kernel("conv_dw_dma_kernel");
     switch (p.cfg) {
         case 0: conv_dw_dma_kernel<2, 2, 1, 1><<<grid, threads, 0, current_stream()>>>(a); break;
         case 1: conv_dw_dma_kernel<2, 2, 2, 1><<<grid, threads, 0, current_stream()>>>(a); break;

@@ -611,6 +611,7 @@ static void launch_dma_cfg(DmaArgs& a, int max_cols) {
     a.mtiles = ceil_div(a.M, BM);
     a.stats_splits = ceil_div(max_cols, BN);
     dim3 grid((unsigned)(a.mtiles * a.stats_splits), (unsigned)a.s.groups, (unsigned)a.nclass);
+    trace_kernel(a.bs_out ? "conv_igemm_dma_kernel:dx+bnsums" : a.mode ? "conv_igemm_dma_kernel:dx" : "conv_igemm_dma_kernel:fwd");
     if (a.bs_out != nullptr) {
         if (WM == 2 && WN == 2 && TM == 1 && TN == 1) {
             conv_igemm_dma_kernel<2, 2, 1, 1, true><<<grid, 256, 0, current_stream()>>>(a);

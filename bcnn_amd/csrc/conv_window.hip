@@ -410,6 +410,7 @@ bool conv_forward_window(const float* x, const float* w, const float* bias, cons
                                    else LAUNCH4(CGv, Pv, TMv, 2); } while (0)
 #define LAUNCH2(CGv, Pv) do { if (tm == 1) LAUNCH3(CGv, Pv, 1); else LAUNCH3(CGv, Pv, 2); } while (0)
 #define LAUNCH1(CGv) do { if (pitch == 232) LAUNCH2(CGv, 232); else LAUNCH2(CGv, 264); } while (0)
+    trace_kernel("conv_fwd_window_kernel");
     if (s.Cg == 1) LAUNCH1(1);
     else if (s.Cg == 2) LAUNCH1(2);
     else LAUNCH1(3);
@@ -688,6 +689,7 @@ bool conv_forward_stem(const float* x, const float* w, const float* bias, const 
 #define SLAUNCH3(CGv, Av, STv) conv_fwd_stem_kernel<CGv, R, 232, Av, STv><<<grid, 256, 0, current_stream()>>>(a)
 #define SLAUNCH2(CGv) do { if (want_stats) SLAUNCH3(CGv, 0, true); else if (actm == 0) SLAUNCH3(CGv, 0, false); \
                            else if (actm == 1) SLAUNCH3(CGv, 1, false); else SLAUNCH3(CGv, 2, false); } while (0)
+    trace_kernel("conv_fwd_stem_kernel");
     if (s.Cg == 1) SLAUNCH2(1);
     else if (s.Cg == 2) SLAUNCH2(2);
     else SLAUNCH2(3);
@@ -1094,6 +1096,7 @@ bool conv_backward_weights_stem(const float* x, const float* dy, float* dw, floa
     a.total_rows = s.N * s.OH;
     a.bias_col = dbias ? 1 : 0;
     const dim3 grid((unsigned)blocks, (unsigned)s.groups);
+    trace_kernel("conv_dw_stem_kernel");
     if (s.Cg == 1) conv_dw_stem_kernel<1, 120, 232><<<grid, 512, 0, current_stream()>>>(a);
     else if (s.Cg == 2) conv_dw_stem_kernel<2, 120, 232><<<grid, 512, 0, current_stream()>>>(a);
     else conv_dw_stem_kernel<3, 120, 232><<<grid, 512, 0, current_stream()>>>(a);
@@ -1165,6 +1168,7 @@ bool conv_backward_weights_window(const float* x, const float* dy, float* dw, fl
 #define ROWS_PX 232
 #endif
 #define RLAUNCH1(CGv) do { if (pitch == 232) RLAUNCH2(CGv, 228, ROWS_PX); else RLAUNCH2(CGv, 260, 264); } while (0)
+    trace_kernel("conv_dw_rows_kernel");
     if (s.Cg == 1) RLAUNCH1(1);
     else if (s.Cg == 2) RLAUNCH1(2);
     else RLAUNCH1(3);

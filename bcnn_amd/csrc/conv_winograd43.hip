@@ -617,12 +617,14 @@ static void wino43_run(const float* src, const float* w, float* dst, const ConvS
         }
     }
     const bool rag = (s.H & 3) != 0 || (s.W & 3) != 0;
+    trace_kernel(dx_mode ? "wino43_kernel:dx" : "wino43_kernel:fwd");
     if (a.stats && rag) wino43_kernel<true, true><<<grid, 64 * W4_NW, 0, current_stream()>>>(a);
     else if (a.stats) wino43_kernel<true, false><<<grid, 64 * W4_NW, 0, current_stream()>>>(a);
     else if (rag) wino43_kernel<false, true><<<grid, 64 * W4_NW, 0, current_stream()>>>(a);
     else wino43_kernel<false, false><<<grid, 64 * W4_NW, 0, current_stream()>>>(a);
     KERNEL_CHECK();
     if (a.tail_units > 0) {
+        trace_kernel("wino43_tail_fixup");
         if (a.stats) wino43_tail_fixup_kernel<true><<<(unsigned)(a.tail_units * 8), 256, 0, current_stream()>>>(a);
         else wino43_tail_fixup_kernel<false><<<(unsigned)(a.tail_units * 8), 256, 0, current_stream()>>>(a);
         KERNEL_CHECK();

@@ -1117,6 +1117,7 @@ static void wino_fused_run(const float* src, const float* w, float* dst, const C
         fprintf(stderr, "[bcnn_hip] fused Winograd: output statistics are taken on the raw convolution output only\n");
         abort();
     }
+    trace_kernel(dx_mode ? "wino_fused_kernel:dx" : "wino_fused_kernel:fwd");
     if (parts == 2) wino_bf16_launch<2>(a, w, s, dx_mode, grid, plain);
     else if (parts == 3) wino_bf16_launch<3>(a, w, s, dx_mode, grid, plain);
     else if (a.stats) wino_fused_kernel<0, true><<<grid, 512, 0, current_stream()>>>(a);
@@ -1125,6 +1126,7 @@ static void wino_fused_run(const float* src, const float* w, float* dst, const C
     else wino_fused_kernel<2, false><<<grid, 512, 0, current_stream()>>>(a);
     KERNEL_CHECK();
     if (a.tail_units > 0) {
+        trace_kernel("wino_tail_fixup");
         if (a.stats) wino_tail_fixup_kernel<true><<<(unsigned)(a.tail_units * 16), 256, 0, current_stream()>>>(a);
         else wino_tail_fixup_kernel<false><<<(unsigned)(a.tail_units * 16), 256, 0, current_stream()>>>(a);
         KERNEL_CHECK();
@@ -1563,6 +1565,7 @@ bool conv_backward_weights_winograd_fused(const float* x, const float* dy, float
     a.x_bytes = (unsigned)((size_t)s.N * s.C * s.HW * 4);
     a.dy_bytes = (unsigned)((size_t)s.N * s.F * s.HW * 4);
     const int nob = p.fblocks * p.cblocks;
+    trace_kernel("wino_dw_fused_kernel");
     if (s.W & 1) wino_dw_fused_kernel<true><<<(unsigned)(p.splits * nob), 512, 0, current_stream()>>>(a);
     else wino_dw_fused_kernel<false><<<(unsigned)(p.splits * nob), 512, 0, current_stream()>>>(a);
     KERNEL_CHECK();

@@ -797,6 +797,7 @@ bool depthwise_forward_march(const float* x, const float* w, const float* bias, 
     a.in = in ? *in : DwBnIn{nullptr, nullptr, nullptr, nullptr, 0};
     const unsigned waves = dwm_waves(a.g, (long long)s.N * s.C), blocks = (waves + 3) / 4;
     hipStream_t st = current_stream();
+    trace_kernel(in ? "dwm_fwd_kernel:bnin" : "dwm_fwd_kernel");
     // rows requested ahead: 2 for 16-byte lanes at stride 1 (with the producer's batch-norm applied on load the kernel is vector-ALU
     // bound and 4 costs it two waves per SIMD), 4 at stride 2 and for the 8- / 4-byte lanes of small planes (latency bound)
     int pf = (s.stride == 2 || a.g.V < 4) ? 4 : 2;
@@ -878,6 +879,7 @@ bool depthwise_backward_march(const float* x, const float* w, const float* y, fl
     }
     const unsigned waves = dwm_waves(a.g, (long long)s.N * s.C), blocks = (waves + 3) / 4;
     hipStream_t st = current_stream();
+    trace_kernel(bn && in ? "dwm_bwd_kernel:bn+bnin" : bn ? "dwm_bwd_kernel:bn" : in ? "dwm_bwd_kernel:bnin" : "dwm_bwd_kernel");
     bool relu = act == BCNN_HIP_ACT_RELU && (!in || in->act == BCNN_HIP_ACT_RELU);
     if (BCNN_EXP_ENV("BCNN_HIP_DWM_NORELU")) relu = false;  // A/B switch (experiment build only)
 #define DWM_LAUNCH_O(SV, VV, RV, OV)                                                                                \

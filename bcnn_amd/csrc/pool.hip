@@ -458,6 +458,7 @@ void bcnn_hip_maxpool_forward_bn_keep(const float* x, float* y, int* indexes, in
         exit(1);
     }
     KTimer kt(K_POOL, 0.0, 4.0 * ((double)n * c * h * w + 2.0 * (double)total));
+    trace_kernel("maxpool_fwd_s2_bn_kernel");
     constexpr int R = 4;
     const long long items = (long long)n * c * ((out_h + R - 1) / R) * ((out_w + 1) / 2);
     const unsigned blocks = (unsigned)((items + 255) / 256);
@@ -512,6 +513,7 @@ void bcnn_hip_maxpool_bn_backward(const float* dpool, const int* indexes, const 
     KTimer kt(K_POOL, 0.0, 4.0 * (2.0 * (double)total + 2.0 * (double)ptotal));
     dim3 grid((unsigned)ceil_div(h * (w / 4), 256), (unsigned)(n * c));
     const unsigned w4 = (unsigned)(w / 4);
+    trace_kernel("maxpool_bwd_pair_bn_kernel");
     maxpool_bwd_pair_bn_kernel<<<grid, 256, 0, current_stream()>>>(dpool, indexes, raw, dx, c, h, w, out_h, out_w, consts,
                                                                    w4 > 1 ? (unsigned)((0x100000000ULL + w4 - 1) / w4) : 0u, fM,
                                                                    1.0f / fM, act);

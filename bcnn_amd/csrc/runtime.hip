@@ -35,6 +35,16 @@ KTimer::~KTimer() {
     if (idx >= 0) HIP_CHECK(hipEventRecord((*g_records)[idx].b, g_stream));
 }
 
+// ---- dispatch trace ------------------------------------------------------------------------------
+thread_local bool g_trace_on = false;
+static thread_local std::vector<char>* g_trace_log = nullptr;
+void trace_kernel_slow(const char* name) {
+    if (!g_trace_log) g_trace_log = new std::vector<char>();
+    if (g_trace_log->size() > (8u << 20)) return;  // a forgotten trace must not grow without bound
+    g_trace_log->insert(g_trace_log->end(), name, name + strlen(name));
+    g_trace_log->push_back('\n');
+}
+
 // The first device-touching HIP call initialises the runtime, and that initialisation re-seeds / consumes libc's
 // rand() (measured: srand(7); hipMalloc; rand() differs from run to run, tools/exp/dbg_rand.py). The reference's
 // builders -- and this build's, for source compatibility -- draw their initial weights from rand()
@@ -231,6 +241,21 @@ void bcnn_hip_profile_read(int cls, double* ms, long long* launches, double* flo
     if (launches) *launches = n;
     if (flops) *flops = f;
     if (bytes) *bytes = b;
+}
+
+void bcnn_hip_trace_enable(int on) {
+    g_trace_on = (on != 0);
+    if (on && g_trace_log) g_trace_log->clear();
+}
+
+size_t bcnn_hip_trace_read(char* buf, size_t cap) {
+    const size_t len = g_trace_log ? g_trace_log->size() : 0;
+    if (buf && cap > 0) {
+        const size_t n = len < cap - 1 ? len : cap - 1;
+        if (n) memcpy(buf, g_trace_log->data(), n);
+        buf[n] = 0;
+    }
+    return len;
 }
 
 double bcnn_hip_profile_read_useful_flops(int cls) {

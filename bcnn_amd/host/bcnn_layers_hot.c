@@ -235,7 +235,7 @@ void bcnn_backward_conv_layer(bcnn_net *net, bcnn_node *node) {
                                      mp->stride, io.scales->data_gpu, io.scales->grad_data_gpu, io.b->data_gpu,
                                      io.b->grad_data_gpu, p->saved_mean.data_gpu, p->saved_variance.data_gpu,
                                      p->saved_mean.grad_data_gpu, p->saved_variance.grad_data_gpu, (int)p->activation);
-        bcnn_hip_conv_backward_bn_done(io.x->data_gpu, io.w->data_gpu, io.y->grad_data_gpu, io.x->grad_data_gpu,
+        bcnn_hip_conv_backward_bn_done(xin, io.w->data_gpu, io.y->grad_data_gpu, io.x->grad_data_gpu,
                                        io.w->grad_data_gpu, io.x->n, io.x->c, io.x->h, io.x->w, p->num, p->size, p->stride,
                                        p->pad, p->num_groups, p->conv_workspace_gpu, hctx(net)->workspace_size);
         return;
@@ -247,7 +247,7 @@ void bcnn_backward_conv_layer(bcnn_net *net, bcnn_node *node) {
         bcnn_tensor *r = &net->tensors[en->src[1]], *out = &net->tensors[en->dst[0]];
         ep->deferred = 0;
         ep->grad_pending = 1;
-        bcnn_hip_conv_backward_residual(io.x->data_gpu, io.w->data_gpu, io.b->data_gpu, io.y->grad_data_gpu, io.x->grad_data_gpu,
+        bcnn_hip_conv_backward_residual(xin, io.w->data_gpu, io.b->data_gpu, io.y->grad_data_gpu, io.x->grad_data_gpu,
                                         io.w->grad_data_gpu, io.b->grad_data_gpu, io.x->n, io.x->c, io.x->h, io.x->w,
                                         p->num, p->size, p->stride, p->pad, p->num_groups, io.scales->data_gpu,
                                         io.scales->grad_data_gpu, p->saved_mean.data_gpu, p->saved_variance.data_gpu,

@@ -73,6 +73,14 @@ void bcnn_hip_profile_read(int cls, double *ms, long long *launches, double *flo
 /* the part of the class's `flops` that is not tile padding (Winograd classes on odd-sized planes; otherwise == flops) */
 double bcnn_hip_profile_read_useful_flops(int cls);
 
+/* Dispatch trace (test aid, off by default): while enabled every dispatcher decision of the calling thread appends the name
+ * of the kernel family it launched ("wino43_kernel", "wino43_tail_fixup", "wino_fused_kernel", "maxpool_bwd_pair_bn", ...),
+ * one per line, so a parity test can assert WHICH kernels produced the tensors it compares instead of assuming the
+ * size-dependent dispatch rules. enable(1) clears the log; read() copies at most cap - 1 bytes + a terminating 0 and
+ * returns the full length of the log. */
+void bcnn_hip_trace_enable(int on);
+size_t bcnn_hip_trace_read(char *buf, size_t cap);
+
 /* ---------------------------------------------------------------------------------------------
  * BLAS-1 / per-channel helpers.  Replaces bcnn_cuda_axpy/scal/copy (bcnn_mat.cu:44-100),
  * bcnn_cuda_add_bias / bcnn_cuda_grad_bias (bcnn_mat.cu:348-391), bcnn_scales_gpu /

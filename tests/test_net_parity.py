@@ -86,6 +86,24 @@ def depthwise_small_planes_graph(net):
     net.avgpool(src, "avg")
 
 
+def linear_bottleneck_graph(net):
+    """MobileNet-v2 style tails around a FOLDED batch-norm: [depthwise] -> [batchnorm] -> [1x1 conv + BN,
+    no activation] -> eltwise (the convolution's backward rides on the eltwise node: bcnn_hip_conv_backward_residual), and the
+    same chain in front of a 3x3 / s2 max-pooling (bcnn_hip_conv_backward_bn_done). In both branches the weight gradient has
+    to be formed against the batch-norm's INPUT with the fold's column factors, not against the batch-norm's (unwritten)
+    output tensor. 40 channels: the LDS-DMA GEMM that takes the fold wants more than 32 filters."""
+    net.conv(40, 3, 1, 1, 1, 1, rb.ACT_RELU, "input", "stem")
+    net.depthwise(3, 1, 1, rb.ACT_RELU, "stem", "dw1")
+    net.batchnorm("dw1", "dwbn1")
+    net.conv(40, 1, 1, 0, 1, 1, rb.ACT_NONE, "dwbn1", "pw1")
+    net.eltwise(rb.ACT_RELU, "stem", "pw1", "res1")
+    net.depthwise(3, 1, 1, rb.ACT_RELU, "res1", "dw2")
+    net.batchnorm("dw2", "dwbn2")
+    net.conv(48, 1, 1, 0, 1, 1, rb.ACT_RELU, "dwbn2", "pw2")
+    net.maxpool(3, 2, rb.PADDING_SAME, "pw2", "p2")
+    net.avgpool("p2", "avg")
+
+
 def prelu_node_graph(net):
     """a stand-alone PReLU activation node (the only stand-alone activation the reference's CPU build can run,
     bcnn_activation_layer.c:148-163): its slopes are stepped with batch_size = weights->n = 1, not the net's
@@ -106,6 +124,13 @@ GRAPHS = {
     "lenet": (lenet_graph, dict(w=12, h=12, c=1, n=16), True),
     "mobilenet_unit": (depthwise_graph, dict(w=16, h=16, c=3, n=2), False),
     "mobilenet_small_planes": (depthwise_small_planes_graph, dict(w=56, h=56, c=3, n=4), False),
+    "linear_bottleneck": (linear_bottleneck_graph, dict(w=16, h=16, c=3, n=4), False),
+}
+
+# graphs whose point is a particular fused path: the dispatch trace (include/bcnn_hip.h) must show it ran
+EXPECT_TRACE = {
+    "linear_bottleneck": ["bnfold:fwd", "bnfold:dw", "maxpool_fwd_s2_bn_kernel", "maxpool_bwd_pair_bn_kernel"],
+    "mobilenet_small_planes": ["bnfold:fwd", "bnfold:dw", "dwm_fwd_kernel:bnin"],
 }
 
 
@@ -176,6 +201,8 @@ def test_net_matches_reference(gname):
         hip.data(1)[...] = lab
         hip.upload(1)
     last = nt - 1
+    from bcnn_amd import _lib
+    _lib.load().bcnn_hip_trace_enable(1)
     for it in range(2):  # two steps: the second one runs on updated weights and the momentum carry
         ref.forward()
         hip.forward()
@@ -200,6 +227,13 @@ def test_net_matches_reference(gname):
         for i in range(2, nt):
             hip.download(i)
             _compare("%s it%d %s data after update" % (gname, it, names[i]), hip.data(i), ref.data(i))
+    tl = _lib.load().bcnn_hip_trace_read(None, 0)
+    tbuf = ctypes.create_string_buffer(tl + 1)
+    _lib.load().bcnn_hip_trace_read(tbuf, tl + 1)
+    _lib.load().bcnn_hip_trace_enable(0)
+    ran = set(tbuf.value.decode().split())
+    missing = [k for k in EXPECT_TRACE.get(gname, []) if k not in ran]
+    assert not missing, "%s: %s did not run (trace: %s)" % (gname, missing, sorted(ran))
     # bit-exact pooling indices
     nn = ref.L.ref_num_nodes(ref.net)
     import torch
