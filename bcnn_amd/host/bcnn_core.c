@@ -865,6 +865,11 @@ void *bcnn_get_node_state(bcnn_net *net, int node, int which) {
         sv = &((bcnn_batchnorm_param *)nd->param)->saved_variance;
     }
     if (!sm) return NULL;
+    if (which == 5) { /* the pre-normalisation values the backward pass works from (the reference's param->workspace) */
+        if (nd->type == BCNN_LAYER_CONV2D) return ((bcnn_conv_param *)nd->param)->bn_workspace_gpu;
+        const bcnn_batchnorm_param *bp = (const bcnn_batchnorm_param *)nd->param;
+        return (bp->input_kept || !bp->workspace_gpu) ? net->tensors[nd->src[0]].data_gpu : bp->workspace_gpu;
+    }
     switch (which) {
         case 1: return sm->data_gpu;
         case 2: return sv->data_gpu;

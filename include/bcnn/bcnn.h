@@ -229,7 +229,9 @@ BCNN_API bcnn_tensor *bcnn_peek_tensor(bcnn_net *net, int index);
 BCNN_API int bcnn_get_num_nodes(bcnn_net *net);
 BCNN_API int bcnn_get_node_tensor(bcnn_net *net, int node, int is_dst, int slot); /* -1 if out of range */
 /* layer-private device state needed by parity tests: which = 0 maxpool indexes (int*), 1 saved_mean,
- * 2 saved_variance, 3 d(saved_mean), 4 d(saved_variance); returns a DEVICE pointer or NULL */
+ * 2 saved_variance, 3 d(saved_mean), 4 d(saved_variance), 5 the pre-normalisation values a batch-norm's backward works
+ * from (the reference's param->workspace: a fused-BN convolution's raw output / a batch-norm node's kept input);
+ * returns a DEVICE pointer or NULL */
 BCNN_API void *bcnn_get_node_state(bcnn_net *net, int node, int which);
 /* Run ONE node's forward / backward worker on whatever its tensors currently hold (no executor bookkeeping:
  * no zero fill of the dst gradients, no dead-fill elision -- a sole-writer gradient is accumulated like in the

@@ -130,7 +130,7 @@ GRAPHS = {
 # graphs whose point is a particular fused path: the dispatch trace (include/bcnn_hip.h) must show it ran
 EXPECT_TRACE = {
     "linear_bottleneck": ["bnfold:fwd", "bnfold:dw", "maxpool_fwd_s2_bn_kernel", "maxpool_bwd_pair_bn_kernel"],
-    "mobilenet_small_planes": ["bnfold:fwd", "bnfold:dw", "dwm_fwd_kernel:bnin"],
+    "mobilenet_small_planes": ["dwm_fwd_kernel:bnin", "dwm_bwd_kernel:bn+bnin"],  # (<= 32 filters: no fold here)
 }
 
 
@@ -139,6 +139,7 @@ ZERO_FLOOR = {
     # sides hold the rounding noise of a sum over N * H * W terms, which grows with the square root of the count (3136
     # terms per channel on this graph's 28 x 28 planes against <= 512 on the others)
     "mobilenet_small_planes": 4e-7,
+    "linear_bottleneck": 4e-7,  # 1024 terms per channel, gradients of O(0.1)
 }
 
 

@@ -12,13 +12,21 @@ bcnn_backward_node of include/bcnn/bcnn.h):
   backward: copy data AND gradients of every tensor the node touches from the reference (the state right before
             its backward) -> run node i's backward on both -> compare the gradients of all its tensors (src
             gradients, weight / bias / scale gradients, the rewritten dst gradient).
-Layer-private state (saved batch statistics, pre-normalisation workspace, max-pool indexes) is each side's own,
-produced by its forward of that same node from identical inputs.
+Max-pool indexes are each side's own, produced by its forward of that same node from identical inputs (and compared
+bit for bit elsewhere). The batch-norm state of a node -- saved mean / variance and the pre-normalisation values its
+backward works from (the reference's param->workspace) -- is TEACHER-FORCED too before the node's backward runs: this
+build recomputes the forward output, and with it the ReLU mask, from those values, and an element whose pre-activation
+lies within the convolution kernel's rounding distance of zero (F(4x4,3x3): ~1e-5 of the tensor's scale) would otherwise
+take the other side of the kink and change the gradient there by a whole term. That is a property of ANY second fp32
+implementation (the reference's own USE_BLAS and in-tree gemm builds sit 1e-6 .. 3e-5 apart), not a
+deviation of the backward kernels under test; the walk counts such elements in the forward comparison (`mask flips`), holds
+them to a small fraction, and the forward bar (1e-4 + element-wise) already bounds how far each of them is from zero.
 
 Where the reference's in-tree gemm is itself wrong (dW for C/g*k*k > 4096, dX for
 F/g > 384; pinned by tests/test_reference_gemm_limits.py) that one tensor is compared against float64 torch on the
 same teacher-forced inputs instead; everything else of the node still against the reference."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -151,10 +159,15 @@ def _walk(graph, shape, classes, **kw):
     worst_elem = {"fwd": (0.0, ""), "bwd": (0.0, "")}
     fp64_checked = []
 
+    survey = os.environ.get("TF_SURVEY")  # diagnostic runs: print every tensor's deviation, assert nothing
+
     def check(kind, a, b, what, tol=TOL, floor=ABS_FLOOR):
         err = _rel(a, b, floor)
         if err > worst[kind][0]:
             worst[kind] = (err, what)
+        if survey:
+            print("TF_SURVEY %s %-28s %.3e" % (kind, what, err))
+            return
         assert err <= tol, (kind, what, err)
         # element-wise bar: |a - b| <= 1e-4 |b| + 1e-5 max|b| (+ the rounding floor of sums that cancel)
         a64, b64 = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
@@ -166,6 +179,7 @@ def _walk(graph, shape, classes, **kw):
         assert ratio[j] <= 1.0, (kind, what, "element %d: %.9g against %.9g = %.2f x its bound" % (j, a64[j], b64[j], ratio[j]))
 
     # ---- forward, node by node ----------------------------------------------------------------------
+    flips = elems = 0
     for i in range(nn):
         src, dst = _node_tensors(ref, i)
         _copy_in(ref, hip, src, False)
@@ -174,6 +188,26 @@ def _walk(graph, shape, classes, **kw):
         for t in dst + src[1:]:
             hip.download(t, False)
             check("fwd", hip.data(t), ref.data(t), "node %d %s" % (i, names[t]))
+        cp = convs.get(i)
+        if cp is not None and cp["bn"] and cp["act"] == rb.ACT_RELU:  # elements on the other side of the ReLU kink
+            flips += int(np.count_nonzero((hip.data(dst[0]) > 0) != (ref.data(dst[0]) > 0)))
+            elems += hip.data(dst[0]).size
+    assert flips <= 1e-4 * max(elems, 1), (flips, elems)
+    from bcnn_amd import _lib
+    h2d = _lib.load().bcnn_hip_memcpy_h2d
+
+    def force_bn_state(i, dst_t):
+        """the reference's batch statistics and pre-normalisation values of node i -> this build's node state"""
+        shp = ref.shape(dst_t)
+        ws = ref.bn_field(i, 5, int(np.prod(shp)))
+        if ws is None:
+            return
+        for which_hip, which_ref, n in ((5, 5, int(np.prod(shp))), (1, 0, shp[1]), (2, 1, shp[1])):
+            p = hip.node_state(i, which_hip)
+            v = np.ascontiguousarray(ref.bn_field(i, which_ref, n), np.float32)
+            assert p, (i, which_hip)
+            h2d(p, v.ctypes.data, v.nbytes)
+
     # ---- backward, node by node, on the reference's own gradient chain -------------------------------
     for i in range(nn - 1, -1, -1):
         src, dst = _node_tensors(ref, i)
@@ -186,6 +220,7 @@ def _walk(graph, shape, classes, **kw):
             if ref.grad(x_t) is not None:
                 pre_dx = ref.grad(x_t).copy()
         pre_dy = ref.grad(dst[0]).copy() if ref.grad(dst[0]) is not None else None
+        force_bn_state(i, dst[0])
         ref.backward_node(i)
         hip.backward_node(i)
         for t in ids:
@@ -231,6 +266,8 @@ def _walk(graph, shape, classes, **kw):
             check("bwd", hip.grad(t), ref.grad(t), what, floor=floor)
     ref.close()
     hip.close()
+    print("teacher-forced %s: %d of %d ReLU outputs of fused-BN convolutions on the other side of the kink (mask flips)"
+          % (graph, flips, elems))
     print("teacher-forced %s: worst relative deviation fwd %.2e (%s), bwd %.2e (%s); %d tensors vs float64 + oracle"
           % (graph, worst["fwd"][0], worst["fwd"][1], worst["bwd"][0], worst["bwd"][1], len(fp64_checked)))
     print("teacher-forced %s: worst element against its own bound (1e-4 |ref| + 1e-5 max|ref|): fwd %.3f (%s), bwd %.3f (%s)"
