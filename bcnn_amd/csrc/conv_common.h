@@ -66,6 +66,7 @@ struct WinoPackJob {
     int F, C, dx_mode, Jpad, Mpad;
     int blocks;  // of 256 threads
     int npos;    // 16: G g G^T of F(2x2,3x3) (conv_winograd_fused.hip); 36: of F(4x4,3x3) (conv_winograd43.hip)
+    int layout;  // npos 36 only: wino43_pack_one's layout (1: the stage order of conv_winograd43b.hip)
 };
 constexpr int kPackMaxTaps = 49;
 struct IgemmPackJob {

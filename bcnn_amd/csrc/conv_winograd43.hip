@@ -23,6 +23,7 @@
 // is the precedent for computing these layers in a transformed domain; the transform matrices are Lavin & Gray's F(4x4,3x3).
 #include "conv_common.h"
 #include "lds_dma.h"
+#include "wino43_math.h"
 #include "wino43_pack.h"
 
 // Timing experiments (tools/exp/variant.sh NAME conv_winograd43 "-DW43_ABL_..."; normal builds define none of them; results
@@ -68,26 +69,6 @@ __device__ __forceinline__ float w43_half_sum(float v) {
     return v;
 }
 
-// one 6-vector through B^T: (4 d0 - 5 d2 + d4, -4 d1 - 4 d2 + d3 + d4, 4 d1 - 4 d2 - d3 + d4, -2 d1 - d2 + 2 d3 + d4,
-//                            2 d1 - d2 - 2 d3 + d4, 4 d1 - 5 d3 + d5) -- 13 instructions
-__device__ __forceinline__ void w43_bt(const float (&d)[6], float (&t)[6]) {
-    const float a = __builtin_fmaf(-4.f, d[2], d[4]), b = __builtin_fmaf(-4.f, d[1], d[3]);
-    const float c = d[4] - d[2], e = 2.f * (d[3] - d[1]);
-    t[0] = __builtin_fmaf(4.f, d[0], __builtin_fmaf(-5.f, d[2], d[4]));
-    t[1] = a + b;
-    t[2] = a - b;
-    t[3] = c + e;
-    t[4] = c - e;
-    t[5] = __builtin_fmaf(4.f, d[1], __builtin_fmaf(-5.f, d[3], d[5]));
-}
-// one 6-vector through A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
-__device__ __forceinline__ void w43_at(const float (&m)[6], float (&y)[4]) {
-    const float s1 = m[1] + m[2], d1 = m[1] - m[2], s2 = m[3] + m[4], d2 = m[3] - m[4];
-    y[0] = m[0] + s1 + s2;
-    y[1] = __builtin_fmaf(2.f, d2, d1);
-    y[2] = __builtin_fmaf(4.f, s2, s1);
-    y[3] = __builtin_fmaf(8.f, d2, d1) + m[5];
-}
 
 // RAG: planes that are not whole 4 x 4 tiles (14 x 14, 7 x 7): the last tile row / column hangs over -- rows beyond H arrive
 // as zeros through the row test, columns beyond W (which a 16-byte row load takes from the NEXT image row) are zeroed by
@@ -533,6 +514,17 @@ static float* w43_tail_scratch(size_t floats) {
     return sc.p;
 }
 
+// conv_winograd43b.hip: the second form of the kernel (16 x 16 MFMA tiles, output transform in registers), whole-tile planes
+void wino43b_run(const float* src, const float* w, float* dst, const ConvShape& s, int dx_mode, ConvStats* stats);
+int wino43b_stats_slots(const ConvShape& s);
+void wino43b_pack_dims(int J, int M, int* Jpad, int* Mpad);
+// which form takes a wanted layer: the second one wherever the planes are whole tiles (experiment build: BCNN_HIP_W43_FORM=1
+// keeps everything on the first form)
+static bool wino43_second_form(const ConvShape& s) {
+    static const int forced_first = BCNN_EXP_ENV("BCNN_HIP_W43_FORM") ? (BCNN_EXP_ENV("BCNN_HIP_W43_FORM")[0] == '1') : 0;
+    return !forced_first && (s.H & 3) == 0 && (s.W & 3) == 0;
+}
+
 static int g_w43_force = -1;  // experiment build: BCNN_HIP_WINOGRAD43=0/1 overrides the rule
 bool wino43_wanted(const ConvShape& s, int J, int M) {
     if (s.ksz != 3 || s.stride != 1 || s.pad != 1 || s.groups != 1) return false;
@@ -566,7 +558,8 @@ static bool wino43_usable(const float* src, const float* dst, const ConvShape& s
     if (stats && stats->partials) {
         const long long T = (long long)s.N * ((s.H + 3) / 4) * ((s.W + 3) / 4);
         const int M = dx_mode ? s.C : s.F;
-        if ((size_t)M * (size_t)ceil_div(T, W4_BT) * 2 > stats->capacity) return false;
+        const size_t slots = wino43_second_form(s) ? (size_t)wino43b_stats_slots(s) : (size_t)ceil_div(T, W4_BT);
+        if ((size_t)M * slots * 2 > stats->capacity) return false;
     }
     return true;
 }
@@ -641,6 +634,11 @@ bool wino43_pack_plan(const ConvShape& s, int dx_mode, WinoPackJob* job, size_t*
     job->F = s.F; job->C = s.C; job->dx_mode = dx_mode;
     job->Jpad = (J + W4_KC - 1) / W4_KC * W4_KC;
     job->Mpad = (M + W4_BF - 1) / W4_BF * W4_BF;
+    job->layout = 0;
+    if (wino43_second_form(s)) {
+        wino43b_pack_dims(J, M, &job->Jpad, &job->Mpad);
+        job->layout = 1;
+    }
     job->blocks = (int)ceil_div((long long)job->Jpad * job->Mpad, 256);
     job->npos = W4_NP;
     *floats = (size_t)W4_NP * job->Jpad * job->Mpad;
@@ -658,14 +656,16 @@ static double w43_bytes(const ConvShape& s) {
 bool conv_forward_winograd43(const float* x, const float* w, float* y, const ConvShape& s, int raw, ConvStats* stats) {
     if (!raw || !wino43_wanted(s, s.C, s.F) || !wino43_usable(x, y, s, 0, stats)) return false;
     KTimer kt(K_CONV_FWD_WINO, w43_flops(s), w43_bytes(s), w43_useful_flops(s));
-    wino43_run(x, w, y, s, 0, stats);
+    if (wino43_second_form(s)) wino43b_run(x, w, y, s, 0, stats);
+    else wino43_run(x, w, y, s, 0, stats);
     return true;
 }
 
 bool conv_backward_data_winograd43(const float* w, const float* dy, float* dx, const ConvShape& s) {
     if (!wino43_wanted(s, s.F, s.C) || !wino43_usable(dy, dx, s, 1, nullptr)) return false;
     KTimer kt(K_CONV_DX_WINO, w43_flops(s), w43_bytes(s), w43_useful_flops(s));
-    wino43_run(dy, w, dx, s, 1, nullptr);
+    if (wino43_second_form(s)) wino43b_run(dy, w, dx, s, 1, nullptr);
+    else wino43_run(dy, w, dx, s, 1, nullptr);
     return true;
 }
 

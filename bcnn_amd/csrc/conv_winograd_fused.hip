@@ -960,7 +960,7 @@ __global__ __launch_bounds__(256) void wino_pack_weights_kernel(const float* __r
 __global__ __launch_bounds__(256) void wino_pack_weights_multi_kernel(const WinoPackJob* __restrict__ jobs) {
     const WinoPackJob j = jobs[blockIdx.y];
     if ((int)blockIdx.x >= j.blocks) return;
-    if (j.npos == 36) wino43_pack_one(j.w, j.u, j.F, j.C, j.dx_mode, j.Jpad, j.Mpad, blockIdx.x * 256 + threadIdx.x);
+    if (j.npos == 36) wino43_pack_one(j.w, j.u, j.F, j.C, j.dx_mode, j.Jpad, j.Mpad, blockIdx.x * 256 + threadIdx.x, j.layout);
     else wino_pack_one(j.w, j.u, j.F, j.C, j.dx_mode, j.Jpad, j.Mpad, blockIdx.x * 256 + threadIdx.x);
 }
 
@@ -1148,6 +1148,7 @@ bool wino_fused_pack_plan(const ConvShape& s, int dx_mode, WinoPackJob* job, siz
     job->Mpad = (M + WF_BF - 1) / WF_BF * WF_BF;
     job->blocks = (int)ceil_div((long long)job->Jpad * job->Mpad, 256);
     job->npos = 16;
+    job->layout = 0;
     *floats = (size_t)16 * job->Jpad * job->Mpad;
     return true;
 }

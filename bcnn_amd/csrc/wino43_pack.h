@@ -5,10 +5,13 @@
 
 namespace bcnn_hip {
 
-// U[xi][j][m] = (G g G^T)[xi] packed [36][Jpad][Mpad] with zero padding.
+// U[xi][j][m] = (G g G^T)[xi] with zero padding.
 //   forward: m = f, j = c; dX: m = c, j = f and the filter rotated by 180 degrees
+//   layout 0: [36][Jpad][Mpad] (conv_winograd43.hip)
+//   layout 1: [m / 64][j / 4][xi / 4][j % 4][m % 64][xi % 4] -- the LDS stages of conv_winograd43b.hip, one linear 36 KB run
+//             per (channel block, sub-chunk of 4 reduction channels); Mpad a multiple of 64, Jpad of 8
 __device__ __forceinline__ void wino43_pack_one(const float* __restrict__ w, float* __restrict__ u, int F, int C, int dx_mode,
-                                                int Jpad, int Mpad, int idx) {
+                                                int Jpad, int Mpad, int idx, int layout = 0) {
     if (idx >= Jpad * Mpad) return;
     const int j = idx / Mpad, m = idx - j * Mpad;
     const int M = dx_mode ? C : F, J = dx_mode ? F : C;
@@ -41,12 +44,17 @@ __device__ __forceinline__ void wino43_pack_one(const float* __restrict__ w, flo
     }
     const size_t plane = (size_t)Jpad * Mpad;
     float* dst = u + idx;
+    float* dst1 = u + ((((size_t)(m >> 6) * (Jpad >> 2) + (j >> 2)) * 9 * 4 + (j & 3)) * 64 + (m & 63)) * 4;  // + (xi / 4) * 1024 + xi % 4
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
         float o[6];
         gvec(t[r][0], t[r][1], t[r][2], o);
 #pragma unroll
-        for (int c = 0; c < 6; ++c) dst[(size_t)(6 * r + c) * plane] = o[c];
+        for (int c = 0; c < 6; ++c) {
+            const int xi = 6 * r + c;
+            if (layout == 0) dst[(size_t)xi * plane] = o[c];
+            else dst1[(xi >> 2) * 1024 + (xi & 3)] = o[c];
+        }
     }
 }
 
