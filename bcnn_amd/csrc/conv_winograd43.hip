@@ -655,7 +655,7 @@ static double w43_bytes(const ConvShape& s) {
 // raw output only (a fused batch-norm behind it, or a caller that adds nothing): the other forms stay on F(2x2, 3x3)
 bool conv_forward_winograd43(const float* x, const float* w, float* y, const ConvShape& s, int raw, ConvStats* stats) {
     if (!raw || !wino43_wanted(s, s.C, s.F) || !wino43_usable(x, y, s, 0, stats)) return false;
-    KTimer kt(K_CONV_FWD_WINO, w43_flops(s), w43_bytes(s), w43_useful_flops(s));
+    KTimer kt(K_CONV_FWD_WINO43, w43_flops(s), w43_bytes(s), w43_useful_flops(s));
     if (wino43_second_form(s)) wino43b_run(x, w, y, s, 0, stats);
     else wino43_run(x, w, y, s, 0, stats);
     return true;
@@ -663,7 +663,7 @@ bool conv_forward_winograd43(const float* x, const float* w, float* y, const Con
 
 bool conv_backward_data_winograd43(const float* w, const float* dy, float* dx, const ConvShape& s) {
     if (!wino43_wanted(s, s.F, s.C) || !wino43_usable(dy, dx, s, 1, nullptr)) return false;
-    KTimer kt(K_CONV_DX_WINO, w43_flops(s), w43_bytes(s), w43_useful_flops(s));
+    KTimer kt(K_CONV_DX_WINO43, w43_flops(s), w43_bytes(s), w43_useful_flops(s));
     if (wino43_second_form(s)) wino43b_run(dy, w, dx, s, 1, nullptr);
     else wino43_run(dy, w, dx, s, 1, nullptr);
     return true;

@@ -74,21 +74,42 @@ __device__ __forceinline__ void wb_store_x4(f32x4 v, rsrc_i4 rs, unsigned voff, 
     asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" : : "v"(v), "v"(voff), "s"(rs), "s"(soff) : "memory");
 }
 
-// 36 MFMAs: one reduction step of 4 channels for every position; FIRST: onto zero (a unit's first sub-chunk)
+// 36 MFMAs: one reduction step of 4 channels for every position; FIRST: onto zero (a unit's first sub-chunk). The fragments
+// come in three groups of 3 + 3 ds_read_b128 (twelve positions), each requested while the group before is multiplied: 48
+// registers. Left to itself hipcc hoists all 18 reads to the top (72 registers), which with the 144 accumulators and the
+// 25 patch registers in flight no longer fits.
 template <bool FIRST>
 __device__ __forceinline__ void wb_mma(f32x4 (&acc)[36], const float* up, const float* vp) {
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    f32x4 a4 = *reinterpret_cast<const f32x4*>(up), b4 = *reinterpret_cast<const f32x4*>(vp);
+    f32x4 a4[2][3], b4[2][3];
 #pragma unroll
-    for (int x = 0; x < 9; ++x) {
-        f32x4 an = a4, bn = b4;
-        if (x + 1 < 9) {
-            an = *reinterpret_cast<const f32x4*>(up + (x + 1) * 1024);
-            bn = *reinterpret_cast<const f32x4*>(vp + (x + 1) * 512);
+    for (int x = 0; x < 3; ++x) {
+        a4[0][x] = *reinterpret_cast<const f32x4*>(up + x * 1024);
+        b4[0][x] = *reinterpret_cast<const f32x4*>(vp + x * 512);
+    }
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        __builtin_amdgcn_sched_barrier(0);
+#ifndef WB_ABL_NOLDSRD
+        if (g + 1 < 3) {
+#pragma unroll
+            for (int x = 0; x < 3; ++x) {
+                a4[(g + 1) & 1][x] = *reinterpret_cast<const f32x4*>(up + (3 * (g + 1) + x) * 1024);
+                b4[(g + 1) & 1][x] = *reinterpret_cast<const f32x4*>(vp + (3 * (g + 1) + x) * 512);
+            }
         }
+#endif
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[4 * x + j] = mfma16(a4[j], b4[j], FIRST ? zero : acc[4 * x + j]);
-        a4 = an; b4 = bn;
+        for (int x = 0; x < 3; ++x)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int xi = 12 * g + 4 * x + j;
+#ifdef WB_ABL_NOMFMA
+                acc[xi][0] = (FIRST ? 0.f : acc[xi][0]) + a4[g & 1][x][j] * b4[g & 1][x][j];
+#else
+                acc[xi] = mfma16(a4[g & 1][x][j], b4[g & 1][x][j], FIRST ? zero : acc[xi]);
+#endif
+            }
     }
 }
 
@@ -158,60 +179,89 @@ __global__ __launch_bounds__(64 * WB_NW, 2) void wino43b_kernel(const Wino43bArg
     auto slot_of = [&](const WbCur& c) { return c.it < nreg ? -1 : 2 * bid + (c.it - nreg); };
 
     // ---- patch requests of the transforming role: lane = (channel 2 tw4 + lhi of the period, tile l31 of the tile block) ----
+    // The two columns either side of a lane's own four are the neighbouring lanes' (DPP wave shifts) except at the ends of a
+    // half-wave: lane l31 = 0 lacks its left column, l31 = 31 its right one. Those 2 x 6 values are fetched by lanes that have
+    // nothing else to do in that instruction -- lanes l31 = 1..6 rows 0..5 of lane 0's left column, lanes 25..30 those of lane
+    // 31's right column: ONE dword request per patch instead of six almost empty ones -- and handed over with ds_bpermute when
+    // the patch is transformed.
     unsigned v_mid_ = kOOB;  // byte offset of patch row 1 (image row 4 th), own columns, channel lhi of the wave's pair
-    unsigned pflags = 0;    // 1 row 0 exists, 2 row 5 exists, 4 / 8 left / right neighbour column fetched by this lane, 16 / 32 left / right padding
-    int dec_tb = -1;        // the tile block those belong to (this group's last request)
+    unsigned e_off_ = kOOB;  // byte offset of this lane's edge duty (out of range: none, or that value is padding)
+    unsigned pflags = 0;     // 1 row 0 exists, 2 row 5 exists, 16 / 32 left / right padding
+    int dec_tb = -1;         // the tile block those belong to (this group's last request)
+    auto tile_coords = [&](unsigned t, unsigned& n, int& th, int& tw) {
+        n = t / per_img;
+        const unsigned rr = t - n * per_img;
+        th = (int)(rr / (unsigned)a.TW);
+        tw = (int)(rr - (unsigned)th * (unsigned)a.TW);
+    };
     auto decode = [&](int tb) {
         dec_tb = tb;
         const unsigned t = (unsigned)tb * WB_BT + (unsigned)l31;
         const bool ok = t < a.T;
-        const unsigned n = ok ? t / per_img : 0u;
-        const unsigned rr = ok ? t - n * per_img : 0u;
-        const int th = (int)(rr / (unsigned)a.TW);
-        const int tw = (int)(rr - (unsigned)th * (unsigned)a.TW);
-        v_mid_ = ok ? (n * (unsigned)a.J * (unsigned)HW + (unsigned)lhi * (unsigned)HW) * 4u + (unsigned)(4 * th * a.W + 4 * tw) * 4u : kOOB;
-        const bool pad_l = tw == 0, pad_r = tw + 1 == a.TW;
+        unsigned n = 0; int th = 0, tw = 0;
+        if (ok) tile_coords(t, n, th, tw);
+        const unsigned chan = (unsigned)lhi * (unsigned)HW * 4u;
+        v_mid_ = ok ? n * (unsigned)a.J * (unsigned)HW * 4u + chan + (unsigned)(4 * th * a.W + 4 * tw) * 4u : kOOB;
         // rows 1..4 of a whole tile always exist; rows 0 and 5 are padding at the top / bottom tile row
-        pflags = !ok ? 0u : (th > 0 ? 1u : 0u) | (4 * th + 4 < a.H ? 2u : 0u) | ((l31 == 0 && !pad_l) ? 4u : 0u) |
-                            ((l31 == 31 && !pad_r) ? 8u : 0u) | (pad_l ? 16u : 0u) | (pad_r ? 32u : 0u);
+        pflags = !ok ? 0u : (th > 0 ? 1u : 0u) | (4 * th + 4 < a.H ? 2u : 0u) | (tw == 0 ? 16u : 0u) | (tw + 1 == a.TW ? 32u : 0u);
+        // edge duty: row (l31 - 1) of the first tile's left column / row (l31 - 25) of the last tile's right column
+        const bool left = l31 >= 1 && l31 <= 6, right = l31 >= 25 && l31 <= 30;
+        const unsigned td = (unsigned)tb * WB_BT + (left ? 0u : 31u);
+        const int row = left ? l31 - 1 : l31 - 25;
+        e_off_ = kOOB;
+        if ((left || right) && td < a.T) {
+            unsigned dn; int dth, dtw;
+            tile_coords(td, dn, dth, dtw);
+            const int ih = 4 * dth - 1 + row, iw = left ? 4 * dtw - 1 : 4 * dtw + 4;
+            if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W)
+                e_off_ = dn * (unsigned)a.J * (unsigned)HW * 4u + chan + (unsigned)(ih * a.W + iw) * 4u;
+        }
     };
-    buf_f32x4 p[6];  // a patch: own columns (kept as the 16-byte tuples the requests fill: no copies between request and use)
-    float e[6];      // and the edge lanes' neighbour column (0.0 elsewhere)
-    // live = false: the same twelve instructions with every lane out of range (nothing is fetched, zeros come back). The
-    // requests of a period are issued by ALL waves at one place in the loop, those of the group whose turn it is not as such
-    // blanks: requested under an if / else, the patch registers reach the loop's back edge as a merge of two values, which hipcc
-    // resolves with copies behind an `s_waitcnt vmcnt(0)` -- the requests then have no lead at all.
-    auto load_patch = [&](const WbCur& c, bool live) {
+    // a patch = p[6]: own columns (kept as the 16-byte tuples the requests fill) + eduty: this lane's edge duty.
+    // live = false: the same seven instructions with every lane out of range (nothing is fetched, zeros come back).
+    auto load_patch = [&](const WbCur& c, buf_f32x4 (&p)[6], float& eduty, bool live) {
+#ifdef WB_ABL_NOLOADINSTR
+        return;
+#endif
         if (live && c.tb != dec_tb) decode(c.tb);
         // The row step rides in the scalar offset (the range check sees the vector offset only); out-of-range offsets return 0.0
         const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((c.period() * WB_KP + 2 * tw4) * HW * 4);
-        const unsigned v_mid = live ? v_mid_ : kOOB;
+#ifdef WB_ABL_NOLOAD
+        live = false;
+#endif
+        const unsigned v_mid = live ? v_mid_ : kOOB, e_off = live ? e_off_ : kOOB;
         const unsigned v_top = ((pflags & 1u) && live) ? v_mid - row_bytes : kOOB, v_bot = (pflags & 2u) ? v_mid : kOOB;
-        const unsigned delta = (pflags & 4u) ? (unsigned)-4 : 16u;
-        const bool edge = (pflags & 12u) != 0;
-        const unsigned e_mid = (edge && live) ? v_mid + delta : kOOB;
-        const unsigned e_top = (edge && (pflags & 1u)) ? v_top + delta : kOOB, e_bot = (edge && (pflags & 2u)) ? e_mid : kOOB;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const unsigned so = i == 0 ? soff : (unsigned)__builtin_amdgcn_readfirstlane((int)(soff + (unsigned)(i - 1) * row_bytes));
             p[i] = buffer_load_f32x4(rs_src, (int)(i == 0 ? v_top : i == 5 ? v_bot : v_mid), (int)so, 0);
-            e[i] = buffer_load_f32(rs_src, (int)(i == 0 ? e_top : i == 5 ? e_bot : e_mid), (int)so, 0);
         }
+        eduty = buffer_load_f32(rs_src, (int)e_off, (int)soff, 0);
     };
     // B^T d B -> V[vs][c = tw4 / 2][xi / 4][k = 2 (tw4 % 2) + lhi][tile l31][xi % 4]: nine 16-byte writes, a wave's 64 lanes 1 KB each
-    auto write_v = [&](int vs) {
+    auto write_v = [&](int vs, const buf_f32x4 (&p)[6], const float eduty) {
+#ifdef WB_ABL_NOXFORM
+        { float sum = eduty;
+          for (int i = 0; i < 6; ++i) sum += p[i][0] + p[i][1] + p[i][2] + p[i][3];
+          if (sum == 123.456f) lds[2 * WB_USTAGE + lane] = sum;
+          return; }
+#endif
         const bool pad_l = (pflags & 16u) != 0, pad_r = (pflags & 32u) != 0;
+        // the edge values: lane l31 = 0 takes row i from lane + 1 + i, lane l31 = 31 from lane - 6 + i (others: unused)
+        const int esrc = 4 * (l31 == 0 ? lane + 1 : lane - 6);
         float tt[6][6];  // columns first: tt[.][j] = B^T d[.][j]
-        {   // the two neighbour columns first: they read the neighbouring lanes' own columns, which are overwritten below
+        {   // the two neighbour columns first: they read the neighbouring lanes' own columns
             float cl[6], cr[6], out[6];
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
-                const int ev = __builtin_bit_cast(int, e[i]);
-                // lane l - 1's last own column; the first lane of a half-wave fetched its own
-                const int l = __builtin_amdgcn_update_dpp(ev, __builtin_bit_cast(int, p[i][3]), 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+                const int ev = __builtin_amdgcn_ds_bpermute(esrc + 4 * i, __float_as_int(eduty));
+                // (through scalars: hipcc 7.2 reads element 0 for `__builtin_bit_cast(int, vector[3])`)
+                const float own_first = p[i][0], own_last = p[i][3];
+                // lane l - 1's last own column; the first lane of a half-wave takes the fetched value
+                const int l = __builtin_amdgcn_update_dpp(ev, __float_as_int(own_last), 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
                 cl[i] = pad_l ? 0.f : __builtin_bit_cast(float, l31 == 0 ? ev : l);
                 // lane l + 1's first own column
-                const int r = __builtin_amdgcn_update_dpp(ev, __builtin_bit_cast(int, p[i][0]), 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+                const int r = __builtin_amdgcn_update_dpp(ev, __float_as_int(own_first), 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
                 cr[i] = pad_r ? 0.f : __builtin_bit_cast(float, l31 == 31 ? ev : r);
             }
             w43_bt(cl, out);
@@ -242,6 +292,9 @@ __global__ __launch_bounds__(64 * WB_NW, 2) void wino43b_kernel(const Wino43bArg
     };
     // one KB piece of a U sub-chunk: the packed weights hold every (channel block, sub-chunk) stage as 36 linear pieces
     auto dma_u = [&](const WbCur& c, int sub, int piece) {
+#ifdef WB_ABL_NODMA
+        return;
+#endif
         const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(((c.mb() * nc4 + 2 * c.period() + sub) * 36 + piece) * 1024);
         dma_row_x4(rs_u, lds0 + (unsigned)((sub * WB_USTAGE) * 4 + piece * 1024), (unsigned)lane * 16u, soff);
     };
@@ -252,6 +305,12 @@ __global__ __launch_bounds__(64 * WB_NW, 2) void wino43b_kernel(const Wino43bArg
 
     // A^T M A on the accumulators, stores and statistics of item c (the wave's 16 channels x 16 tiles)
     auto epilogue = [&](const WbCur& c) {
+#ifdef WB_ABL_NOEPI
+        { float sum = 0.f;
+          for (int x = 0; x < 36; ++x) sum += acc[x][0] + acc[x][1] + acc[x][2] + acc[x][3];
+          if (sum == 123.456f) a.dst[0] = sum;
+          return; }
+#endif
         const unsigned t = (unsigned)c.tb * WB_BT + (unsigned)(16 * tbw + l15);
         const bool ok = t < a.T;
         const unsigned n = ok ? t / per_img : 0u;
@@ -310,44 +369,56 @@ __global__ __launch_bounds__(64 * WB_NW, 2) void wino43b_kernel(const Wino43bArg
         }
     };
 
-    // ---- prologue: period 0's V and first U sub-chunk into stage 0; period 1's patches into group 1's registers ----
+    // ---- prologue: period 0's V (group 0) and first U sub-chunk into stage 0; period 1's patches into group 1's registers ----
     WbCur c0, c1, c2;
     load_item(0, c0);
     c1 = c0; advance(c1);
     c2 = c1; advance(c2);
     for (int q = wid; q < 36; q += WB_NW) dma_u(c0, 0, q);  // older than the patch requests below
+    buf_f32x4 p[6]; float eduty;
     if (grp == 0) {
-        load_patch(c0, true);
+        load_patch(c0, p, eduty, true);
         dma_wait();
-        write_v(0);
+        write_v(0, p, eduty);
     }
-    load_patch(c1, grp == 1 && c1.valid());  // (blanks in group 0)
-    dma_wait_n<12>();                        // the U pieces have landed; the twelve patch requests fly on
+    load_patch(c1, p, eduty, grp == 1 && c1.valid());  // (blanks in group 0)
+    dma_wait_n<7>();                                   // the U pieces have landed; the seven patch requests fly on
 
-    int gp = 0;
-    while (c0.valid()) {
-        const int tgrp = (gp + 1) & 1;  // this period's transforming / U-requesting group
+    // The stream of periods. Roles alternate per group and period: in period gp the group T = (gp + 1) & 1 transforms the NEXT
+    // period's V -- after its MFMAs of the first sub-chunk, from the patches it requested a period ago in the other role -- and
+    // requests that period's U stage 0 in the second sub-chunk; the group R requests this period's U stage 1 right behind
+    // the first barrier and, after its MFMAs, the patches of period gp + 2 (its U pieces are OLDER than its patch requests, so
+    // `vmcnt(7)` waits for exactly them: one in-order counter per wave). What the order of these blocks owes to hipcc: the patch
+    // registers are (re)defined at ONE place of the loop by both roles (T: blank requests -- every lane out of range, nothing
+    // fetched -- behind its use), so they reach the back edge as one value; requested under one branch and used under another,
+    // or defined as zeros on the other path, they are merged with copies behind `s_waitcnt vmcnt(0)` and the request loses
+    // its lead.
+    for (int gp = 0; c0.valid(); ++gp) {
+        const bool t_role = grp == ((gp + 1) & 1);
         const int vs = gp & 1;
         // ---- first sub-chunk: U stage 0, V[vs][0] ----
+#ifndef WB_ABL_NOBAR
         lds_barrier();  // U stage 0 and V stage vs are complete; the other stages' readers are done
-        if (grp == tgrp) {
-            if (c1.valid()) {
-                dma_wait();  // the patches of the next period (requested a period ago, as the other role)
-                write_v(vs ^ 1);
-            }
-            // (behind the transform: the compiler's own counted waits for the patch registers would otherwise take these in)
+#endif
+        if (!t_role) {
 #pragma unroll
             for (int q = 0; q < 9; ++q) dma_u(c0, 1, 9 * tw4 + q);
         }
-        load_patch(c2, grp != tgrp && c2.valid());
         __builtin_amdgcn_sched_barrier(0);
         if (c0.kp() == 0) wb_mma<true>(acc, ufrag, vfrag + vs * WB_VSTAGE);
         else wb_mma<false>(acc, ufrag, vfrag + vs * WB_VSTAGE);
         __builtin_amdgcn_sched_barrier(0);
+        if (t_role && c1.valid()) {
+            dma_wait();  // the patches (and whatever an epilogue stored since)
+            write_v(vs ^ 1, p, eduty);
+        }
+        load_patch(c2, p, eduty, !t_role && c2.valid());
         // ---- second sub-chunk: U stage 1, V[vs][1] ----
-        if (grp == tgrp) dma_wait();  // its pieces of U stage 1 (its patches are consumed: nothing else is in flight)
+        if (!t_role) dma_wait_n<7>();  // its pieces of U stage 1 (older than the seven requests)
+#ifndef WB_ABL_NOBAR
         lds_barrier();
-        if (grp == tgrp && c1.valid()) {
+#endif
+        if (t_role && c1.valid()) {
 #pragma unroll
             for (int q = 0; q < 9; ++q) dma_u(c1, 0, 9 * tw4 + q);
         }
@@ -356,10 +427,9 @@ __global__ __launch_bounds__(64 * WB_NW, 2) void wino43b_kernel(const Wino43bArg
         __builtin_amdgcn_sched_barrier(0);
         // its pieces of the next period's U stage 0 have had 36 MFMAs to land; waiting here, before an epilogue puts stores
         // into the same counter, keeps the next barrier free of memory waits
-        if (grp == tgrp) dma_wait();
+        if (t_role) dma_wait();
         if (c0.kp() + 1 == c0.np()) epilogue(c0);
         c0 = c1; c1 = c2; advance(c2);
-        ++gp;
     }
 }
 

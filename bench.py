@@ -207,13 +207,15 @@ def roofline_of(prof, workload, traffic_ok):
     """roofline of the class that takes the most time inside the timed region"""
     if not prof:
         return None
-    # ONE kernel (wino_fused_kernel) serves the forward and the dX class of the Winograd layers: the dominant KERNEL is
-    # judged on both together (the per-class figures stay in `kernel_classes`)
+    # Each Winograd kernel serves the forward AND the dX class of its layers (wino_fused_kernel: F(2x2,3x3), classes
+    # *_winograd; wino43b_kernel: F(4x4,3x3), classes *_winograd43): a dominant KERNEL is judged on both of its classes together
+    # (the per-class figures stay in `kernel_classes`)
     prof = dict(prof)
-    fw, dx = prof.pop("conv_fwd_winograd", None), prof.pop("conv_dx_winograd", None)
-    if fw or dx:
-        parts = [p for p in (fw, dx) if p]
-        prof["conv_fwd_dx_winograd"] = {k: sum(p[k] for p in parts) for k in ("ms", "launches", "flops", "bytes", "useful_flops")}
+    for suffix in ("winograd", "winograd43"):
+        fw, dx = prof.pop("conv_fwd_" + suffix, None), prof.pop("conv_dx_" + suffix, None)
+        if fw or dx:
+            parts = [p for p in (fw, dx) if p]
+            prof["conv_fwd_dx_" + suffix] = {k: sum(p[k] for p in parts) for k in ("ms", "launches", "flops", "bytes", "useful_flops")}
     name, d = max(prof.items(), key=lambda kv: kv[1]["ms"])
     avg_ms = d["ms"] / d["launches"]
     tf = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["flops"] else 0.0
@@ -226,15 +228,17 @@ def roofline_of(prof, workload, traffic_ok):
     else:
         roof = {"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
-    traffic, source = (pmc_traffic(workload, "conv_fwd_winograd" if name == "conv_fwd_dx_winograd" else name) if traffic_ok
+    traffic, source = (pmc_traffic(workload, name.replace("conv_fwd_dx_", "conv_fwd_")) if traffic_ok
                        else (None, "non-default batch or variant: no PMC summary applies"))
     if "winograd" in name:
-        # the class timers of the Winograd kernels carry the FLOPs the MFMAs really execute (16 instead of 36
-        # multiplies per 2x2 outputs: DESIGN.md section 4.8); the direct-convolution count of the same layers is 2.25x that
-        roof["flops_counted"] = ("executed (Winograd transformed domain); direct-equivalent rate = 2.25 x the rate of the "
-                                 "multiplies that are not tile padding")
+        # the class timers of the Winograd kernels carry the FLOPs the MFMAs really execute -- 16 instead of 36 multiplies
+        # per 2 x 2 outputs for F(2x2,3x3), 36 instead of 144 per 4 x 4 outputs for F(4x4,3x3)
+        # (section 4.9): the direct-convolution count of the same layers is 2.25x / 4x that
+        factor = 4.0 if name.endswith("43") else 2.25
+        roof["flops_counted"] = ("executed (Winograd transformed domain); direct-equivalent rate = %.2f x the rate of the "
+                                 "multiplies that are not tile padding" % factor)
         useful_tf = d.get("useful_flops", d["flops"]) / (d["ms"] * 1e-3) / 1e12
-        roof["direct_equivalent_tflops"] = round(2.25 * useful_tf, 2)  # algorithmic (direct) FLOPs of the layers / time
+        roof["direct_equivalent_tflops"] = round(factor * useful_tf, 2)  # algorithmic (direct) FLOPs of the layers / time
         # `frac` counts what the MFMAs execute, tile padding included (7 x 7 planes: 16 tiles cover 8 x 8);
         # frac_unpadded counts only the multiplies of tiles' cells that exist
         roof["frac_unpadded"] = round(d.get("useful_flops", d["flops"]) / (d["ms"] * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4)

@@ -74,8 +74,10 @@ out = {
    "conv_dw": cls(lambda k: ("conv_dw" in k) and "wino" not in k),
    "conv_fwd": cls(lambda k: "conv_fwd_direct" in k or "conv_fwd_window" in k or "conv_fwd_stem" in k or "cache_prefetch" in k or "conv_igemm" in k or "conv_pack_weights" in k or "dma_pack" in k, "fwd"),
    "conv_dx": cls(lambda k: "conv_igemm" in k or "conv_pack_weights" in k or "dma_pack" in k or "conv_dx" in k, "bwd"),
-   "conv_fwd_winograd": cls(lambda k: "wino_fused_kernel" in k or "wino43_kernel" in k or "wino_tail_fixup" in k or "wino43_tail_fixup" in k or "wino_pack_weights" in k or "wino_pack" in k or "wino43_pack" in k, "fwd"),
-   "conv_dx_winograd": cls(lambda k: "wino_fused_kernel" in k or "wino43_kernel" in k or "wino_tail_fixup" in k or "wino43_tail_fixup" in k or "wino_pack_weights" in k or "wino_pack" in k or "wino43_pack" in k, "bwd"),
+   "conv_fwd_winograd": cls(lambda k: "wino_fused_kernel" in k or "wino_tail_fixup" in k or "wino_pack_weights" in k or "wino_pack" in k, "fwd"),
+   "conv_dx_winograd": cls(lambda k: "wino_fused_kernel" in k or "wino_tail_fixup" in k or "wino_pack_weights" in k or "wino_pack" in k, "bwd"),
+   "conv_fwd_winograd43": cls(lambda k: "wino43" in k, "fwd"),
+   "conv_dx_winograd43": cls(lambda k: "wino43" in k, "bwd"),
    "conv_dw_winograd": cls(lambda k: "wino_dw" in k or "wino_input_transform" in k or "wino_dy_transform" in k),
    "bn_fwd": cls(lambda k: "BnApplyBody" in k or "bn_stats" in k or "StatsF" in k or "bn_fwd" in k, "fwd"),
    "bn_bwd": cls(lambda k: "BnBwd" in k or "bn_bwd" in k or "BwdSumsF" in k),
