@@ -42,6 +42,8 @@ SIGNATURES = {
     "bcnn_hip_profile_class_name": (C.c_char_p, [i]),
     "bcnn_hip_profile_read": (None, [i, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "bcnn_hip_profile_read_useful_flops": (C.c_double, [i]),
+    "bcnn_hip_conv_side_stream_mode": (i, [i]),
+    "bcnn_hip_conv_side_join": (None, []),
     "bcnn_hip_trace_enable": (None, [i]),
     "bcnn_hip_trace_read": (C.c_size_t, [C.c_char_p, C.c_size_t]),
     "bcnn_hip_axpy": (None, [sz, f, vp, vp]),

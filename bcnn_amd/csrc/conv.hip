@@ -135,7 +135,12 @@ struct SideStream {
     hipStream_t stream = nullptr;
     hipEvent_t ready = nullptr, done = nullptr;
     int dev = -1;
+    bool pending = false;  // deferred mode: work queued whose completion the caller's stream has not been ordered behind yet
 };
+// 0: weight gradients on the caller's stream (default); 1: on the side stream, joined before the call returns (the round-1
+// experiment); 2: on the side stream, joined when the caller says so (bcnn_hip_conv_side_join) -- bcnn_backward's mode: the
+// weight gradient of a layer then runs next to the batch-norm / pooling sweeps and the data gradients of the layers in front
+static thread_local int g_side_mode = 0;
 static SideStream* side_stream() {
     static thread_local SideStream ss;
     int dev = 0;
@@ -489,8 +494,10 @@ static void conv_backward_impl(const float* x, const float* w, const float* bias
     // this function returns). Measured on ResNet-18 N=128 it is 1.7 % SLOWER than running them back to back
     // (18.15 vs 17.86 ms/step): both GEMMs are MFMA-bound and evict each other's L2 working set. Kept as an
     // opt-in experiment (BCNN_HIP_SIDE_STREAM=1), off by default.
-    static const int side_on = BCNN_EXP_ENV("BCNN_HIP_SIDE_STREAM") ? 1 : 0;
-    SideStream* side = (side_on && dx) ? side_stream() : nullptr;
+    static const int side_env = BCNN_EXP_ENV("BCNN_HIP_SIDE_STREAM") ? 1 : 0;
+    const int side_mode = g_side_mode ? g_side_mode : side_env;
+    // deferred mode: EVERY weight gradient (the per-net workspace of split partials then belongs to the side stream alone)
+    SideStream* side = (side_mode == 2 || (side_mode == 1 && dx)) ? side_stream() : nullptr;
     hipStream_t main_stream = current_stream();
     if (side) {
         HIP_CHECK(hipEventRecord(side->ready, main_stream));
@@ -539,7 +546,23 @@ static void conv_backward_impl(const float* x, const float* w, const float* bias
     if (dx && !conv_backward_data_winograd43(w, dy, dx, s) && !conv_backward_data_winograd_fused(w, dy, dx, s) &&
         !conv_backward_data_winograd(w, dy, dx, s))
         conv_backward_data(w, dy, dx, s, bs);
-    if (side) HIP_CHECK(hipStreamWaitEvent(main_stream, side->done, 0));
+    if (side) {
+        if (side_mode == 2) side->pending = true;
+        else HIP_CHECK(hipStreamWaitEvent(main_stream, side->done, 0));
+    }
+}
+
+int bcnn_hip_conv_side_stream_mode(int mode) {
+    const int prev = g_side_mode;
+    if (mode >= 0 && mode <= 2) g_side_mode = mode;
+    return prev;
+}
+
+void bcnn_hip_conv_side_join(void) {
+    SideStream* ss = side_stream();
+    if (!ss->pending) return;
+    ss->pending = false;
+    HIP_CHECK(hipStreamWaitEvent(current_stream(), ss->done, 0));  // `done` was recorded behind the last weight-gradient launch
 }
 
 void bcnn_hip_conv_backward(const float* x, const float* w, const float* bias, const float* y, float* dy, float* dx,

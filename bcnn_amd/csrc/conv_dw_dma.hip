@@ -416,7 +416,7 @@ bool conv_backward_weights_dma(const float* x, const float* dy, float* dw, const
 
 // ---- few input channels (the RGB stem): dW[f][(c, kr, kc)] as ONE GEMM over the zero-padded input ----------
 bool conv_small_c_applicable(const ConvShape& s);                                                    // conv_igemm_dma.hip
-float* conv_small_c_padded_input(const float* x, const ConvShape& s, size_t extra_floats, float** extra);
+float* conv_small_c_padded_input(const float* x, const ConvShape& s, size_t extra_floats, float** extra, int for_dw);
 
 static DwDmaPlan plan_dw_small_c(const ConvShape& s) {
     DwDmaPlan p;
@@ -453,7 +453,7 @@ bool conv_backward_weights_small_c(const float* x, const float* dy, float* dw, c
         exit(1);
     }
     const int Hp = s.H + 2 * s.pad, Wp = s.W + 2 * s.pad;
-    float* xp = conv_small_c_padded_input(x, s, 0, nullptr);
+    float* xp = conv_small_c_padded_input(x, s, 0, nullptr, /*for_dw=*/1);
     const ConvShape sp = make_conv_shape(s.N, s.C, Hp, Wp, s.F, s.ksz, s.stride, 0, 1);
     DwDmaArgs a;
     a.x = xp; a.dy = dy; a.partials = workspace; a.s = sp;

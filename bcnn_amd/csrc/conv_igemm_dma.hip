@@ -557,12 +557,14 @@ struct DmaScratch {
     size_t cap = 0;
     int dev = -1;
 };
-static thread_local DmaScratch g_dma_scratch;
+// two blocks: [0] forward / data gradient (weight packs, the padded input of the few-channel forward), [1] the padded input of
+// the few-channel WEIGHT gradient, which may run on a side stream next to another layer's data gradient
+static thread_local DmaScratch g_dma_scratch[2];
 
-static float* dma_scratch(size_t floats) {
+static float* dma_scratch(size_t floats, int which = 0) {
     int dev = 0;
     HIP_CHECK(hipGetDevice(&dev));
-    DmaScratch& sc = g_dma_scratch;
+    DmaScratch& sc = g_dma_scratch[which];
     if (sc.p == nullptr || sc.cap < floats || sc.dev != dev) {
         if (sc.p && sc.dev == dev) HIP_CHECK(hipFree(sc.p));  // hipFree synchronises the device
         const size_t cap = floats < (1u << 20) ? (1u << 20) : floats + floats / 2;
@@ -754,10 +756,10 @@ bool conv_small_c_applicable(const ConvShape& s) {
 }
 
 // the zero-padded copy, shared by the forward pass and the weight gradient of the step (same thread, same x)
-float* conv_small_c_padded_input(const float* x, const ConvShape& s, size_t extra_floats, float** extra) {
+float* conv_small_c_padded_input(const float* x, const ConvShape& s, size_t extra_floats, float** extra, int for_dw) {
     const int Hp = s.H + 2 * s.pad, Wp = s.W + 2 * s.pad;
     const size_t xp_floats = (size_t)s.N * s.C * Hp * Wp;
-    float* base = dma_scratch(xp_floats + extra_floats + 64);
+    float* base = dma_scratch(xp_floats + extra_floats + 64, for_dw ? 1 : 0);
     float* xp = base;
     if (extra) *extra = base + ((xp_floats + 63) & ~(size_t)63);
     conv_pad_input_kernel<<<stream_grid(xp_floats / 4 + 1, 256), 256, 0, current_stream()>>>(x, xp, s.H, s.W, Hp, Wp, s.pad,
@@ -775,7 +777,7 @@ bool conv_forward_small_c(const float* x, const float* w, const float* bias, con
     a.J = s.K; a.M = s.Mg; a.Jpad = round_up(a.J, kDmaBK); a.Mpad = round_up(a.M, 128); a.kk2 = 1;
     const size_t at_floats = (size_t)a.Jpad * a.Mpad;
     float* at = nullptr;
-    float* xp = conv_small_c_padded_input(x, s, at_floats, &at);
+    float* xp = conv_small_c_padded_input(x, s, at_floats, &at, /*for_dw=*/0);
     // the problem as the kernel sees it: the padded tensor, no padding left, one tap
     const ConvShape sp = make_conv_shape(s.N, s.C, Hp, Wp, s.F, s.ksz, s.stride, 0, 1);
     a.s = sp;

@@ -269,12 +269,14 @@ struct WinoScratch {
     size_t cap = 0;
     int dev = -1;
 };
-static thread_local WinoScratch g_wino_scratch;
+// two blocks: [0] forward / data gradient, [1] weight gradient -- the weight gradient may run on a side stream next to
+// another layer's data gradient (bcnn_hip_conv_side_stream_mode)
+static thread_local WinoScratch g_wino_scratch[2];
 
-static float* wino_scratch(size_t floats) {
+static float* wino_scratch(size_t floats, int which = 0) {
     int dev = 0;
     HIP_CHECK(hipGetDevice(&dev));
-    WinoScratch& sc = g_wino_scratch;
+    WinoScratch& sc = g_wino_scratch[which];
     if (sc.p == nullptr || sc.cap < floats || sc.dev != dev) {
         if (sc.p && sc.dev == dev) {
             HIP_CHECK(hipStreamSynchronize(current_stream()));  // launches still reading the old block
@@ -410,7 +412,7 @@ bool conv_backward_weights_winograd(const float* x, const float* dy, float* dw, 
     g.TH = (s.H + 1) / 2; g.TW = (s.W + 1) / 2;
     g.T = (unsigned)((long long)s.N * g.TH * g.TW);
     const size_t v_floats = (size_t)16 * s.C * g.T, m_floats = (size_t)16 * s.F * g.T, u_floats = (size_t)16 * s.F * s.C;
-    float* V = wino_scratch(v_floats + m_floats + u_floats);
+    float* V = wino_scratch(v_floats + m_floats + u_floats, 1);
     float* dM = V + v_floats;
     float* dU = dM + m_floats;
     dim3 gi((unsigned)ceil_div(g.T, 256), (unsigned)s.C);

@@ -593,14 +593,20 @@ void bcnn_backward(bcnn_net *net) {
     if (hc->comm_active) hc->comm_lo = hc->comm_hi = hc->arena_size;
     bcnn_prepack_conv_weights(net, 1);
     hc->in_pass = 2;
+    /* weight gradients on a side stream, next to the sweeps and data gradients of the layers in front (joined below, and
+     * before anybody is told that gradients are final) */
+    const int side_prev = bcnn_hip_conv_side_stream_mode(BCNN_EXP_ENV("BCNN_NO_SIDE_STREAM") ? 0 : 2);
     for (int i = net->num_nodes - 1; i >= 0; --i) {
         net->nodes[i].backward(net, &net->nodes[i]);
         if (hc->grad_ready_fn && hc->node_grad_first && hc->node_grad_first[i] < ready_from) {
+            bcnn_hip_conv_side_join();
             hc->grad_ready_fn(hc->node_grad_first[i], ready_from - hc->node_grad_first[i], hc->grad_ready_user);
             ready_from = hc->node_grad_first[i];
         }
     }
     hc->in_pass = 0;
+    bcnn_hip_conv_side_join();
+    bcnn_hip_conv_side_stream_mode(side_prev);
     bcnn_hip_conv_prepack_discard(); /* before bcnn_update rewrites the weights an unused copy was made from */
     if (hc->grad_ready_fn && ready_from > 0 && hc->arena_size > 0)  /* members no node claims (none today) */
         hc->grad_ready_fn(0, ready_from, hc->grad_ready_user);

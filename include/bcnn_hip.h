@@ -78,6 +78,13 @@ double bcnn_hip_profile_read_useful_flops(int cls);
  * one per line, so a parity test can assert WHICH kernels produced the tensors it compares instead of assuming the
  * size-dependent dispatch rules. enable(1) clears the log; read() copies at most cap - 1 bytes + a terminating 0 and
  * returns the full length of the log. */
+/* Weight gradients on a side stream (per host thread). mode 0: off (default); 1: bcnn_hip_conv_backward* queue the
+ * weight-gradient kernels of a layer that also has a data gradient on a private stream and order the caller's stream behind
+ * them before returning; 2: ... and do NOT order it: the caller does, with bcnn_hip_conv_side_join(), before anything reads
+ * the weight gradients (bcnn_backward: at its end, and before every gradient-ready callback). Returns the previous mode. */
+int bcnn_hip_conv_side_stream_mode(int mode);
+void bcnn_hip_conv_side_join(void);
+
 void bcnn_hip_trace_enable(int on);
 size_t bcnn_hip_trace_read(char *buf, size_t cap);
 
