@@ -141,12 +141,16 @@ struct SideStream {
 // experiment); 2: on the side stream, joined when the caller says so (bcnn_hip_conv_side_join) -- bcnn_backward's mode: the
 // weight gradient of a layer then runs next to the batch-norm / pooling sweeps and the data gradients of the layers in front
 static thread_local int g_side_mode = 0;
+bool conv_side_stream_deferred() { return g_side_mode == 2; }
 static SideStream* side_stream() {
     static thread_local SideStream ss;
     int dev = 0;
     HIP_CHECK(hipGetDevice(&dev));
     if (ss.stream == nullptr || ss.dev != dev) {
-        HIP_CHECK(hipStreamCreateWithFlags(&ss.stream, hipStreamNonBlocking));
+        // lowest priority: when a CU frees up, the caller's stream (the pass's critical chain: data gradients, sweeps) gets it first
+        int prio_lo = 0, prio_hi = 0;
+        HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        HIP_CHECK(hipStreamCreateWithPriority(&ss.stream, hipStreamNonBlocking, BCNN_EXP_ENV("BCNN_HIP_SIDE_PRIO_SAME") ? prio_hi : prio_lo));
         HIP_CHECK(hipEventCreateWithFlags(&ss.ready, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&ss.done, hipEventDisableTiming));
         ss.dev = dev;

@@ -98,6 +98,8 @@ __device__ __forceinline__ float bnfold_a(const float* __restrict__ var, const f
     return scales[c] / sqrtf(var[c] + 0.000001f);  // one formula for the pack, the constant and the weight gradient
 }
 #endif
+// true while the calling thread's weight gradients go to the side stream without a join per call (conv.hip)
+bool conv_side_stream_deferred();
 // the pack of (w, kind, mode) made by the current prepack batch and not yet used, or nullptr (conv.hip)
 float* prepack_take(const float* w, int kind, int mode, size_t floats);
 // what the kernel a layer will run on needs packed; false: nothing (another kernel takes the layer)

@@ -1516,7 +1516,10 @@ struct WinoDwPlan {
 };
 
 static int g_wd_force = -1;  // experiment build: BCNN_HIP_WINOGRAD_DW_FUSED=0/1 overrides the rule
-static WinoDwPlan wino_dw_fused_plan(const ConvShape& s) {
+// cus: the CUs the launch may fill. On the side stream of a backward pass (conv.hip: conv_side_stream_deferred) a quarter of
+// the chip is left to the pass's critical chain -- the sweeps and data gradients of the layers in front --, whose kernels
+// cannot share a CU with this one's 128 KB workgroups: 192 of 256 measured best (224: +0.10 ms, 160: +0.15 ms per ResNet-18 step).
+static WinoDwPlan wino_dw_fused_plan(const ConvShape& s, int cus = kCUs) {
     WinoDwPlan p;
     p.ok = false; p.partial_floats = 0;
     if (s.ksz != 3 || s.stride != 1 || s.pad != 1 || s.groups != 1) return p;
@@ -1532,14 +1535,15 @@ static WinoDwPlan wino_dw_fused_plan(const ConvShape& s) {
     p.T = (unsigned)((long long)s.N * TH * TW);
     p.fblocks = (s.F + 63) / 64; p.cblocks = (s.C + 63) / 64;
     const int nob = p.fblocks * p.cblocks;
-    int splits = kCUs / nob;  // one 128 KB workgroup per CU
+    static const int dw_cus_env = BCNN_EXP_ENV("BCNN_HIP_DW_CUS") ? atoi(BCNN_EXP_ENV("BCNN_HIP_DW_CUS")) : 0;  // experiment override
+    int splits = (dw_cus_env > 0 ? dw_cus_env : cus) / nob;  // one 128 KB workgroup per CU
     if (splits < 1) splits = 1;
     unsigned per = (p.T + (unsigned)splits - 1) / (unsigned)splits;
     per = (per + WD_KT - 1) / WD_KT * WD_KT;
     if (per < 4 * WD_KT) per = 4 * WD_KT;
     p.tiles_per_split = per;
     p.splits = (int)((p.T + per - 1) / per);
-    if (g_wd_force == 2 && p.splits * nob < kCUs / 2) return p;  // too few tiles to fill the chip
+    if (g_wd_force == 2 && p.splits * nob < cus / 2) return p;  // too few tiles to fill the chip
     p.partial_floats = (size_t)p.splits * nob * (16 * 64 * 64);
     p.ok = true;
     return p;
@@ -1549,7 +1553,8 @@ size_t conv_dw_winograd_fused_workspace_floats(const ConvShape& s) { return wino
 
 bool conv_backward_weights_winograd_fused(const float* x, const float* dy, float* dw, const ConvShape& s, float* workspace,
                                           size_t workspace_floats) {
-    const WinoDwPlan p = wino_dw_fused_plan(s);
+    const bool yield_cus = conv_side_stream_deferred() && wino_dw_fused_plan(s).ok;  // (the workspace was sized for the full plan)
+    const WinoDwPlan p = wino_dw_fused_plan(s, yield_cus ? kCUs * 3 / 4 : kCUs);
     if (!p.ok) return false;
     if (reinterpret_cast<uintptr_t>(workspace) & 15) return false;  // the finalize kernel reads the slabs 16 bytes at a time
     if (workspace == nullptr || workspace_floats < p.partial_floats) {

@@ -177,7 +177,11 @@ void bcnn_hip_sync(void) { HIP_CHECK(hipStreamSynchronize(current_stream())); }
 void* bcnn_hip_stream_create(void) {
     hipStream_t s;
     warm_device_keeping_rand_state();
-    HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    // the highest priority the device offers: work that shares the device with this library's own side stream (the weight
+    // gradients of a backward pass, conv.hip) is the pass's critical chain
+    int prio_lo = 0, prio_hi = 0;
+    HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    HIP_CHECK(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio_hi));
     return (void*)s;
 }
 
