@@ -589,6 +589,12 @@ def main():
             "roofline": roofline_of(prof, args.workload, default_shape),
             "profiled_steps": profiled_steps,
             "kernel_classes": class_table(prof, profiled_steps),
+            # bcnn_backward queues the weight-gradient kernels on a second HIP stream of the library (include/bcnn_hip.h:
+            # bcnn_hip_conv_side_stream_mode), where they run next to the batch-norm / pooling sweeps and the data gradients
+            # of the layers in front. Each class is timed with HIP events on the stream its kernels are launched on, so the
+            # *_dw classes overlap the others in time: the classes' sum exceeds ms_per_step, and a class's rate is what it
+            # reaches while it shares the chip.
+            "streams": "weight gradients on a second stream: per-class times overlap (sum > ms_per_step)",
         }
         if os.environ.get("BENCH_TEST_CHECKSUM") == "1" and wl.net is not None:
             pptr, psize = wl.net.parameter_arena()
@@ -613,8 +619,11 @@ def main():
                           "warmup_extra": w2.warmup_extra,
                           "roofline": roofline_of(sprof, name, True),
                           "kernel_classes": class_table(sprof, sprofiled)}
+            side_sample = w2.sample_n
             w2.close()
             del w2
+            if not args.no_cpu_baseline:  # the reference on the same host, a bounded sample of THIS workload
+                side[name]["cpu_baseline"] = cpu_baseline(name, side_sample)
         out["workloads"] = side
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:  # reported by the single-GPU run only

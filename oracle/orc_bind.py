@@ -112,17 +112,20 @@ def orc_conv(cs):
         out["run_mean"], out["run_var"] = rm.copy(), rv.copy()
         if mode == MODE_TRAIN:
             out["saved_mean"], out["saved_var"] = sm.copy(), sv.copy()
-    if mode == MODE_TRAIN:
+    if mode == MODE_TRAIN and not int(cs.get("forward_only", 0)):
         dy = cs["dy"].copy()
         dw = cs["dw0"].copy() if "dw0" in cs else np.zeros_like(cs["wt"])
         db = cs["db0"].copy() if "db0" in cs else z()
         dsc = cs["dscales0"].copy() if "dscales0" in cs else z()
         dm, dv = z(), z()
         dx = np.full_like(cs["x"], 7.0) if int(cs["input_grad"]) else None
+        dsl = cs["dslopes0"].copy() if "dslopes0" in cs else None
         L.orc_conv_backward(P(cs["x"]), P(cs["wt"]), P(y), P(dy), P(dx), P(dw), P(db), n, c, h, w, f,
-                            k, s, p, g, act, P(slopes), None, bn, P(sc), P(dsc), P(sm), P(sv), P(dm),
+                            k, s, p, g, act, P(slopes), P(dsl), bn, P(sc), P(dsc), P(sm), P(sv), P(dm),
                             P(dv), P(xn), P(ws), P(col))
         out.update(dy_out=dy, dw=dw, db=db)
+        if dsl is not None:
+            out["dslopes"] = dsl
         if dx is not None:
             out["dx"] = dx
         if bn:

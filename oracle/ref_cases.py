@@ -27,7 +27,7 @@ def conv_out_hw(h, w, k, s, p):
 # conv (+ fused BN, + fused activation)          src/layers/bcnn_conv_layer.c:367-587
 # --------------------------------------------------------------------------------------------
 def make_conv(seed, n, c, h, w, f, k, s, p, g=1, bn=0, act=rb.ACT_NONE, input_grad=True,
-              mode=rb.MODE_TRAIN, bias_one=False, carry=False, name=None, via_model_file=False):
+              mode=rb.MODE_TRAIN, bias_one=False, carry=False, name=None, via_model_file=False, forward_only=False):
     rs = np.random.RandomState(seed)
     oh, ow = conv_out_hw(h, w, k, s, p)
     cg = c // g
@@ -36,6 +36,8 @@ def make_conv(seed, n, c, h, w, f, k, s, p, g=1, bn=0, act=rb.ACT_NONE, input_gr
                 input_grad=int(input_grad), mode=mode, name=name or "conv")
     if via_model_file:
         case["via_model_file"] = 1
+    if forward_only:
+        case["forward_only"] = 1
     case["x"] = _u(rs, (n, c, h, w))
     case["wt"] = _u(rs, (f, cg, k, k), -a, a)
     case["bias"] = _u(rs, (f,), -0.5, 0.5)
@@ -52,6 +54,14 @@ def make_conv(seed, n, c, h, w, f, k, s, p, g=1, bn=0, act=rb.ACT_NONE, input_gr
         case["scales"] = _u(rs, (f,), 0.5, 1.5)
         if carry:
             case["dscales0"] = (_u(rs, (f,)) * 0.05).astype(F32)
+    if act == rb.ACT_PRELU:
+        # fused PReLU: per-filter slopes (bcnn_conv_layer.c:188-198, 476-481). The reference creates that tensor WITHOUT a
+        # gradient buffer (:192 "no gradients") and its backward hands the NULL to bcnn_backward_activation_cpu, which
+        # accumulates slope gradients into it (bcnn_activation_layer.c:214): a TRAIN-mode backward through such a node is a
+        # segmentation fault in the reference. Fixtures of this kind are forward-only; the backward is pinned on the oracle.
+        case["slopes"] = _u(rs, (f,), 0.05, 0.5)
+        if not forward_only:
+            case["dslopes0"] = (_u(rs, (f,)) * 0.1).astype(F32)
     return case
 
 
@@ -72,6 +82,10 @@ def ref_conv(case):
         net.data(i_rm).reshape(-1)[...] = cs["run_mean0"]
         net.data(i_rv).reshape(-1)[...] = cs["run_var0"]
         net.data(i_sc).reshape(-1)[...] = cs["scales"]
+    i_sl = None
+    if cs["act"] == rb.ACT_PRELU:  # the slopes of a fused PReLU: src slot 3 + 3 * batch_norm (bcnn_conv_layer.c:188-198)
+        i_sl = net.node_src(node, 3 + 3 * int(cs["bn"]))
+        net.data(i_sl).reshape(-1)[...] = cs["slopes"]
     if cs.get("via_model_file"):
         # PREDICT-mode 3x3/s1 convolutions of the reference read Winograd-transformed weights that only
         # bcnn_load_weights prepares (bcnn_net.c:1326-1346): round-trip the parameters through a model file
@@ -89,7 +103,8 @@ def ref_conv(case):
         if cs["mode"] == rb.MODE_TRAIN:
             out["saved_mean"] = net.bn_field(node, 0, f).copy()
             out["saved_var"] = net.bn_field(node, 1, f).copy()
-    if cs["mode"] == rb.MODE_TRAIN:
+    if cs["mode"] == rb.MODE_TRAIN and not cs.get("forward_only"):
+        assert i_sl is None, "the reference's backward through a fused PReLU dereferences a NULL gradient buffer"
         net.grad(i_y)[...] = cs["dy"]
         if "dw0" in cs:
             net.grad(i_w)[...] = cs["dw0"]

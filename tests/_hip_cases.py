@@ -31,13 +31,14 @@ def hip_conv(cs):
     if bn:
         b = dict(run_mean=D(cs["run_mean0"]), run_var=D(cs["run_var0"]), scales=D(cs["scales"]),
                  saved_mean=Z(f), saved_var=Z(f), workspace=torch.full((n, f, oh, ow), 5.0, device=DEV))
-    ops.conv_forward(x, wt, bias, y, k, s, p, g, act, None, b, mode)
+    slopes = D(cs["slopes"]) if "slopes" in cs else None
+    ops.conv_forward(x, wt, bias, y, k, s, p, g, act, slopes, b, mode)
     out = {"y": H(y)}
     if bn:
         out["run_mean"], out["run_var"] = H(b["run_mean"]), H(b["run_var"])
         if mode == MODE_TRAIN:
             out["saved_mean"], out["saved_var"] = H(b["saved_mean"]), H(b["saved_var"])
-    if mode == MODE_TRAIN:
+    if mode == MODE_TRAIN and not int(cs.get("forward_only", 0)):
         dy = D(cs["dy"])
         dw = D(cs["dw0"]) if "dw0" in cs else Z(*cs["wt"].shape)
         db = D(cs["db0"]) if "db0" in cs else Z(f)
@@ -45,8 +46,11 @@ def hip_conv(cs):
         if bn:
             b.update(dscales=D(cs["dscales0"]) if "dscales0" in cs else Z(f), dmean=Z(f), dvar=Z(f))
         ws = Z(max(1, ops.conv_workspace_size(n, c, h, w, f, k, s, p, g)))
-        ops.conv_backward(x, wt, y, dy, dx, dw, db, k, s, p, g, act, ws, None, None, b, bias)
+        dsl = D(cs["dslopes0"]) if "dslopes0" in cs else None
+        ops.conv_backward(x, wt, y, dy, dx, dw, db, k, s, p, g, act, ws, slopes, dsl, b, bias)
         out.update(dy_out=H(dy), dw=H(dw), db=H(db))
+        if dsl is not None:
+            out["dslopes"] = H(dsl)
         if dx is not None:
             out["dx"] = H(dx)
         if bn:

@@ -46,6 +46,13 @@ CASES = [
     rc.make_conv(22, 2, 2, 6, 6, 3, 3, 1, 1, act=A.ACT_CLAMP, name="conv_clamp"),
     rc.make_conv(23, 2, 2, 6, 6, 3, 3, 1, 1, act=A.ACT_ABS, name="conv_abs"),
     rc.make_conv(24, 2, 2, 6, 6, 3, 3, 1, 1, act=A.ACT_SOFTPLUS, name="conv_softplus"),
+    # fused PReLU (slopes = src slot 3 + 3 * batch_norm of the node), without and with the fused batch-norm; 8 and 64 filters
+    # (the second one reaches the LDS-DMA GEMM and its epilogue)
+    # forward only: the reference's backward through such a node dereferences a NULL slope-gradient buffer (oracle/ref_cases.py)
+    rc.make_conv(25, 2, 3, 8, 8, 8, 3, 1, 1, act=A.ACT_PRELU, forward_only=True, name="conv_prelu_fwd"),
+    rc.make_conv(26, 2, 3, 8, 8, 8, 3, 1, 1, bn=1, act=A.ACT_PRELU, forward_only=True, name="conv_bn_prelu_fwd"),
+    rc.make_conv(27, 3, 32, 10, 10, 64, 3, 1, 1, bn=1, act=A.ACT_PRELU, forward_only=True, name="conv_dma_bn_prelu_c32_f64_fwd"),
+    rc.make_conv(28, 2, 16, 9, 9, 40, 5, 1, 2, act=A.ACT_PRELU, mode=A.MODE_PREDICT, input_grad=False, name="conv_k5_prelu_predict"),
     # ---- conv at channel counts that reach the LDS-DMA GEMM kernels (M > 32, reduction majors >= 8/16):
     #      ragged M and J tiles, stride-parity classes, 1x1 raw views, groups, fused batch-norm statistics
     rc.make_conv(101, 3, 48, 12, 12, 80, 3, 1, 1, act=A.ACT_RELU, name="conv_dma_c48_f80_k3"),

@@ -35,6 +35,7 @@ def test_bench_prints_the_contract_line(workload):
         assert set(side) == {"conv3x3", "mobilenet"}
         for w in side.values():
             assert w["images_per_s"] > 0 and w["roofline"]["bound"] in ("hbm", "mfma") and w["kernel_classes"]
+            assert w["cpu_baseline"]["kind"] == "reference" and w["cpu_baseline"]["value"] > 0  # per workload
     else:
         assert "workloads" not in d
     cpu = d["cpu_baseline"]

@@ -249,3 +249,54 @@ def test_net_matches_reference(gname):
             assert np.array_equal(got.cpu().numpy(), want), "maxpool indexes differ in node %d" % node
     ref.close()
     hip.close()
+
+
+def test_fused_prelu_net_forward_matches_reference():
+    """bcnn_add_convolutional_layer(..., BCNN_ACT_PRELU, ...) with and without the fused batch-norm (slopes = src slot
+    3 + 3 * batch_norm, bcnn_conv_layer.c:188-198, :476-481). Forward only, TRAIN mode: the reference's backward through
+    such a node accumulates slope gradients through a NULL pointer (the tensor is created without a gradient buffer, :192;
+    bcnn_activation_layer.c:214) -- the backward is pinned on the oracle (tests/test_hip_parity.py)."""
+    _need_ref()
+    import ctypes
+    from bcnn_amd import capi
+    ctypes.CDLL(None).srand(20240608)
+    shp = dict(w=12, h=10, c=3, n=3)
+    ref = rb.RefNet(mode=rb.MODE_TRAIN, **shp)
+    ref.L.ref_set_threads(ref.net, 4)
+    hip = capi.Net(mode=capi.MODE_TRAIN, **shp)
+    for net in (ref, hip):
+        net.conv(8, 3, 1, 1, 1, 1, rb.ACT_PRELU, "input", "c1")
+        net.conv(40, 3, 2, 1, 1, 0, rb.ACT_PRELU, "c1", "c2")
+        net.conv(48, 1, 1, 0, 1, 1, rb.ACT_PRELU, "c2", "c3")
+        net.avgpool("c3", "avg")
+        net.compile()
+    rs = np.random.RandomState(3)
+    nt = ref.L.ref_num_tensors(ref.net)
+    names = [ref.L.ref_tensor_name(ref.net, i).decode() for i in range(nt)]
+    assert sum("prelu_slopes" in nm for nm in names) == 3
+    for i in range(2, nt):
+        if not ref.tensor(i).data:
+            continue
+        d = ref.data(i)
+        if "prelu" in names[i]:
+            d[...] = rs.uniform(0.05, 0.5, d.shape)
+        elif names[i].endswith("_scales"):
+            d[...] = rs.uniform(0.5, 1.5, d.shape)
+        elif names[i].endswith("_b"):
+            d[...] = rs.uniform(-0.2, 0.2, d.shape)
+        assert hip.shape(i) == ref.shape(i), names[i]
+        hip.data(i)[...] = d
+        hip.upload(i)
+    x = rs.uniform(-1, 1, ref.shape(0)).astype(np.float32)
+    ref.data(0)[...] = x
+    hip.data(0)[...] = x
+    hip.upload(0)
+    ref.forward()
+    hip.forward()
+    for i in range(nt):
+        if not ref.tensor(i).data:
+            continue
+        hip.download(i, False)
+        _compare("fused prelu %s" % names[i], hip.data(i), ref.data(i))
+    ref.close()
+    hip.close()
