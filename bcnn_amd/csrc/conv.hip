@@ -265,6 +265,7 @@ void bcnn_hip_conv_prepack(const bcnn_hip_conv_desc* layers, int count, int data
         st.dev = dev;
     }
     ++st.epoch;  // every copy made earlier and not used is stale now
+    (void)take_fold();  // a pass begins: a fold announced earlier and never consumed must not meet this pass's first convolution
     const int mode = data_gradient ? 1 : 0;
     std::vector<WinoPackJob> wj;
     std::vector<IgemmPackJob> ij;

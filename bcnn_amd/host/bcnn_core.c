@@ -483,10 +483,22 @@ static void relink_graph(bcnn_net *net) {
 /* Reference bcnn_net.c:287-335: new input extent (batch 1, like the reference's bcnn_set_input_shape(net, w, h, c, 1)), then
  * the first destination tensor of every node re-shaped from its first source -- convolution and max-pooling by their output
  * rules, every other node as a copy of the source's shape -- and, with need_realloc, re-allocated (host and device mirrors).
- * As in the reference, layer-private buffers (batch-norm workspaces, pooling indexes, weights) keep the size they were built
- * with: the call is meant for fully convolutional PREDICT nets that shrink or keep their extent. What this build derives
- * from shapes (the conv scratch, the node-to-node links) is brought up to date before returning; the reference's function
- * falls off its end without a return value, here the status is BCNN_SUCCESS. */
+ * In the reference, layer-private buffers (batch-norm workspaces, pooling indexes) keep the size they were built with, so a
+ * net resized to a LARGER extent -- the usual detection use of this call -- overruns them (there: host heap; here it
+ * would be device memory). Deliberate deviation: with need_realloc the private buffers whose size follows a dst tensor
+ * (pooling indexes and kept maxima, the batch-norm workspaces of convolution and batch-norm nodes) are re-allocated for the
+ * new shape as well; without it, a shape that outgrew them is refused (BCNN_INVALID_PARAMETER) instead of corrupting memory.
+ * What this build derives from shapes (the conv scratch, the node-to-node links and their sums buffers) is brought up to
+ * date before returning; the reference's function falls off its end without a return value, here the status is BCNN_SUCCESS. */
+static bcnn_status resize_private_f32(float **buf, size_t old_elems, size_t new_elems, int need_realloc) {
+    if (!*buf || new_elems <= old_elems) return BCNN_SUCCESS;
+    if (!need_realloc) return BCNN_INVALID_PARAMETER;
+    bcnn_hip_sync();
+    bcnn_hip_free(*buf);
+    *buf = bcnn_hip_malloc_f32(new_elems);
+    return *buf ? BCNN_SUCCESS : BCNN_FAILED_ALLOC;
+}
+
 bcnn_status bcnn_resize_net(bcnn_net *net, int w, int h, int c, int need_realloc) {
     if (!net || w <= 0 || h <= 0 || c <= 0) return BCNN_INVALID_PARAMETER;
     bcnn_set_input_shape(net, w, h, c, 1);
@@ -495,6 +507,7 @@ bcnn_status bcnn_resize_net(bcnn_net *net, int w, int h, int c, int need_realloc
         if (nd->num_src < 1 || nd->num_dst < 1) continue;
         const bcnn_tensor *s = &net->tensors[nd->src[0]];
         bcnn_tensor *d = &net->tensors[nd->dst[0]];
+        const size_t old_elems = (size_t)bcnn_tensor_size(d);
         if (nd->type == BCNN_LAYER_CONV2D) {
             const bcnn_conv_param *p = (const bcnn_conv_param *)nd->param;
             bcnn_tensor_set_shape(d, s->n, p->num, (s->h + 2 * p->pad - p->size) / p->stride + 1,
@@ -506,6 +519,29 @@ bcnn_status bcnn_resize_net(bcnn_net *net, int w, int h, int c, int need_realloc
             bcnn_tensor_set_shape(d, s->n, s->c, s->h, s->w, 1);
         }
         if (need_realloc) BCNN_CHECK_STATUS(bcnn_tensor_allocate(d, net->mode));
+        const size_t new_elems = (size_t)bcnn_tensor_size(d);
+        if (nd->type == BCNN_LAYER_CONV2D) {
+            bcnn_conv_param *p = (bcnn_conv_param *)nd->param;
+            BCNN_CHECK_STATUS(resize_private_f32(&p->bn_workspace_gpu, old_elems, new_elems, need_realloc));
+            BCNN_CHECK_STATUS(resize_private_f32(&p->x_norm_gpu, old_elems, new_elems, need_realloc));
+        } else if (nd->type == BCNN_LAYER_BATCHNORM) {
+            bcnn_batchnorm_param *p = (bcnn_batchnorm_param *)nd->param;
+            BCNN_CHECK_STATUS(resize_private_f32(&p->workspace_gpu, old_elems, new_elems, need_realloc));
+            BCNN_CHECK_STATUS(resize_private_f32(&p->x_norm_gpu, old_elems, new_elems, need_realloc));
+        } else if (nd->type == BCNN_LAYER_MAXPOOL && new_elems > old_elems) {
+            bcnn_maxpool_param *p = (bcnn_maxpool_param *)nd->param;
+            if (!need_realloc) return BCNN_INVALID_PARAMETER;
+            bcnn_hip_sync();
+            bcnn_hip_free(p->indexes_gpu);
+            p->indexes_gpu = bcnn_hip_malloc_i32(new_elems);
+            int *host = (int *)realloc(p->indexes, new_elems * sizeof(int));
+            if (!host || !p->indexes_gpu) return BCNN_FAILED_ALLOC;
+            p->indexes = host;
+            if (p->raw_at_max_gpu) { /* re-made by bcnn_link_conv_maxpool for the new shape */
+                bcnn_hip_free(p->raw_at_max_gpu);
+                p->raw_at_max_gpu = NULL;
+            }
+        }
     }
     if (hctx(net)->compiled) return bcnn_compile_net(net); /* input tensor, conv scratch, links */
     return BCNN_SUCCESS;

@@ -306,12 +306,15 @@ void bcnn_prepack_conv_weights(bcnn_net *net, int data_gradient) {
         const bcnn_conv_param *p = (const bcnn_conv_param *)node->param;
         const bcnn_tensor *x = &net->tensors[node->src[0]], *w = &net->tensors[node->src[1]];
         if (!w->data_gpu || (data_gradient && !x->grad_data_gpu)) continue;
+        /* a forward pack of a node that folds the batch-norm in front is made per call (its column factors depend on this
+         * batch's statistics): nothing to prepare ahead */
+        if (!data_gradient && net->mode == BCNN_MODE_TRAIN && p->fold_bn >= 0) continue;
         d[n].w_d = w->data_gpu;
         d[n].n = x->n; d[n].c = x->c; d[n].h = x->h; d[n].w = x->w;
         d[n].f = p->num; d[n].k = p->size; d[n].stride = p->stride; d[n].pad = p->pad; d[n].groups = p->num_groups;
         ++n;
     }
-    if (n > 0) bcnn_hip_conv_prepack(d, n, data_gradient);
+    bcnn_hip_conv_prepack(d, n, data_gradient); /* also with nothing to pack: a pass begins (stale packs and folds are dropped) */
     free(d);
 }
 

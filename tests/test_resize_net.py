@@ -51,3 +51,30 @@ def test_resize_rejects_nonsense():
     net = _build(capi, 16, 16, 1)
     assert net.resize(0, 16, 3) != 0
     net.close()
+
+
+def test_net_resized_to_a_larger_extent_equals_a_net_built_for_it():
+    """the usual detection use of bcnn_resize_net: a batch-1 fully convolutional net grows (16 x 16 -> 48 x 40). The
+    pooling node's index buffer and the batch-norm workspaces follow the new shapes (the reference leaves them at their old
+    size and overruns them); results equal those of a net built for the larger extent."""
+    from bcnn_amd import capi
+    small = _build(capi, 16, 16, 1)
+    big = _build(capi, 48, 40, 1)
+    assert small.resize(48, 40, 3, True) == 0
+    for name in ("input", "c1", "p1", "c2", "c3"):
+        assert small.shape(small.index(name)) == big.shape(big.index(name)), name
+    x = np.random.RandomState(5).uniform(-1, 1, (1, 3, 40, 48)).astype(np.float32)
+    for net in (small, big):
+        net.data(0)[...] = x
+        net.upload(0)
+        net.forward()
+    for name in ("c1", "p1", "c2", "c3"):
+        a, b = small.index(name), big.index(name)
+        small.download(a, False)
+        big.download(b, False)
+        assert np.array_equal(small.data(a), big.data(b)), name
+    # without need_realloc a shape that outgrew the layers' private buffers is refused, not run past them
+    tiny = _build(capi, 16, 16, 1)
+    assert tiny.resize(64, 64, 3, False) != 0
+    for net in (small, big, tiny):
+        net.close()

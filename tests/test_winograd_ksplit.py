@@ -2,8 +2,8 @@
 round of the persistent workgroups would hold are cut along the input channels and dealt out over all CUs; a fix-up kernel
 adds the pieces in channel order, stores them and takes the batch-norm statistics). Shapes whose block counts leave such a
 tail (288 and 576 blocks on 256 CUs; a ragged channel count; a partial last tile block): raw forward with batch-norm
-statistics and dX against torch's float64 convolution at 1e-5 (the parity bar is 1e-4; 3e-5 where the F(4x4, 3x3) kernel of
-conv_winograd43.hip takes the shape: whole 4 x 4 tiles and >= 512 units), and bit-identical repeats."""
+statistics and dX against torch's float64 convolution at 1e-5 (the parity bar is 1e-4; 3e-5 where an F(4x4, 3x3) kernel took
+the shape -- read off the dispatch trace of include/bcnn_hip.h, not re-derived from the shape), and bit-identical repeats."""
 import numpy as np
 import pytest
 import torch
@@ -34,10 +34,27 @@ def test_tail_pieces_add_up(shape):
         torch.cuda.synchronize()
         return bn
 
-    bn = forward()
+    import ctypes
+    from bcnn_amd import _lib
+    L = _lib.load()
+
+    def traced(fn):
+        """fn() under the dispatch trace of include/bcnn_hip.h -> (result, set of kernel families that ran)"""
+        L.bcnn_hip_trace_enable(1)
+        out = fn()
+        n_ = L.bcnn_hip_trace_read(None, 0)
+        buf = ctypes.create_string_buffer(n_ + 1)
+        L.bcnn_hip_trace_read(buf, n_ + 1)
+        L.bcnn_hip_trace_enable(0)
+        return out, set(buf.value.decode().split())
+
+    bn, ran = traced(forward)
     raw = F.conv2d(x.double(), wt.double(), None, padding=1)
     rel = lambda a, r: float((a.double() - r).abs().max() / max(float(r.abs().max()), 1e-30))
-    tol = 3e-5 if (h % 4 == 0 and w % 4 == 0) else 1e-5   # F(4x4, 3x3) in fp32: ~1e-5 (tools/exp/wino43_error.py)
+    # the bar follows the kernel that TOOK the shape (asked of the dispatch trace, not re-derived from the shape): F(4x4, 3x3) in
+    # fp32 sits at ~1e-5 (tools/exp/wino43_error.py), F(2x2, 3x3) at ~4e-7
+    assert any(k.startswith(("wino43", "wino_fused")) for k in ran), ran
+    tol = 3e-5 if any(k.startswith("wino43") for k in ran) else 1e-5
     assert rel(bn["workspace"], raw) <= tol
     mean = raw.mean(dim=(0, 2, 3))
     var = (raw * raw).mean(dim=(0, 2, 3)) - mean * mean
@@ -51,10 +68,10 @@ def test_tail_pieces_add_up(shape):
     dx = torch.full_like(x, float("nan"))
     dw, db = torch.zeros_like(wt), torch.zeros(f, device=DEV)
     ws = torch.zeros(max(1, ops.conv_workspace_size(n, c, h, w, f, 3, 1, 1, 1)), device=DEV)
-    ops.conv_backward(x, wt, y, dy.clone(), dx, dw, db, 3, 1, 1, 1, 0, ws)
+    _, ran = traced(lambda: ops.conv_backward(x, wt, y, dy.clone(), dx, dw, db, 3, 1, 1, 1, 0, ws))
     torch.cuda.synchronize()
     dxr = F.conv_transpose2d(dy.double(), wt.double(), None, padding=1)
-    assert rel(dx, dxr) <= tol
+    assert rel(dx, dxr) <= (3e-5 if any(k.startswith("wino43") and k.endswith(":dx") for k in ran) else 1e-5)
     dx2 = torch.full_like(x, float("nan"))
     ops.conv_backward(x, wt, y, dy.clone(), dx2, torch.zeros_like(wt), torch.zeros(f, device=DEV), 3, 1, 1, 1, 0, ws)
     torch.cuda.synchronize()
