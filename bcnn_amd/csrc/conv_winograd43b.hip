@@ -90,7 +90,6 @@ __device__ __forceinline__ void wb_mma(f32x4 (&acc)[36], const float* up, const 
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
         __builtin_amdgcn_sched_barrier(0);
-#ifndef WB_ABL_NOLDSRD
         if (g + 1 < 3) {
 #pragma unroll
             for (int x = 0; x < 3; ++x) {
@@ -98,17 +97,12 @@ __device__ __forceinline__ void wb_mma(f32x4 (&acc)[36], const float* up, const 
                 b4[(g + 1) & 1][x] = *reinterpret_cast<const f32x4*>(vp + (3 * (g + 1) + x) * 512);
             }
         }
-#endif
 #pragma unroll
         for (int x = 0; x < 3; ++x)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int xi = 12 * g + 4 * x + j;
-#ifdef WB_ABL_NOMFMA
-                acc[xi][0] = (FIRST ? 0.f : acc[xi][0]) + a4[g & 1][x][j] * b4[g & 1][x][j];
-#else
                 acc[xi] = mfma16(a4[g & 1][x][j], b4[g & 1][x][j], FIRST ? zero : acc[xi]);
-#endif
             }
     }
 }
@@ -220,15 +214,9 @@ __global__ __launch_bounds__(64 * WB_NW, 2) void wino43b_kernel(const Wino43bArg
     // a patch = p[6]: own columns (kept as the 16-byte tuples the requests fill) + eduty: this lane's edge duty.
     // live = false: the same seven instructions with every lane out of range (nothing is fetched, zeros come back).
     auto load_patch = [&](const WbCur& c, buf_f32x4 (&p)[6], float& eduty, bool live) {
-#ifdef WB_ABL_NOLOADINSTR
-        return;
-#endif
         if (live && c.tb != dec_tb) decode(c.tb);
         // The row step rides in the scalar offset (the range check sees the vector offset only); out-of-range offsets return 0.0
         const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((c.period() * WB_KP + 2 * tw4) * HW * 4);
-#ifdef WB_ABL_NOLOAD
-        live = false;
-#endif
         const unsigned v_mid = live ? v_mid_ : kOOB, e_off = live ? e_off_ : kOOB;
         const unsigned v_top = ((pflags & 1u) && live) ? v_mid - row_bytes : kOOB, v_bot = (pflags & 2u) ? v_mid : kOOB;
 #pragma unroll
@@ -240,12 +228,6 @@ __global__ __launch_bounds__(64 * WB_NW, 2) void wino43b_kernel(const Wino43bArg
     };
     // B^T d B -> V[vs][c = tw4 / 2][xi / 4][k = 2 (tw4 % 2) + lhi][tile l31][xi % 4]: nine 16-byte writes, a wave's 64 lanes 1 KB each
     auto write_v = [&](int vs, const buf_f32x4 (&p)[6], const float eduty) {
-#ifdef WB_ABL_NOXFORM
-        { float sum = eduty;
-          for (int i = 0; i < 6; ++i) sum += p[i][0] + p[i][1] + p[i][2] + p[i][3];
-          if (sum == 123.456f) lds[2 * WB_USTAGE + lane] = sum;
-          return; }
-#endif
         const bool pad_l = (pflags & 16u) != 0, pad_r = (pflags & 32u) != 0;
         // the edge values: lane l31 = 0 takes row i from lane + 1 + i, lane l31 = 31 from lane - 6 + i (others: unused)
         const int esrc = 4 * (l31 == 0 ? lane + 1 : lane - 6);
@@ -292,9 +274,6 @@ __global__ __launch_bounds__(64 * WB_NW, 2) void wino43b_kernel(const Wino43bArg
     };
     // one KB piece of a U sub-chunk: the packed weights hold every (channel block, sub-chunk) stage as 36 linear pieces
     auto dma_u = [&](const WbCur& c, int sub, int piece) {
-#ifdef WB_ABL_NODMA
-        return;
-#endif
         const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(((c.mb() * nc4 + 2 * c.period() + sub) * 36 + piece) * 1024);
         dma_row_x4(rs_u, lds0 + (unsigned)((sub * WB_USTAGE) * 4 + piece * 1024), (unsigned)lane * 16u, soff);
     };
@@ -305,12 +284,6 @@ __global__ __launch_bounds__(64 * WB_NW, 2) void wino43b_kernel(const Wino43bArg
 
     // A^T M A on the accumulators, stores and statistics of item c (the wave's 16 channels x 16 tiles)
     auto epilogue = [&](const WbCur& c) {
-#ifdef WB_ABL_NOEPI
-        { float sum = 0.f;
-          for (int x = 0; x < 36; ++x) sum += acc[x][0] + acc[x][1] + acc[x][2] + acc[x][3];
-          if (sum == 123.456f) a.dst[0] = sum;
-          return; }
-#endif
         const unsigned t = (unsigned)c.tb * WB_BT + (unsigned)(16 * tbw + l15);
         const bool ok = t < a.T;
         const unsigned n = ok ? t / per_img : 0u;
@@ -397,9 +370,7 @@ __global__ __launch_bounds__(64 * WB_NW, 2) void wino43b_kernel(const Wino43bArg
         const bool t_role = grp == ((gp + 1) & 1);
         const int vs = gp & 1;
         // ---- first sub-chunk: U stage 0, V[vs][0] ----
-#ifndef WB_ABL_NOBAR
         lds_barrier();  // U stage 0 and V stage vs are complete; the other stages' readers are done
-#endif
         if (!t_role) {
 #pragma unroll
             for (int q = 0; q < 9; ++q) dma_u(c0, 1, 9 * tw4 + q);
@@ -415,9 +386,7 @@ __global__ __launch_bounds__(64 * WB_NW, 2) void wino43b_kernel(const Wino43bArg
         load_patch(c2, p, eduty, !t_role && c2.valid());
         // ---- second sub-chunk: U stage 1, V[vs][1] ----
         if (!t_role) dma_wait_n<7>();  // its pieces of U stage 1 (older than the seven requests)
-#ifndef WB_ABL_NOBAR
         lds_barrier();
-#endif
         if (t_role && c1.valid()) {
 #pragma unroll
             for (int q = 0; q < 9; ++q) dma_u(c1, 0, 9 * tw4 + q);
