@@ -46,6 +46,7 @@ struct ActBwdBody {
 
 // PReLU slope gradient: dslope[c] += sum dx*x*(x<0), taken BEFORE dx is rescaled (:213-216)
 struct PreluGradF {
+    static constexpr int kInFlight = 4;  // chan_reduce_partial's unroll
     const float* x;
     const float* dx;
     __device__ void operator()(long long off, int, float (&acc)[1]) const {

@@ -74,6 +74,7 @@ __device__ __forceinline__ void bn_bwd_consts_store(float4* consts, int c, const
 
 // ---- forward statistics --------------------------------------------------------------------------
 struct StatsF {
+    static constexpr int kInFlight = 4;  // chan_reduce_partial's unroll
     const float* x;
     __device__ void operator()(long long off, int, float (&acc)[2]) const {
         const float v = x[off];
@@ -247,6 +248,7 @@ __device__ __forceinline__ float bn_recompute_y(float x, float m, const BnDiv& r
 }
 
 struct BwdSumsF {
+    static constexpr int kInFlight = 2;  // chan_reduce_partial's unroll: <= 48 registers, see there
     const float* dy;
     const float* y;   // post-activation output, used only when act != NONE and fwd_bias == NULL
     const float* x;   // pre-normalisation input (workspace)

@@ -81,6 +81,7 @@ struct ChanMapBody {
 
 // ---- per-channel reductions ---------------------------------------------------------------------
 struct SumF {
+    static constexpr int kInFlight = 4;  // chan_reduce_partial's unroll
     const float* g;
     __device__ void operator()(long long off, int, float (&acc)[1]) const { acc[0] += g[off]; }
     __device__ void vec4(long long off, int, float (&acc)[1]) const {
@@ -91,6 +92,7 @@ struct SumF {
 // g = dy * act'(y) written back over dy, and summed: the activation backward and the bias gradient of a layer in
 // one sweep (the depthwise node runs them back to back, bcnn_depthwise_conv_layer.c:311-317)
 struct ActBwdSumF {
+    static constexpr int kInFlight = 4;  // chan_reduce_partial's unroll
     const float* y;
     float* dy;
     int act;
@@ -109,6 +111,7 @@ struct ActBwdSumF {
     }
 };
 struct DotF {
+    static constexpr int kInFlight = 4;  // chan_reduce_partial's unroll
     const float* g;
     const float* x;
     __device__ void operator()(long long off, int, float (&acc)[1]) const { acc[0] += g[off] * x[off]; }

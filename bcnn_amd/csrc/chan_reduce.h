@@ -32,7 +32,10 @@ inline int chan_splits(int channels, long long per_channel) {
 #ifdef __HIPCC__
 // F: struct with  __device__ void operator()(long long off, int c, float (&acc)[NV]) const  (one element)
 // and             __device__ void vec4(long long off, int c, float (&acc)[NV]) const        (4 consecutive)
-template <int NV, class F>
+// U: elements in flight per thread (unroll). The backward-sums functor runs with 2: its kernel then needs <= 48 registers and
+// two of its waves per SIMD fit NEXT TO the 2 x 192 registers of a fused Winograd weight-gradient workgroup -- inside a
+// backward pass these reductions run while the weight gradients occupy the chip on the side stream (conv.hip).
+template <int NV, class F, int U = 4>
 __global__ __launch_bounds__(256) void chan_reduce_partial(const F f, int C, int HW, int M /* N*HW */,
                                                            int splits, float* __restrict__ partials) {
     __shared__ float red[4][NV];
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(256) void chan_reduce_partial(const F f, int C, int
             int i = idx - n0 * HW;
             long long base = ((long long)n0 * C + c) * HW;
             const long long img = (long long)C * HW;
-#pragma unroll 4
+#pragma unroll U
             for (; idx < hi; idx += 256 * 4) {
                 f.vec4(base + i, c, acc);
                 i += 256 * 4;
@@ -68,7 +71,7 @@ __global__ __launch_bounds__(256) void chan_reduce_partial(const F f, int C, int
             int i = idx - n0 * HW;
             long long base = ((long long)n0 * C + c) * HW;
             const long long img = (long long)C * HW;
-#pragma unroll 4
+#pragma unroll U
             for (; idx < hi; idx += 256) {
                 f(base + i, c, acc);
                 i += 256;
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(256) void chan_reduce_partial(const F f, int C, int
 template <int NV, class F>
 inline void launch_chan_reduce(const F& f, int C, int HW, long long M, int splits, float* partials) {
     dim3 grid((unsigned)C, (unsigned)splits);
-    chan_reduce_partial<NV, F><<<grid, 256, 0, current_stream()>>>(f, C, HW, (int)M, splits, partials);
+    chan_reduce_partial<NV, F, F::kInFlight><<<grid, 256, 0, current_stream()>>>(f, C, HW, (int)M, splits, partials);
     KERNEL_CHECK();
 }
 #endif
