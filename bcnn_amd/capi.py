@@ -63,6 +63,7 @@ def lib():
         "bcnn_add_softmax_layer": (i, [vp, cp, cp]), "bcnn_add_cost_layer": (i, [vp, i, i, f, cp, cp, cp]),
         "bcnn_upload_tensor": (i, [vp, i, i]), "bcnn_download_tensor": (i, [vp, i, i]),
         "bcnn_set_data_parallel": (i, [vp, i, i]), "bcnn_set_data_parallel_comm": (i, [vp, i, i, cp]),
+        "bcnn_set_weight_gradient_stream": (None, [vp, i]),
         "bcnn_set_gradient_ready_callback": (None, [vp, vp, vp]),
         "bcnn_get_gradient_arena": (vp, [vp, C.POINTER(sz)]), "bcnn_get_parameter_arena": (vp, [vp, C.POINTER(sz)]),
         "bcnn_synchronize": (None, [vp]), "bcnn_peek_tensor": (tp, [vp, i]), "bcnn_get_num_nodes": (i, [vp]),

@@ -631,7 +631,7 @@ void bcnn_backward(bcnn_net *net) {
     hc->in_pass = 2;
     /* weight gradients on a side stream, next to the sweeps and data gradients of the layers in front (joined below, and
      * before anybody is told that gradients are final) */
-    const int side_prev = bcnn_hip_conv_side_stream_mode(BCNN_EXP_ENV("BCNN_NO_SIDE_STREAM") ? 0 : 2);
+    const int side_prev = bcnn_hip_conv_side_stream_mode((hc->no_side_stream || BCNN_EXP_ENV("BCNN_NO_SIDE_STREAM")) ? 0 : 2);
     for (int i = net->num_nodes - 1; i >= 0; --i) {
         net->nodes[i].backward(net, &net->nodes[i]);
         if (hc->grad_ready_fn && hc->node_grad_first && hc->node_grad_first[i] < ready_from) {
@@ -651,6 +651,8 @@ void bcnn_backward(bcnn_net *net) {
         bcnn_hip_comm_join(); /* bcnn_update (same stream) is ordered behind every bucket; the host does not block */
     }
 }
+
+void bcnn_set_weight_gradient_stream(bcnn_net *net, int enable) { hctx(net)->no_side_stream = enable ? 0 : 1; }
 
 void bcnn_set_gradient_ready_callback(bcnn_net *net, bcnn_gradient_ready_fn fn, void *user) {
     bcnn_hip_context *hc = hctx(net);

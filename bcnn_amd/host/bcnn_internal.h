@@ -165,6 +165,7 @@ typedef struct bcnn_hip_context {
     /* 1 inside bcnn_forward / 2 inside bcnn_backward: node workers may rely on their neighbours having run in this pass
      * (bcnn_forward_node / bcnn_backward_node run one worker alone: 0) */
     int in_pass;
+    int no_side_stream; /* bcnn_set_weight_gradient_stream(net, 0) */
 } bcnn_hip_context;
 
 /* ---- net ------------------------------------------------------------------------------------------ */

@@ -203,8 +203,8 @@ def class_table(prof, profiled_steps):
     return out
 
 
-def roofline_of(prof, workload, traffic_ok):
-    """roofline of the class that takes the most time inside the timed region"""
+def roofline_of(prof, workload, traffic_ok, pick=None):
+    """roofline of the class that takes the most time inside the timed region (pick: of that class instead)"""
     if not prof:
         return None
     # Each Winograd kernel serves the forward AND the dX class of its layers (wino_fused_kernel: F(2x2,3x3), classes
@@ -216,7 +216,9 @@ def roofline_of(prof, workload, traffic_ok):
         if fw or dx:
             parts = [p for p in (fw, dx) if p]
             prof["conv_fwd_dx_" + suffix] = {k: sum(p[k] for p in parts) for k in ("ms", "launches", "flops", "bytes", "useful_flops")}
-    name, d = max(prof.items(), key=lambda kv: kv[1]["ms"])
+    if pick is not None and pick not in prof:
+        return None
+    name, d = (pick, prof[pick]) if pick is not None else max(prof.items(), key=lambda kv: kv[1]["ms"])
     avg_ms = d["ms"] / d["launches"]
     tf = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["flops"] else 0.0
     gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
@@ -433,7 +435,25 @@ class Workload:
             dist.barrier()
         dt = time.perf_counter() - t0
         L.bcnn_hip_profile_enable(0)
-        return dt, read_profile(L), profiled
+        prof = read_profile(L)
+        # `alone` leg, OUTSIDE the timed region: a few more steps with the weight gradients on the caller's stream
+        # (bcnn_set_weight_gradient_stream(net, 0)), every launch timed -- what each kernel class takes when it has the chip to
+        # itself. Inside the timed region the weight gradients run next to the sweeps and data gradients of the layers in
+        # front, and a class's events span the time it shares the chip.
+        self.prof_alone = None
+        if self.net is not None and self.world == 1 and os.environ.get("BENCH_NO_ALONE_LEG") != "1":
+            capi_lib = self.net.L
+            capi_lib.bcnn_set_weight_gradient_stream(self.net.net, 0)
+            self.step(); L.bcnn_hip_sync()
+            L.bcnn_hip_profile_reset()
+            L.bcnn_hip_profile_enable(1)
+            for _ in range(3):
+                self.step()
+            L.bcnn_hip_sync()
+            L.bcnn_hip_profile_enable(0)
+            self.prof_alone = (read_profile(L), 3)
+            capi_lib.bcnn_set_weight_gradient_stream(self.net.net, 1)
+        return dt, prof, profiled
 
     def close(self):
         self.L.bcnn_hip_sync()
@@ -569,6 +589,18 @@ def main():
     overlap = not args.no_overlap and os.environ.get("BENCH_NO_OVERLAP") != "1"
     wl = Workload(args.workload, n, rank, world, dev, L, stream, input_grad=args.input_grad, overlap=overlap, comm=args.comm)
     dt, prof, profiled_steps = wl.run(args.steps, args.warmup)
+
+    def with_alone(roof, w, workload):
+        """the dominant class once more from the untimed `alone` leg (weight gradients on the caller's stream)"""
+        pa = getattr(w, "prof_alone", None)
+        if roof and pa:
+            al = roofline_of(pa[0], workload, False, pick=roof["kernel"])
+            if al:
+                roof["alone"] = {"avg_ms": al["avg_ms"], "achieved": al["achieved"], "frac": al["frac"], "unit": al["unit"],
+                                 "note": "same class in 3 untimed steps with every kernel on one stream: in the timed region it "
+                                         "shares the chip with the other stream's kernels and its events span that time"}
+        return roof
+
     if world > 1:
         tmax = torch.tensor([dt], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -586,9 +618,10 @@ def main():
                        "comm": ("none (one rank)" if world == 1 and os.environ.get("BENCH_FORCE_DP") != "1" else
                                 "in-library RCCL (csrc/comm.hip, bcnn_set_data_parallel_comm)" if args.comm == "inlib" else
                                 "torch.distributed (%s)" % dist.get_backend())},
-            "roofline": roofline_of(prof, args.workload, default_shape),
+            "roofline": with_alone(roofline_of(prof, args.workload, default_shape), wl, args.workload),
             "profiled_steps": profiled_steps,
             "kernel_classes": class_table(prof, profiled_steps),
+            "kernel_classes_alone": class_table(*wl.prof_alone) if getattr(wl, "prof_alone", None) else None,
             # bcnn_backward queues the weight-gradient kernels on a second HIP stream of the library (include/bcnn_hip.h:
             # bcnn_hip_conv_side_stream_mode), where they run next to the batch-norm / pooling sweeps and the data gradients
             # of the layers in front. Each class is timed with HIP events on the stream its kernels are launched on, so the
@@ -617,8 +650,9 @@ def main():
             side[name] = {"config": w2.desc, "images_per_s": round(ssteps * sn / sdt, 2),
                           "ms_per_step": round(sdt / ssteps * 1e3, 4), "steps": ssteps, "warmup": swarm,
                           "warmup_extra": w2.warmup_extra,
-                          "roofline": roofline_of(sprof, name, True),
-                          "kernel_classes": class_table(sprof, sprofiled)}
+                          "roofline": with_alone(roofline_of(sprof, name, True), w2, name),
+                          "kernel_classes": class_table(sprof, sprofiled),
+                          "kernel_classes_alone": class_table(*w2.prof_alone) if getattr(w2, "prof_alone", None) else None}
             side_sample = w2.sample_n
             w2.close()
             del w2

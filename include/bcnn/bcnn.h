@@ -214,6 +214,11 @@ BCNN_API bcnn_status bcnn_set_data_parallel(bcnn_net *net, int rank, int world_s
  * communicator is destroyed by bcnn_end_net. A launcher that runs the collective itself (bench.py through
  * torch.distributed) keeps using bcnn_set_data_parallel + bcnn_get_gradient_arena. */
 BCNN_API bcnn_status bcnn_set_data_parallel_comm(bcnn_net *net, int rank, int world_size, const char *id_path);
+/* bcnn_backward queues the weight-gradient kernels of a pass on a second stream of the library, next to the sweeps and
+ * data gradients of the layers in front, and joins it at the end of the pass (include/bcnn_hip.h:
+ * bcnn_hip_conv_side_stream_mode). enable = 0 keeps everything on the caller's stream (a profiler
+ * that wants every kernel alone, bench.py's `roofline.alone` leg); the results are the same bit for bit either way. */
+BCNN_API void bcnn_set_weight_gradient_stream(bcnn_net *net, int enable);
 BCNN_API float *bcnn_get_gradient_arena(bcnn_net *net, size_t *num_floats);  /* device pointer */
 BCNN_API float *bcnn_get_parameter_arena(bcnn_net *net, size_t *num_floats); /* device pointer */
 /* Overlap of the gradient all-reduce with backward. Parameters sit in the arena in node order and backward
