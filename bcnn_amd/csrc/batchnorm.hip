@@ -483,6 +483,10 @@ void batchnorm_forward_impl(const float* x, float* y, float* run_mean, float* ru
     }
     if (stats_only) return;  // the consumer normalises on the fly (bcnn_hip_maxpool_forward_bn)
     auto al16 = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+#ifdef BCNN_HIP_EXPERIMENT
+    static const int skip_fw = getenv("BCNN_HIP_SKIP_SWEEPS") ? atoi(getenv("BCNN_HIP_SKIP_SWEEPS")) : 0;
+    if (!(skip_fw & 4))
+#endif
     launch_chan_map(BnApplyBody{a, al16(x) && al16(y) && al16(a.ws) && al16(a.xn) && al16(a.res)}, n, c, hw);
     if (want_act != act) bcnn_hip_activation_forward(y, (size_t)total, want_act, nullptr, hw, c);
 }
@@ -538,6 +542,14 @@ void batchnorm_backward_sums(const float* dy, const float* y, int act, const flo
     BwdSumsF f;
     f.dy = dy; f.y = y; f.x = workspace; f.mean = saved_mean; f.act = act; f.C = c; f.HW = hw;
     f.fwd_bias = fwd_bias; f.var = saved_var; f.scale = scales; f.res = res; f.res_count = res_count;
+#ifdef BCNN_HIP_EXPERIMENT
+    // timing experiment (wrong results): what the step gains if the sums of the conv1 batch-norms of the 56 x 56 / 28 x 28 blocks
+    // came from the data-gradient kernel behind them instead of this sweep
+    static const int skip_exp = getenv("BCNN_HIP_SKIP_C1_SUMS") ? 1 : 0;
+    static const int skip_all = getenv("BCNN_HIP_SKIP_SWEEPS") ? atoi(getenv("BCNN_HIP_SKIP_SWEEPS")) : 0;  // 1 sums, 2 bwd apply, 4 fwd apply
+    if (!(skip_all & 1))
+    if (!(skip_exp && res == nullptr && act == BCNN_HIP_ACT_RELU && ((hw == 3136 && c == 64) || (hw == 784 && c == 128))))
+#endif
     launch_chan_reduce<2>(f, c, hw, M, splits, part);
     bn_bwd_finalize_kernel<<<ceil_div(c, 256), 256, 0, current_stream()>>>(part, c, splits, scales, saved_var,
                                                                           dbias, dscales, dmean, dvar, consts, saved_mean,
@@ -560,6 +572,10 @@ static void batchnorm_backward_apply(float* dy, float* dx, const float* y, int a
     a.C = c; a.HW = hw; a.act = act; a.M = (int)M; a.total = total; a.fwd_bias = fwd_bias;
     a.keep_dy = keep_dy; a.res = res; a.res_count = res_count;
     auto al16 = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+#ifdef BCNN_HIP_EXPERIMENT
+    static const int skip_bw = getenv("BCNN_HIP_SKIP_SWEEPS") ? atoi(getenv("BCNN_HIP_SKIP_SWEEPS")) : 0;
+    if (skip_bw & 2) return;
+#endif
     launch_chan_map(BnBwdApplyBody{a, al16(dy) && al16(a.dx) && al16(workspace) && al16(y)}, n, c, hw);
 }
 
