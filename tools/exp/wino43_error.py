@@ -50,20 +50,21 @@ def direct64(x, w):
     return y
 
 
-rs = np.random.RandomState(0)
-print("%-22s %-10s %-12s %12s %14s" % ("stage", "input", "algorithm", "rel (1e-4)", "element (<=1)"))
-for name, C, HW in (("64 ch 56x56", 64, 56), ("128 ch 28x28", 128, 28), ("256 ch 14x14 (pad 16)", 256, 16), ("512 ch 7x7 (pad 8)", 512, 8)):
-    # "relu": the input of such a layer in the forward pass (a ReLU output: non-negative, half zeros); "zero-mean": what the data
-    # gradient convolves (the gradient behind a batch-norm: white, zero mean per channel; round 6 asked whether the transforms'
-    # cancellation is worse there: hardly, 4.7e-6 ... 9.2e-6 against 4.6e-6 ... 5.8e-6)
-    for dist in ("relu", "zero-mean"):
-        x = rs.uniform(-1, 1, (C, HW, HW)).astype(f32)
-        if dist == "relu":
-            x *= (x > 0)
-        w = (rs.uniform(-1, 1, (8, C, 3, 3)) * (3.0 / (C * 9)) ** 0.5).astype(f32)
-        ref = direct64(x, w)
-        for alg, args in (("F(2x2,3x3)", (BT2, G2, AT2, 2)), ("F(4x4,3x3)", (BT4, G4, AT4, 4))):
-            y = wino(x, w, *args).astype(np.float64)
-            rel = np.abs(y - ref).max() / np.abs(ref).max()
-            bound = 1e-4 * np.abs(ref) + 1e-5 * np.abs(ref).max()
-            print("%-22s %-10s %-12s %12.2e %14.3f" % (name, dist, alg, rel, (np.abs(y - ref) / bound).max()), flush=True)
+if __name__ == "__main__":
+    rs = np.random.RandomState(0)
+    print("%-22s %-10s %-12s %12s %14s" % ("stage", "input", "algorithm", "rel (1e-4)", "element (<=1)"))
+    for name, C, HW in (("64 ch 56x56", 64, 56), ("128 ch 28x28", 128, 28), ("256 ch 14x14 (pad 16)", 256, 16), ("512 ch 7x7 (pad 8)", 512, 8)):
+        # "relu": the input of such a layer in the forward pass (a ReLU output: non-negative, half zeros); "zero-mean": what the data
+        # gradient convolves (the gradient behind a batch-norm: white, zero mean per channel; round 6 asked whether the transforms'
+        # cancellation is worse there: hardly, 4.7e-6 ... 9.2e-6 against 4.6e-6 ... 5.8e-6)
+        for dist in ("relu", "zero-mean"):
+            x = rs.uniform(-1, 1, (C, HW, HW)).astype(f32)
+            if dist == "relu":
+                x *= (x > 0)
+            w = (rs.uniform(-1, 1, (8, C, 3, 3)) * (3.0 / (C * 9)) ** 0.5).astype(f32)
+            ref = direct64(x, w)
+            for alg, args in (("F(2x2,3x3)", (BT2, G2, AT2, 2)), ("F(4x4,3x3)", (BT4, G4, AT4, 4))):
+                y = wino(x, w, *args).astype(np.float64)
+                rel = np.abs(y - ref).max() / np.abs(ref).max()
+                bound = 1e-4 * np.abs(ref) + 1e-5 * np.abs(ref).max()
+                print("%-22s %-10s %-12s %12.2e %14.3f" % (name, dist, alg, rel, (np.abs(y - ref) / bound).max()), flush=True)
