@@ -148,11 +148,7 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_direct_kernel(const ConvDirec
         return qvalid ? m : 0u;
     };
     auto ldx = [&](unsigned off) -> float {
-#ifdef ABL_NOLOAD
-        return __builtin_bit_cast(float, (off & 0x007fffffu) | 0x3f800000u);
-#else
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off, 0, 0));
-#endif
     };
 
     // ---- tile pipeline ---------------------------------------------------------------------------
@@ -169,9 +165,6 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_direct_kernel(const ConvDirec
                                 // (a tap with k >= K carries OOB = 2^31: pixel + 2^31 stays out of range for tensors < 1 GiB)
 #pragma unroll
             for (int st = 0; st < KS; ++st) {
-#ifdef ABL_FEWGATHER   // timing experiment: only every ABL_FEWGATHER-th gather is real
-                if (st % ABL_FEWGATHER != 0) { buf[st] = buf[st - st % ABL_FEWGATHER]; continue; }
-#endif
                 buf[st] = ldx(pixb + koffb[st]);
             }
         } else {                // border tile (or tail): invalid taps get an out-of-range offset => 0
@@ -206,12 +199,7 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_direct_kernel(const ConvDirec
         for (int st = 0; st < KS; ++st)
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
-#ifdef ABL_NOMFMA
-                if (st == 0) acc[tm] = mfma32(areg[tm][st], buf[st], acc[tm]);
-                else acc[tm][st & 15] += areg[tm][st] * buf[st];
-#else
                 acc[tm] = mfma32(areg[tm][st], buf[st], acc[tm]);
-#endif
             }
     };
     // epilogue on the accumulators: activation, one store per element.
@@ -263,16 +251,8 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_direct_kernel(const ConvDirec
     unsigned yprev = OOB;
     bool have_prev = false;
     // ablation switches for tools/exp (normal builds define none of them)
-#ifdef ABL_NOWAIT
-#define DIRECT_WAIT()
-#else
 #define DIRECT_WAIT() __builtin_amdgcn_s_waitcnt(0x0f70)
-#endif
-#ifdef ABL_NOSTORE
-#define DIRECT_STORE(y) do { if (a.act == 12345) store_tile(y); } while (0)
-#else
 #define DIRECT_STORE(y) store_tile(y)
-#endif
     // one pipeline stage: `cur` holds tile t's operands (issued one stage ago), `nxt` receives tile t+4's
 #define DIRECT_STAGE(cur, nxt)                                                                          \
     {                                                                                                   \
@@ -434,10 +414,6 @@ __device__ __forceinline__ DwFrag<TM> dw_load_window(const ConvDirectDwArgs& a, 
 template <int TM>
 __global__ __launch_bounds__(256) void conv_dw_direct_kernel(const ConvDirectDwArgs a) {
     __shared__ float red[3][TM * 32][33];
-#ifdef ABL_DW_LDSPAD   // occupancy experiment: extra LDS per workgroup
-    __shared__ float ldspad[ABL_DW_LDSPAD / 4];
-    if (a.nwin == -12345) ldspad[threadIdx.x] = 1.f, red[0][0][0] = ldspad[threadIdx.x ^ 1];
-#endif
     const ConvShape& s = a.s;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;

@@ -164,9 +164,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_dw_dma_kernel(const DwDmaAr
         if (it + 1 < nkt) {
             advance();
             lane_offsets();
-#ifndef ABL_NODMA
             stage(cur ^ 1);  // DMA in flight under the MFMAs
-#endif
         }
         const float* buf = lds + cur * BUF;
 #pragma unroll
@@ -185,10 +183,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_dw_dma_kernel(const DwDmaAr
 #pragma unroll
                 for (int j = 0; j < WTN; ++j) acc[i][j] = mfma32(av[i].y, bv[j].y, acc[i][j]);
         }
-#ifndef ABL_NOBAR
         dma_wait();
         __syncthreads();
-#endif
     }
 
     // ---- publish the partial tile ---------------------------------------------------------------------

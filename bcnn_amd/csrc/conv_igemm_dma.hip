@@ -24,8 +24,8 @@
 #include "lds_dma.h"
 
 // ---- compile-time tuning knobs (defaults = what is measured best; tools/exp/build_variant.sh DEFS=-D... builds
-// an alternative library for A/B runs). ABL_* macros (ABL_NODMA, ABL_NOBAR, ABL_NOSTORE, ABL_SETPRIO, ABL_CLOCK)
-// are ablation / instrumentation switches that are never defined in the product build.
+// an alternative library for A/B runs). The timing-only ablation switches of rounds 1-5 (ABL_NODMA, ABL_NOBAR, ABL_NOSTORE,
+// ABL_SETPRIO, ABL_CLOCK) were taken out of the file at the end of round 6; `git log -S ABL_NODMA` has them.
 #ifndef DMA_BK
 #define DMA_BK 16            // reduction rows per K-tile; 32 halves the barriers at twice the LDS: +-0
 #endif
@@ -48,13 +48,6 @@ constexpr int kDmaBK = DMA_BK;   // reduction rows per K-tile (one barrier per t
 constexpr int kDmaMaxTaps = 49;
 constexpr int kDmaMaxClasses = 4;
 
-#ifdef ABL_CLOCK
-__device__ unsigned long long g_dma_clk[2];
-extern "C" void bcnn_hip_debug_read_clock(unsigned long long* out) {
-    (void)hipDeviceSynchronize();
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dma_clk), 16);
-}
-#endif
 
 struct DmaClass {
     int ih0, iw0, Hc, Wc;  // dX: first row/col and extent of the stride-parity class (forward: 0,0,OH,OW)
@@ -125,9 +118,6 @@ __global__ __launch_bounds__(64 * WM * WN, ABL_LB) void conv_igemm_dma_kernel(co
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid / WN, wn = wid % WN;
     const int g = blockIdx.y;
-#ifdef ABL_CLOCK
-    const unsigned long long clk_c0 = clock64(), clk_t0 = wall_clock64();
-#endif
     const DmaClass& ci = a.cls[blockIdx.z];
     const int lb = xcd_remap(blockIdx.x, gridDim.x);
     const int mt = lb % a.mtiles, pt = lb / a.mtiles;
@@ -294,12 +284,7 @@ __global__ __launch_bounds__(64 * WM * WN, ABL_LB) void conv_igemm_dma_kernel(co
         constexpr int CUR = decltype(CURT)::value;
         const int c = CUR >= 0 ? CUR : cur;
         const int f = CUR >= 0 ? (CUR + NS - 1) % NS : fill;
-#ifndef ABL_NODMA
         if (it + NS - 1 < ntiles) request_next(f);  // DMA in flight under the MFMAs
-#endif
-#ifdef ABL_SETPRIO
-        __builtin_amdgcn_s_setprio(ABL_SETPRIO);
-#endif
         // fragments of k-step ks+1 are fetched from LDS before the MFMAs of k-step ks are issued
         float af[2][TM], bf[2][TN];
 #pragma unroll
@@ -322,13 +307,8 @@ __global__ __launch_bounds__(64 * WM * WN, ABL_LB) void conv_igemm_dma_kernel(co
                 for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(af[fc][i], bf[fc][j], acc[i][j]);
             __builtin_amdgcn_sched_barrier(0);
         }
-#ifdef ABL_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
-#ifndef ABL_NOBAR
         if (NS == 3 && it + 2 < ntiles) dma_wait_n<LOADS_PER_TILE>(); else dma_wait();
         __syncthreads();
-#endif
         if (CUR < 0) {
             cur = (cur + 1 == NS) ? 0 : cur + 1;
             fill = (fill + 1 == NS) ? 0 : fill + 1;
@@ -468,12 +448,6 @@ __global__ __launch_bounds__(64 * WM * WN, ABL_LB) void conv_igemm_dma_kernel(co
         }
     }
 
-#ifdef ABL_CLOCK
-    if (blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) {
-        g_dma_clk[0] = clock64() - clk_c0;        // shader cycles over this workgroup's K loop
-        g_dma_clk[1] = wall_clock64() - clk_t0;   // 100 MHz ticks
-    }
-#endif
     // ---- epilogue ------------------------------------------------------------------------------------
     // 32-bit element offsets against the output base (tensors are < 2 GiB here), the 16 rows of an
     // accumulator at compile-time multiples of the wave-uniform row stride, and no per-value predicate or
@@ -505,9 +479,6 @@ __global__ __launch_bounds__(64 * WM * WN, ABL_LB) void conv_igemm_dma_kernel(co
                     if (b != 0.0f) o += b;
                     if (a.act != BCNN_HIP_ACT_NONE) o = act_fwd_cheap(o, a.act, s_slope[row0 + mr]);
                 }
-#ifdef ABL_NOSTORE
-                if (o == 123.456f)
-#endif
 #ifdef NT_STORES   // experiment: the result tensor as a streaming store (tools/micro/mall_probe.hip)
                 __builtin_nontemporal_store(o, &a.out[off0 + (unsigned)mr * o_row_stride]);
 #else

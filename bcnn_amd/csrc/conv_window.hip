@@ -21,9 +21,9 @@
 
 #include <mutex>
 
-// Timing experiments (tools/exp/win_variants.sh builds the file with -DWABL_*; normal builds define none of them):
-// WABL_NOSTORE / WABL_NOMFMA (forward), WABL_FWD_R (strip height), WABL_NW (multiplying waves), WABL_NBUF, WABL_PREFETCH, ROWS_TM,
-// ROWS_INTERLEAVE, DY_DMA_PLAIN, ROWS_ABL_NODMA / ROWS_ABL_NOMFMA (dW; timing only).
+// Tuning knobs (tools/exp/win_variants.sh builds the file with -D...): WABL_FWD_R (strip height), WABL_NW (multiplying waves),
+// WABL_NBUF, ROWS_TM, ROWS_INTERLEAVE, DY_DMA_PLAIN. The timing-only switches of round 5 (WABL_NOSTORE / WABL_NOMFMA / WABL_PREFETCH,
+// ROWS_ABL_NODMA / ROWS_ABL_NOMFMA: wrong results, right time) were taken out at the end of round 6; `git log -S ROWS_ABL_NODMA`.
 #ifndef WABL_FWD_R
 #define WABL_FWD_R 4  // output rows per strip (round 5: the loader wave hides the fill, so the halo rows of short strips cost nothing;
 #endif                // forward-only loops 0.275 ms with 4 rows against 0.293 with 8, inside the fwd / dW alternation 0.305 / 0.31)
@@ -268,22 +268,8 @@ __global__ __launch_bounds__(64 * (NW + 1), 2) void conv_fwd_window_kernel(const
         for (int st = 0; st < KS; ++st)
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
-#ifdef WABL_NOMFMA
-                if (st > 0) { acc[tm][st & 15] += areg[tm][st] * b[st]; continue; }
-#endif
                 acc[tm] = mfma32(areg[tm][st], b[st], acc[tm]);
             }
-#ifdef WABL_NOSTORE
-        if (a.act != 12345) {
-            float sink = 0.f;
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sink += acc[tm][r];
-            if (sink == 123456.789f) buffer_store_f32(sink, ry, (int)ycur, 0, 0);
-            return;
-        }
-#endif
         unsigned fs = fstride;
         asm volatile("" : "+s"(fs));  // recompute the 32 scalar channel offsets per tile instead of pinning 32 SGPRs
 #pragma unroll
@@ -405,9 +391,6 @@ bool conv_forward_window(const float* x, const float* w, const float* bias, cons
     const int pitch = window_pitch(s);
     KTimer kt(K_CONV_FWD, 2.0 * (double)s.total_q * s.Mg * s.K * s.groups,
               4.0 * ((double)s.N * s.C * s.HW + (double)s.F * s.K + (double)s.N * s.F * s.OHOW));
-#ifdef WABL_PREFETCH
-    conv_prefetch_input(x, s, y);
-#endif
     // One workgroup per CU (fewer when there are fewer strips); strips beyond the first round are handed out by a device counter.
     const int nunits = s.N * a.strips;
     a.sched = window_sched_slot(s.groups);
@@ -827,11 +810,7 @@ __global__ __launch_bounds__(256 * TM, 1) void conv_dw_rows_kernel(const ConvRow
     for (int r = r0; r < r1; ++r) {
         const int nbuf = buf == 0 ? NS - 1 : buf - 1;  // the stage read during row r - 1: free for row r + NS - 1
         const int nn = (r + NS - 1) / s.OH, noh = (r + NS - 1) - nn * s.OH;  // the row requested during this one
-#ifdef ROWS_ABL_NODMA   // timing only: every row multiplies what the first request left in LDS
-        const int kend = 0;
-#else
         const int kend = (r + NS - 1 < r1) ? NREQ : 0;
-#endif
         int k = 0;
 #ifdef ROWS_BURST
         while (k < kend) { request(k, nn, noh, nbuf); ++k; }
@@ -850,11 +829,7 @@ __global__ __launch_bounds__(256 * TM, 1) void conv_dw_rows_kernel(const ConvRow
             float bvA[4], bvB[4];
             read_window(avA, bvA);
             int w = slot;
-#ifdef ROWS_ABL_NOMFMA  // timing only
-#define ROWS_MFMA(ca, cb) _Pragma("unroll") for (int e = 0; e < 4; ++e) acc[e] += ca[e] * cb[e];
-#else
 #define ROWS_MFMA(ca, cb) _Pragma("unroll") for (int e = 0; e < 4; ++e) acc = mfma32(ca[e], cb[e], acc);
-#endif
 #define ROWS_STAGE(ca, cb, na, nb)                                                                 \
             {                                                                                      \
                 const bool more = (w + 4 < nwin); /* uniform */                                    \

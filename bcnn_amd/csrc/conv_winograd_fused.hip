@@ -61,16 +61,7 @@ struct WinoFusedArgs {
 #define WF_LATE_AFTER 1  // the late half produces after this k-step (0..3) of its multiply
 #endif
 
-#ifdef WF_ABL_CLOCK
-__device__ unsigned long long g_wf_clk[8][48];
-extern "C" void bcnn_hip_debug_read_wf_clock(unsigned long long* out) {
-    (void)hipDeviceSynchronize();
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wf_clk), sizeof(g_wf_clk));
-}
-#define WF_STAMP(i) do { if (stamp_on && lane == 0) g_wf_clk[wid][i] = clock64(); } while (0)
-#else
 #define WF_STAMP(i) do { } while (0)
-#endif
 
 // EPI: 0 = plain store, 1 = bias + ReLU, 2 = bias + any other cheap activation (runtime switch); STATS: per-channel
 // sum / sum of squares of the raw outputs for a batch-norm that follows (EPI == 0 only)
@@ -161,9 +152,6 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
         }
     };
     auto dma_u = [&](int kc, int stage) {  // each wave brings in two positions: 2 x 8 rows of 64 floats
-#ifdef WF_ABL_NODMA
-        if (kc > 0) return;
-#endif
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int xi = 2 * wid + (q >> 1), r0 = (q & 1) * 4;
@@ -190,15 +178,6 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
             tt[3][j] = d[1][j] - d[3][j];
         }
         float* v = lds + stage * WF_STAGE + 16 * WF_KC * WF_BF + wid * WF_BT + lane;
-#ifdef WF_ABL_NOVWRITE
-        {
-            float sum = 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) sum += (tt[i][0] - tt[i][2]) + (tt[i][1] + tt[i][2]) * 2.f + (tt[i][2] - tt[i][1]) * 3.f + (tt[i][1] - tt[i][3]) * 5.f;
-            if (sum == 123.456f) v[0] = sum;
-            return;
-        }
-#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             v[(4 * i + 0) * WF_KC * WF_BT] = tt[i][0] - tt[i][2];
@@ -230,24 +209,17 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
         else { unit = pa_unit + 1; kb = 0; nchunks = pb_n; slot = 2 * (int)blockIdx.x + 1; }
         decode(unit);
         dma_u(0, 0);
-#ifndef WF_ABL_NOXFORM
         load_patch(0);
-#endif
     };
     auto finish_start = [&]() {
-#ifndef WF_ABL_NOXFORM
         write_v(0);
         if (nchunks > 1) load_patch(1);  // every wave holds the next chunk's patches in registers
-#endif
     };
 
     if (nitems == 0) return;
     start_unit(0);
     finish_start();
     for (int it = 0; it < nitems; ++it) {
-#ifdef WF_ABL_CLOCK
-        const bool stamp_on = blockIdx.x == 37 && it == 1;
-#endif
         WF_STAMP(0);
         WF_STAMP(1);
         WF_STAMP(2);
@@ -261,27 +233,11 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
         // everything chunk kc contributes to the chunks after it: V of chunk kc + 1 from the patches requested a whole
         // chunk ago, the patch requests of chunk kc + 2 into the registers this frees, the U slab of chunk kc + 1
         auto produce = [&](int kc) {
-#ifdef WF_ABL_CLOCK
-            if (kc == 3) { WF_STAMP(40); dma_wait(); WF_STAMP(44); }
-#endif
-#ifndef WF_ABL_NOXFORM
             if (kc + 1 < nchunks) write_v((kc & 1) ^ 1);
-#ifdef WF_ABL_CLOCK
-            if (kc == 3) WF_STAMP(41);
-#endif
-#endif
             // the U slab first: it is what the barrier at the end of this chunk waits for -- the patch requests behind it
             // (needed a whole chunk later) may still be in flight then (vmcnt retires in order)
             if (kc + 1 < nchunks) dma_u(kc + 1, (kc & 1) ^ 1);
-#ifdef WF_ABL_CLOCK
-            if (kc == 3) WF_STAMP(42);
-#endif
-#ifndef WF_ABL_NOXFORM
             if (kc + 2 < nchunks) load_patch(kc + 2);
-#endif
-#ifdef WF_ABL_CLOCK
-            if (kc == 3) WF_STAMP(43);
-#endif
         };
         // 32 MFMAs on stage `cur`; the late half produces (see above) between the second and the third k-step
         auto multiply = [&](int cur, int produce_kc, bool first, int kc_stamp) {
@@ -298,11 +254,7 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
 #pragma unroll
             for (int ks = 0; ks < WF_KC / 2; ++ks) {
                 const int fc = ks & 1, fn = fc ^ 1;
-#ifdef WF_ABL_NOLDSRD
-                if (false) {
-#else
                 if (ks + 1 < WF_KC / 2) {
-#endif
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         af[fn][j] = us[(j * WF_KC + 2 * ks + 2 + lhi) * WF_BF];
@@ -310,12 +262,6 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
                         bf[fn][j][1] = vs[(j * WF_KC + 2 * ks + 2 + lhi) * WF_BT + 32];
                     }
                 }
-#ifdef WF_ABL_NOLDSRD
-                if (ks + 1 < WF_KC / 2) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { af[fn][j] = af[fc][j] + 1.f; bf[fn][j][0] = bf[fc][j][0]; bf[fn][j][1] = bf[fc][j][1]; }
-                }
-#endif
                 __builtin_amdgcn_sched_barrier(0);
                 if (ks == 0 && first) {  // uniform
                     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -327,13 +273,8 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-#ifndef WF_ABL_NOMFMA
                         acc[j][0] = mfma32(af[fc][j], bf[fc][j][0], acc[j][0]);
                         if (whole) acc[j][1] = mfma32(af[fc][j], bf[fc][j][1], acc[j][1]);  // uniform
-#else
-                        acc[j][0][0] += af[fc][j] * bf[fc][j][0];
-                        acc[j][1][0] += af[fc][j] * bf[fc][j][1];
-#endif
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -341,9 +282,6 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
                     produce(produce_kc);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-#ifdef WF_ABL_CLOCK
-                if (kc_stamp == 3 || kc_stamp == 4) WF_STAMP(32 + 4 * (kc_stamp - 3) + ks);
-#endif
             }
         };
 
@@ -358,14 +296,8 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
             multiply(cur, early ? -1 : kc, kc == 0, kc);
             __builtin_amdgcn_sched_barrier(0);
             if (kc < 8) WF_STAMP(6 + 3 * kc);
-#ifndef WF_ABL_NOXFORM
             if (kc + 2 < nchunks) dma_wait_n<8>(); else dma_wait();  // uniform; 8 = the loads of one load_patch
-#else
-            dma_wait();
-#endif
-#ifndef WF_ABL_NOBAR
             __syncthreads();
-#endif
         }
 
         // ---- epilogue, with the next unit's chunk 0 started underneath it ---------------------------------
@@ -375,20 +307,6 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
         const unsigned e_n = n;
         const bool has_next = it + 1 < nitems;
         if (has_next) start_unit(it + 1);  // both stages are free: the K loop ended with a barrier
-#ifdef WF_ABL_NOEPI
-        {
-            float sum = 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) sum += acc[j][tt][r];
-            if (sum == 123.456f) a.dst[0] = sum;
-            if (has_next) finish_start();
-            continue;
-        }
-#endif
         const bool two_cols = ow + 1 < a.W, two_rows = oh + 1 < a.H;
         // byte offsets of this lane's 2 x 2 outputs in channel 0 of its image; out of range = not stored
         const unsigned o00 = e_tile_ok ? (e_n * (unsigned)a.M * (unsigned)HW + (unsigned)(oh * a.W + ow)) * 4u : kOOB;
@@ -462,7 +380,6 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
                     buffer_store_f32x2(buf_f32x2{o[1][0], o[1][1]}, rs_scr, (int)(so + 8u), 0, 0);
                     continue;
                 }
-#ifndef WF_ABL_NOSTORE
                 if (!odd_w) {  // uniform; rows start 8-byte aligned and ow is even
                     buffer_store_f32x2(buf_f32x2{o[0][0], o[0][1]}, rs_dst, (int)(o00 | kill), soff, 0);
                     buffer_store_f32x2(buf_f32x2{o[1][0], o[1][1]}, rs_dst, (int)(o10 | kill), soff, 0);
@@ -472,7 +389,6 @@ __global__ __launch_bounds__(512, 2) void wino_fused_kernel(const WinoFusedArgs 
                     buffer_store_f32(o[1][0], rs_dst, (int)(o10 | kill), soff, 0);
                     buffer_store_f32(o[1][1], rs_dst, (int)(o11 | kill), soff, 0);
                 }
-#endif
                 if (STATS) {  // this wave holds channel f for the workgroup's 64 tiles
                     // masked by multiplication: lanes without a tile / a second row / a second column add 0.0
                     const float sv0 = (o[0][0] + o[0][1] * w01) * w00, sv1 = (o[1][0] + o[1][1] * w01) * w10;
@@ -1016,13 +932,11 @@ __global__ __launch_bounds__(512, 2) void wino_dw_fused_kernel(const WinoDwArgs 
         const int cur = kc & 1, nxt = cur ^ 1;
         const bool more = kc + 1 < nchunks, more2 = kc + 2 < nchunks;
         auto produce = [&]() {  // V / dM of chunk kc + 1 from the registers, then the requests of chunk kc + 2 into them
-#ifndef WD_ABL_NOXFORM
             if (more) write_items(nxt);
             if (more2) {
                 advance();
                 load_items();
             }
-#endif
         };
         if (early) produce();
         __builtin_amdgcn_sched_barrier(0);  // requests first, then the MFMAs they fly under
@@ -1046,11 +960,7 @@ __global__ __launch_bounds__(512, 2) void wino_dw_fused_kernel(const WinoDwArgs 
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-#ifndef WD_ABL_NOMFMA
                         acc[e][i][j] = mfma32(af[e][i], bf[e][j], acc[e][i][j]);
-#else
-                        acc[e][i][j][0] += af[e][i] * bf[e][j];
-#endif
                     }
             if (ks == WD_KT / 4 - 1 && !early) {  // uniform per wave
                 __builtin_amdgcn_sched_barrier(0);

@@ -237,9 +237,6 @@ __device__ __forceinline__ Row<V> dwm_row(const Vals<V>& x, const DwmLane& m) {
 #pragma unroll
     for (int i = 0; i < V; ++i) r.v[1 + i] = x.v[i];
     r.v[0] = r.v[V + 1] = 0.f;
-#ifdef DWM_ABL_NOPERM   // timing only (tools/exp/variant.sh NAME depthwise_march "-DDWM_ABL_..."): wrong results
-    return r;
-#endif
     if (LEFT) {
         const float l = dwm_from(m.addr_l, x.v[V - 1]);
         r.v[0] = m.first ? 0.f : l;
@@ -272,9 +269,6 @@ __device__ __forceinline__ DwmBnInC dwm_bnin_consts(const DwBnIn& in, int c) {
     return k;
 }
 __device__ __forceinline__ float dwm_bnin(float x, const DwmBnInC& k, int act) {
-#ifdef DWM_ABL_NOBNIN
-    return x;
-#endif
     float v = bn_div(__fsub_rn(x, k.mean), k.rs);
     v = __fmul_rn(v, k.sc);
     if (k.any_sc0 && k.sc0) v = 0.f;  // wave-uniform first: no channel of a trained net has a scale of exactly 0
@@ -495,13 +489,7 @@ __global__ __launch_bounds__(256, V == 4 ? DWM_BWD_WAVES : DWM_BWD_WAVES_SMALL) 
     float w[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) w[i] = a.w[m.c * 9 + i];
-#ifdef DWM_ABL_NOCONST   // timing only: no dependent constant loads / sqrt / divide chain in the prologue
-#pragma unroll
-    for (int i = 0; i < 9; ++i) w[i] = 0.1f * (float)(i + 1);
-#define DWM_CONST(expr, val) (val)
-#else
 #define DWM_CONST(expr, val) (expr)
-#endif
     DwmBnC kb;
     if (BN) {
         kb.mean = DWM_CONST(a.bn.mean[m.c], 0.1f);
@@ -515,9 +503,6 @@ __global__ __launch_bounds__(256, V == 4 ? DWM_BWD_WAVES : DWM_BWD_WAVES_SMALL) 
     }
     DwmBnInC kin;
     if (BNIN) kin = dwm_bnin_consts(a.in, m.c);
-#ifdef DWM_ABL_NOCONST
-    if (BNIN) { kin.mean = 0.1f; kin.sc = 1.5f; kin.b = 0.2f; kin.sc0 = false; kin.any_sc0 = false; kin.rs.d = 1.25f; kin.rs.r = 0.8f; }
-#endif
 #undef DWM_CONST
     const BnDiv fM{a.fM, a.rfM};
     const bool sums = BNIN && a.in_sums != nullptr;
@@ -538,9 +523,6 @@ __global__ __launch_bounds__(256, V == 4 ? DWM_BWD_WAVES : DWM_BWD_WAVES_SMALL) 
     // bn_bwd_one of bn_math.h (bcnn_batchnorm_layer.c:292-296) with the per-channel constants folded, then act'(y)
     auto gval = [&](float gin, float yv) -> float {
         float g = gin;
-#ifdef DWM_ABL_NOGVAL
-        return g + yv;
-#endif
         if (BN) {
             g = __fmul_rn(g, kb.sc);
             if (kb.any_sc0 && kb.sc0) g = 0.f;
@@ -607,18 +589,11 @@ __global__ __launch_bounds__(256, V == 4 ? DWM_BWD_WAVES : DWM_BWD_WAVES_SMALL) 
                 for (int kw = 2; kw >= 0; --kw) v = __fadd_rn(v, __fmul_rn(w[0 + kw], Cr.v[c + 2 - kw]));
                 d.v[c] = v;
             }
-#ifdef DWM_ABL_NOSTORE
-            dwm_st<V>(rdx, xo, d, valid && d.v[0] == 123.456f);
-#else
             dwm_st<V>(rdx, xo, d, valid);
-#endif
             if (!valid) return;
             Vals<V> xv = xraw;
             if (BNIN) xv = dwm_bnin_v<V>(xraw, kin, in_act);
             // weight gradient from the rows of x this band owns: x[r][j] meets g[r - kh + 1][j - kw + 1]
-#ifdef DWM_ABL_NODW
-            acc[0] += xv.v[0];
-#else
 #pragma unroll
             for (int c = 0; c < V; ++c) {
 #pragma unroll
@@ -629,10 +604,7 @@ __global__ __launch_bounds__(256, V == 4 ? DWM_BWD_WAVES : DWM_BWD_WAVES_SMALL) 
                 }
                 acc[9] += B.v[c + 1];
             }
-#endif
-#ifndef DWM_ABL_NOSUMS
             if (sums) in_sums(d, xv, xraw);
-#endif
         };
         auto step_row = [&](int st) -> int { return st <= nrows ? rf + dir * st : -1; };
         Row<V> P = make_g(fetch_g(rf - dir), rf - dir), Q = make_g(fetch_g(step_row(0)), step_row(0));
@@ -737,9 +709,6 @@ __global__ __launch_bounds__(256, V == 4 ? DWM_BWD_WAVES : DWM_BWD_WAVES_SMALL) 
             }
         }
     }
-#ifdef DWM_ABL_NOEPI   // timing only: no band sums, no partial stores
-    if (acc[0] != 123.456f) return;
-#endif
     const int splits = (int)(a.g.bands / a.C);  // N * BPP
     const unsigned wave = blockIdx.x * 4u + (threadIdx.x >> 6);
     dwm_band_sums<kDwmPart>(acc, red[threadIdx.x >> 6], a.g.L, a.g.G, [&](int q, int i, float t) {
