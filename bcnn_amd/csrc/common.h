@@ -40,6 +40,7 @@ enum KClass { K_CONV_FWD = 0, K_CONV_DW, K_CONV_DX, K_BN_FWD, K_BN_BWD, K_POOL, 
               K_DEPTHWISE_FWD, K_DEPTHWISE_BWD,
               K_CONV_FWD_WINO, K_CONV_DX_WINO, K_CONV_DW_WINO,  // Winograd F(2x2,3x3) layers: FLOPs = what the MFMAs execute
               K_CONV_FWD_WINO43, K_CONV_DX_WINO43,              // Winograd F(4x4,3x3) layers, likewise (36 positions per 4 x 4 outputs)
+              K_CONV_DW_WINO43,
               K_NUM };
 struct KTimer {
     int idx;

@@ -68,6 +68,10 @@ size_t conv_dw_small_c_workspace_floats(const ConvShape& s);
 bool conv_backward_weights_small_c(const float* x, const float* dy, float* dw, const ConvShape& s, float* workspace,
                                    size_t workspace_floats);
 size_t conv_dw_winograd_fused_workspace_floats(const ConvShape& s);
+// conv_winograd43_dw.hip: F(4x4, 3x3) in its transposed form for planes of whole 4 x 4 tiles
+size_t conv_dw_winograd43_workspace_floats(const ConvShape& s);
+bool conv_backward_weights_winograd43(const float* x, const float* dy, float* dw, const ConvShape& s, float* workspace,
+                                      size_t workspace_floats);
 bool conv_backward_weights_winograd_fused(const float* x, const float* dy, float* dw, const ConvShape& s, float* workspace,
                                           size_t workspace_floats);
 size_t conv_dw_winograd_workspace_floats(const ConvShape& s);
@@ -329,6 +333,8 @@ size_t bcnn_hip_conv_workspace_size(int n, int c, int h, int w, int f, int k, in
     size_t wg = conv_dw_winograd_workspace_floats(s);
     const size_t wgf = conv_dw_winograd_fused_workspace_floats(s);
     if (wgf > wg) wg = wgf;
+    const size_t wg43 = conv_dw_winograd43_workspace_floats(s);
+    if (wg43 > wg) wg = wg43;
     const size_t sc = conv_dw_small_c_workspace_floats(s);
     if (sc > wg) wg = sc;
     if (b > m) m = b;
@@ -527,6 +533,8 @@ static void conv_backward_impl(const float* x, const float* w, const float* bias
         bias_done = true;
     else if (conv_backward_weights_direct(x, dy, dw, batch_norm ? nullptr : dbias, s, workspace, workspace_elems))
         bias_done = true;
+    else if (conv_backward_weights_winograd43(x, dy, dw, s, workspace, workspace_elems))
+        bias_done = false;
     else if (conv_backward_weights_winograd_fused(x, dy, dw, s, workspace, workspace_elems))
         bias_done = false;
     else if (conv_backward_weights_winograd(x, dy, dw, s, workspace, workspace_elems))

@@ -226,7 +226,7 @@ const char* bcnn_hip_profile_class_name(int cls) {
     static const char* names[K_NUM] = {"conv_fwd", "conv_dw", "conv_dx", "bn_fwd", "bn_bwd", "pool",
                                        "eltwise_act", "gemm", "sgd", "depthwise_fwd", "depthwise_bwd",
                                        "conv_fwd_winograd", "conv_dx_winograd", "conv_dw_winograd",
-                                       "conv_fwd_winograd43", "conv_dx_winograd43"};
+                                       "conv_fwd_winograd43", "conv_dx_winograd43", "conv_dw_winograd43"};
     return (cls >= 0 && cls < K_NUM) ? names[cls] : "?";
 }
 
