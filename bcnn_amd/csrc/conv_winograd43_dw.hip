@@ -17,8 +17,10 @@
 // of the other tensor, so the role only picks descriptor, channel count and tile.
 // A lane's transform item: patch = (tile l % 8 of the period, channel l / 8 of the wave's eight): the neighbour columns come
 // from the neighbouring lanes (DPP wave shifts), the ends of an 8-lane group from edge duties of lanes 1..6 as in
-// conv_winograd43b.hip; dy = (tile l % 4 of the window, output channel l / 4 of the wave's sixteen). LDS rows are rotated by the
-// tile (f + 4 k, c + 2 tile) so that both the 16-byte writes of a transform and the fragment reads are conflict-free.
+// conv_winograd43b.hip; dy = (tile l % 4 of the window, output channel l / 4 of the wave's sixteen). The eight lanes a
+// ds_write_b128 is serviced in are then eight tiles of ONE channel -- eight rows of the stage, the same banks: the rows are
+// rotated by 2 (tile / 2) channels, which leaves the 16-byte writes 2-way conflicting (their issue time hides that) and the
+// fragment reads conflict-free (a ds_read_b128 group holds rows k and k + 1 of a pair: they must share their rotation).
 // The partial dU of a workgroup leaves as G^T dU G (9 instead of 36 values per channel pair); wino43_dw_finalize_kernel adds
 // the splits in a fixed order onto dw (beta = 1: the momentum carry of the reference, bcnn_conv_layer.c:533-560).
 #include "conv_common.h"
@@ -65,9 +67,9 @@ __global__ __launch_bounds__(64 * WB_NW, 2) void wino43_dw_kernel(const Wino43Dw
     const int c_own = cbk * WD4_BC + 8 * w4 + lj, f_own = fb * WB_BF + 16 * w4 + lf;
 
     auto coords = [&](unsigned t, unsigned& n, int& th, int& tw) {
-        n = magic_div(t, a.magic_img);
+        n = __umulhi(t, a.magic_img);
         const unsigned rr = t - n * per_img;
-        th = (int)magic_div(rr, a.magic_tw);
+        th = (int)__umulhi(rr, a.magic_tw);
         tw = (int)(rr - (unsigned)th * (unsigned)a.TW);
     };
 
@@ -99,9 +101,10 @@ __global__ __launch_bounds__(64 * WB_NW, 2) void wino43_dw_kernel(const Wino43Dw
         // edge duties: the 8-lane group's first and last tile
         const bool duty = !is_dy && l7 >= 1 && l7 <= 6 && ch < chans;
         const int row = l7 - 1;
-        unsigned nl, nr; int thl, twl, thr, twr;
-        coords(t - (unsigned)l7, nl, thl, twl);
-        coords(t - (unsigned)l7 + 7u, nr, thr, twr);
+        // (the group's tiles are consecutive and a tile row has at least seven: at most one row / image boundary either way)
+        unsigned nl = n, nr = n; int thl = th, twl = tw - l7, thr = th, twr = tw + 7 - l7;
+        if (twl < 0) { twl += a.TW; if (--thl < 0) { thl += a.TH; --nl; } }
+        if (twr >= a.TW) { twr -= a.TW; if (++thr >= a.TH) { thr -= a.TH; ++nr; } }
         const int ihl = 4 * thl - 1 + row, ihr = 4 * thr - 1 + row;
         const bool okl = duty && t - (unsigned)l7 < a.T && twl > 0 && ihl >= 0 && ihl < a.H;
         const bool okr = duty && t - (unsigned)l7 + 7u < a.T && twr + 1 < a.TW && ihr >= 0 && ihr < a.H;
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(64 * WB_NW, 2) void wino43_dw_kernel(const Wino43Dw
 #pragma unroll
             for (int i = 0; i < 6; ++i) tt[i][j] = out[i];
         }
-        float* v = lds + 2 * WB_USTAGE + vs * WB_VSTAGE + (l7 >> 2) * WB_VC + ((l7 & 3) * 32 + ((8 * w4 + lj + 2 * l7) & 31)) * 4;
+        float* v = lds + 2 * WB_USTAGE + vs * WB_VSTAGE + (l7 >> 2) * WB_VC + ((l7 & 3) * 32 + ((8 * w4 + lj + 2 * (l7 >> 1)) & 31)) * 4;
 #pragma unroll
         for (int ip = 0; ip < 3; ++ip) {
             float o0[6], o1[6];
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(64 * WB_NW, 2) void wino43_dw_kernel(const Wino43Dw
 #pragma unroll
             for (int i = 0; i < 6; ++i) tt[i][j] = out[i];
         }
-        float* u = lds + stage * WB_USTAGE + (k4 * 64 + ((16 * w4 + lf + 4 * k4) & 63)) * 4;
+        float* u = lds + stage * WB_USTAGE + (k4 * 64 + ((16 * w4 + lf + 2 * (k4 >> 1)) & 63)) * 4;
 #pragma unroll
         for (int ip = 0; ip < 3; ++ip) {
             float o0[6], o1[6];
@@ -190,9 +193,9 @@ __global__ __launch_bounds__(64 * WB_NW, 2) void wino43_dw_kernel(const Wino43Dw
     };
 
     f32x4 acc[36];
-    const float* const ufrag = lds + (lq * 64 + ((16 * cb + l15 + 4 * lq) & 63)) * 4;  // + sub * WB_USTAGE + (xi / 4) * 1024
-    const float* const vfrag0 = lds + 2 * WB_USTAGE + (lq * 32 + ((16 * tbw + l15 + 2 * lq) & 31)) * 4;
-    const float* const vfrag1 = lds + 2 * WB_USTAGE + WB_VC + (lq * 32 + ((16 * tbw + l15 + 2 * (4 + lq)) & 31)) * 4;
+    const float* const ufrag = lds + (lq * 64 + ((16 * cb + l15 + 2 * (lq >> 1)) & 63)) * 4;  // + sub * WB_USTAGE + (xi / 4) * 1024
+    const float* const vfrag0 = lds + 2 * WB_USTAGE + (lq * 32 + ((16 * tbw + l15 + 2 * (lq >> 1)) & 31)) * 4;
+    const float* const vfrag1 = lds + 2 * WB_USTAGE + WB_VC + (lq * 32 + ((16 * tbw + l15 + 2 * ((4 + lq) >> 1)) & 31)) * 4;
 
     // ---- prologue: V(0) and dM(0, first window) in place; the loop's requests of "period -1" in flight ----
     const bool t0 = grp == 0;  // T in the even periods

@@ -62,7 +62,7 @@ MOBILENET = dict(graph="build_mobilenet_v1", shape=dict(w=224, h=224, c=3, n=32)
 
 # single-node workers: the kernels themselves
 RESNET_WALK_KERNELS = ["wino43b_kernel:fwd", "wino43b_kernel:dx", "wino43b_tail_fixup", "wino_fused_kernel:fwd",
-                       "wino_fused_kernel:dx", "wino_dw_fused_kernel", "conv_fwd_stem_kernel", "conv_dw_stem_kernel",
+                       "wino_fused_kernel:dx", "wino43_dw_kernel", "wino_dw_fused_kernel", "conv_fwd_stem_kernel", "conv_dw_stem_kernel",
                        "conv_igemm_dma_kernel:fwd", "conv_igemm_dma_kernel:dx", "conv_dw_dma_kernel"]
 MOBILENET_WALK_KERNELS = ["dwm_fwd_kernel", "dwm_bwd_kernel", "conv_igemm_dma_kernel:fwd", "conv_igemm_dma_kernel:dx",
                           "conv_dw_dma_kernel"]
@@ -70,7 +70,7 @@ MOBILENET_WALK_KERNELS = ["dwm_fwd_kernel", "dwm_bwd_kernel", "conv_igemm_dma_ke
 RESNET_PASS_FWD = ["conv_fwd_stem_kernel", "maxpool_fwd_s2_bn_kernel", "wino43b_kernel:fwd", "wino43b_tail_fixup",
                    "wino_fused_kernel:fwd", "conv_igemm_dma_kernel:fwd"]
 RESNET_PASS_BWD = ["maxpool_bwd_pair_bn_kernel", "conv_dw_stem_kernel", "wino43b_kernel:dx", "wino43b_tail_fixup",
-                   "wino_fused_kernel:dx", "wino_dw_fused_kernel", "conv_igemm_dma_kernel:dx", "conv_dw_dma_kernel"]
+                   "wino_fused_kernel:dx", "wino43_dw_kernel", "wino_dw_fused_kernel", "conv_igemm_dma_kernel:dx", "conv_dw_dma_kernel"]
 MOBILENET_PASS_FWD = ["dwm_fwd_kernel:bnin", "bnfold:fwd", "conv_igemm_dma_kernel:fwd"]
 MOBILENET_PASS_BWD = ["dwm_bwd_kernel:bn+bnin", "bnfold:dw", "conv_igemm_dma_kernel:dx+bnsums", "conv_dw_dma_kernel"]
 

@@ -18,7 +18,7 @@ import bench
 # pass starts at the first kernel only backward launches (cost / softmax gradient aside, the first weight-gradient,
 # batch-norm-backward, pooling-backward or depthwise-backward kernel). The same LDS-DMA GEMM and the same fused Winograd
 # kernel serve forward and the data gradient: the phase, not the name, decides which class a launch belongs to.
-BWD_MARK = ("conv_dw", "wino_dw", "BnBwd", "bn_bwd", "BwdSums", "_bwd_kernel", "maxpool_bwd", "avgpool_bwd", "dwm_bwd", "dwl_bwd", "dw3_bwd", "eltwise_bwd", "cost_bwd", "softmax_bwd", "ActBwd")
+BWD_MARK = ("conv_dw", "wino_dw", "wino43_dw", "BnBwd", "bn_bwd", "BwdSums", "_bwd_kernel", "maxpool_bwd", "avgpool_bwd", "dwm_bwd", "dwl_bwd", "dw3_bwd", "eltwise_bwd", "cost_bwd", "softmax_bwd", "ActBwd")
 # Per pass (= per counter: FETCH_SIZE and WRITE_SIZE come from separate runs, whose number of steps may differ now that
 # bench.py stretches its warm-up by wall time) the sums are divided by THAT pass's number of steps. A step is counted where
 # the backward phase begins (every step has exactly one such place, also the workloads without an SGD launch: configs[1]);
@@ -76,8 +76,9 @@ out = {
    "conv_dx": cls(lambda k: "conv_igemm" in k or "conv_pack_weights" in k or "dma_pack" in k or "conv_dx" in k, "bwd"),
    "conv_fwd_winograd": cls(lambda k: "wino_fused_kernel" in k or "wino_tail_fixup" in k or "wino_pack_weights" in k or "wino_pack" in k, "fwd"),
    "conv_dx_winograd": cls(lambda k: "wino_fused_kernel" in k or "wino_tail_fixup" in k or "wino_pack_weights" in k or "wino_pack" in k, "bwd"),
-   "conv_fwd_winograd43": cls(lambda k: "wino43" in k, "fwd"),
-   "conv_dx_winograd43": cls(lambda k: "wino43" in k, "bwd"),
+   "conv_fwd_winograd43": cls(lambda k: "wino43b" in k, "fwd"),
+   "conv_dx_winograd43": cls(lambda k: "wino43b" in k, "bwd"),
+   "conv_dw_winograd43": cls(lambda k: "wino43_dw" in k),
    "conv_dw_winograd": cls(lambda k: "wino_dw" in k or "wino_input_transform" in k or "wino_dy_transform" in k),
    "bn_fwd": cls(lambda k: "BnApplyBody" in k or "bn_stats" in k or "StatsF" in k or "bn_fwd" in k, "fwd"),
    "bn_bwd": cls(lambda k: "BnBwd" in k or "bn_bwd" in k or "BwdSumsF" in k),
