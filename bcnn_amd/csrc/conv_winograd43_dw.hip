@@ -12,9 +12,12 @@
 // Both operands are transformed in the loop: per period 256 patches (8 tiles x 32 channels) and 512 dy tiles (8 x 64). The two
 // groups of four waves alternate by period: T transforms the NEXT period's V in the first sub-chunk and the next period's first
 // dy window in the second one, R this period's second dy window in the first sub-chunk. Every wave issues the same twelve
-// 16-byte / 4-byte requests per period at the same two places of the loop (one definition per register and iteration,
+// 16-byte / 4-byte requests per period at the same places of the loop (one definition per register and iteration,
 // DESIGN.md section 4.0); which tensor and tile they address depends on the role: a dy tile's rows ARE rows 1..4 of a patch
-// of the other tensor, so the role only picks descriptor, channel count and tile.
+// of the other tensor, so the role only picks descriptor, channel count and tile. The requests sit BETWEEN the fragment groups
+// of the two MFMA phases (wb_mma's `between`): a request instruction holds its wave while the texture path is busy -- a
+// patch row touches 8-16 lines, an edge duty 48 --, and there the SIMD's other wave multiplies meanwhile; behind the
+// transforms, in front of the barrier, the same stalls had everybody waiting (0.156 -> 0.139 ms at 56 x 56).
 // A lane's transform item: patch = (tile l % 8 of the period, channel l / 8 of the wave's eight): the neighbour columns come
 // from the neighbouring lanes (DPP wave shifts), the ends of an 8-lane group from edge duties of lanes 1..6 as in
 // conv_winograd43b.hip; dy = (tile l % 4 of the window, output channel l / 4 of the wave's sixteen). The eight lanes a
@@ -66,11 +69,12 @@ __global__ __launch_bounds__(64 * WB_NW, 2) void wino43_dw_kernel(const Wino43Dw
     const rsrc_i4 rs_x = make_rsrc(a.x, a.x_bytes), rs_dy = make_rsrc(a.dy, a.dy_bytes);
     const int c_own = cbk * WD4_BC + 8 * w4 + lj, f_own = fb * WB_BF + 16 * w4 + lf;
 
+    // (every factor below is < 2^24 -- the plan checks it --: v_mul_u32_u24 is a full-rate instruction, v_mul_lo_u32 is not)
     auto coords = [&](unsigned t, unsigned& n, int& th, int& tw) {
         n = __umulhi(t, a.magic_img);
-        const unsigned rr = t - n * per_img;
+        const unsigned rr = t - __umul24(n, per_img);
         th = (int)__umulhi(rr, a.magic_tw);
-        tw = (int)(rr - (unsigned)th * (unsigned)a.TW);
+        tw = (int)(rr - __umul24((unsigned)th, (unsigned)a.TW));
     };
 
     // ---- the requests: twelve instructions, the same for both kinds of item ----
@@ -80,52 +84,71 @@ __global__ __launch_bounds__(64 * WB_NW, 2) void wino43_dw_kernel(const Wino43Dw
     buf_f32x4 A[6], B[4];
     float e0, e1;
     unsigned pf;
-    auto request_a = [&](bool is_dy, unsigned t_period) {
+    unsigned qa_mid, qa_top, qa_bot, qa_l, qa_r, qb_mid;   // the voffsets of the next requests (prep_a / prep_b)
+    rsrc_i4 qa_rs;
+    auto prep_a = [&](bool is_dy, unsigned t_period) {
         const unsigned t = t_period + (unsigned)(is_dy ? k4 : l7);
         const int chans = is_dy ? a.F : a.C, ch = is_dy ? f_own : c_own;
-        const rsrc_i4 rs = is_dy ? rs_dy : rs_x;
+        qa_rs = is_dy ? rs_dy : rs_x;
         unsigned n; int th, tw;
         coords(t, n, th, tw);
         const bool ok = t < a.T && ch < chans;
         const unsigned chan_off = (unsigned)ch * (unsigned)HW * 4u;
         const unsigned img = (unsigned)chans * (unsigned)HW * 4u;
-        const unsigned mid = ok ? n * img + chan_off + (unsigned)(4 * th * a.W + 4 * tw) * 4u : kOOB;
-        const unsigned top = (ok && !is_dy && th > 0) ? mid - row_bytes : kOOB;
-        const unsigned bot = (!is_dy && 4 * th + 4 < a.H) ? mid : kOOB;
+        qa_mid = ok ? __umul24(n, img) + chan_off + (__umul24((unsigned)th, row_bytes) + (unsigned)tw * 4u) * 4u : kOOB;
+        qa_top = (ok && !is_dy && th > 0) ? qa_mid - row_bytes : kOOB;
+        qa_bot = (!is_dy && 4 * th + 4 < a.H) ? qa_mid : kOOB;
         pf = (tw == 0 ? 1u : 0u) | (tw + 1 == a.TW ? 2u : 0u);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(i == 0 ? 0 : i - 1) * row_bytes));
-            A[i] = buffer_load_f32x4(rs, (int)(i == 0 ? top : i == 5 ? bot : mid), (int)so, 0);
-        }
         // edge duties: the 8-lane group's first and last tile
         const bool duty = !is_dy && l7 >= 1 && l7 <= 6 && ch < chans;
         const int row = l7 - 1;
         // (the group's tiles are consecutive and a tile row has at least seven: at most one row / image boundary either way)
-        unsigned nl = n, nr = n; int thl = th, twl = tw - l7, thr = th, twr = tw + 7 - l7;
-        if (twl < 0) { twl += a.TW; if (--thl < 0) { thl += a.TH; --nl; } }
-        if (twr >= a.TW) { twr -= a.TW; if (++thr >= a.TH) { thr -= a.TH; ++nr; } }
+        int twl = tw - l7, twr = tw + 7 - l7;
+        const int wl = twl < 0 ? 1 : 0, wr = twr >= a.TW ? 1 : 0;
+        twl += wl ? a.TW : 0; twr -= wr ? a.TW : 0;
+        int thl = th - wl, thr = th + wr;
+        const int wl2 = thl < 0 ? 1 : 0, wr2 = thr >= a.TH ? 1 : 0;
+        thl += wl2 ? a.TH : 0; thr -= wr2 ? a.TH : 0;
+        const unsigned nl = n - (unsigned)wl2, nr = n + (unsigned)wr2;
         const int ihl = 4 * thl - 1 + row, ihr = 4 * thr - 1 + row;
         const bool okl = duty && t - (unsigned)l7 < a.T && twl > 0 && ihl >= 0 && ihl < a.H;
         const bool okr = duty && t - (unsigned)l7 + 7u < a.T && twr + 1 < a.TW && ihr >= 0 && ihr < a.H;
-        const unsigned offl = okl ? nl * img + chan_off + (unsigned)(ihl * a.W + 4 * twl - 1) * 4u : kOOB;
-        const unsigned offr = okr ? nr * img + chan_off + (unsigned)(ihr * a.W + 4 * twr + 4) * 4u : kOOB;
-        e0 = buffer_load_f32(rs, (int)offl, 0, 0);
-        e1 = buffer_load_f32(rs, (int)offr, 0, 0);
+        qa_l = okl ? __umul24(nl, img) + chan_off + (__umul24((unsigned)ihl, (unsigned)a.W) + (unsigned)(4 * twl - 1)) * 4u : kOOB;
+        qa_r = okr ? __umul24(nr, img) + chan_off + (__umul24((unsigned)ihr, (unsigned)a.W) + (unsigned)(4 * twr + 4)) * 4u : kOOB;
     };
-    auto request_b = [&](bool live, unsigned t_window) {
+    // part 1: rows -1, 0, 1; part 2: rows 2, 3, 4; part 3: the edge duties
+    auto issue_a = [&](int part) {
+        if (part == 1 || part == 2) {
+#pragma unroll
+            for (int i = 3 * (part - 1); i < 3 * part; ++i) {
+                const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(i == 0 ? 0 : i - 1) * row_bytes));
+                A[i] = buffer_load_f32x4(qa_rs, (int)(i == 0 ? qa_top : i == 5 ? qa_bot : qa_mid), (int)so, 0);
+            }
+        } else {
+            e0 = buffer_load_f32(qa_rs, (int)qa_l, 0, 0);
+            e1 = buffer_load_f32(qa_rs, (int)qa_r, 0, 0);
+        }
+    };
+    auto request_a = [&](bool is_dy, unsigned t_period) {
+        prep_a(is_dy, t_period);
+        issue_a(1); issue_a(2); issue_a(3);
+    };
+    auto prep_b = [&](bool live, unsigned t_window) {
         const unsigned t = t_window + (unsigned)k4;
         unsigned n; int th, tw;
         coords(t, n, th, tw);
         const bool ok = live && t < a.T && f_own < a.F;
-        const unsigned mid = ok ? (n * (unsigned)a.F + (unsigned)f_own) * (unsigned)HW * 4u + (unsigned)(4 * th * a.W + 4 * tw) * 4u : kOOB;
+        qb_mid = ok ? __umul24(n, (unsigned)a.F * (unsigned)HW * 4u) + (unsigned)f_own * (unsigned)HW * 4u
+                          + (__umul24((unsigned)th, row_bytes) + (unsigned)tw * 4u) * 4u : kOOB;
+    };
+    auto issue_b = [&](int part) {   // part 1: rows 0, 1; part 2: rows 2, 3
+        if (part > 2) return;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 2 * (part - 1); r < 2 * part; ++r) {
             const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)r * row_bytes));
-            B[r] = buffer_load_f32x4(rs_dy, (int)mid, (int)so, 0);
+            B[r] = buffer_load_f32x4(rs_dy, (int)qb_mid, (int)so, 0);
         }
     };
-
     // ---- B^T d B of the patch in A / e0 / e1 -> V stage vs (see conv_winograd43b.hip: write_v; here 8-lane groups) ----
     auto write_v = [&](int vs) {
         const bool pad_l = (pf & 1u) != 0, pad_r = (pf & 2u) != 0;
@@ -203,7 +226,6 @@ __global__ __launch_bounds__(64 * WB_NW, 2) void wino43_dw_kernel(const Wino43Dw
     if (t0) write_v(0);
     else write_dm(0, A[1], A[2], A[3], A[4]);
     request_a(!t0, t_begin + (t0 ? 8u : 4u));  // T: patches of period 1; R: dy of window (0, 1)
-    request_b(t0, t_begin + 8u);                // T: dy of window (1, 0)
 
     for (int p = 0; p < np; ++p) {
         const bool t_role = (grp == (p & 1));
@@ -211,21 +233,23 @@ __global__ __launch_bounds__(64 * WB_NW, 2) void wino43_dw_kernel(const Wino43Dw
         const unsigned t_p = t_begin + 8u * (unsigned)p;
         // ---- first sub-chunk: A stage 0, V[vs][0] ----
         lds_barrier();
+        // the requests ride inside the MFMA phases: a wave that the texture path holds up stalls while its SIMD partner
+        // multiplies. B: T's dy of window (p + 1, 0), transformed behind the second sub-chunk
+        prep_b(t_role, t_p + 8u);
         __builtin_amdgcn_sched_barrier(0);
-        if (p == 0) wb_mma<true>(acc, ufrag, vfrag0 + vs * WB_VSTAGE);
-        else wb_mma<false>(acc, ufrag, vfrag0 + vs * WB_VSTAGE);
+        if (p == 0) wb_mma<true>(acc, ufrag, vfrag0 + vs * WB_VSTAGE, issue_b);
+        else wb_mma<false>(acc, ufrag, vfrag0 + vs * WB_VSTAGE, issue_b);
         __builtin_amdgcn_sched_barrier(0);
         if (t_role) write_v(vs ^ 1);                          // V(p + 1)
         else write_dm(1, A[1], A[2], A[3], A[4]);             // dM(p, second window)
-        // R: the patches of period p + 2 (it transforms them as T of period p + 1); T: dy of window (p + 1, 1)
-        request_a(t_role, t_p + (t_role ? 12u : 16u));
         // ---- second sub-chunk: A stage 1, V[vs][1] ----
         lds_barrier();
+        // A: R's patches of period p + 2 (it transforms them as T of period p + 1); T's dy of window (p + 1, 1)
+        prep_a(t_role, t_p + (t_role ? 12u : 16u));
         __builtin_amdgcn_sched_barrier(0);
-        wb_mma<false>(acc, ufrag + WB_USTAGE, vfrag1 + vs * WB_VSTAGE);
+        wb_mma<false>(acc, ufrag + WB_USTAGE, vfrag1 + vs * WB_VSTAGE, issue_a);
         __builtin_amdgcn_sched_barrier(0);
         if (t_role) write_dm(0, B[0], B[1], B[2], B[3]);      // dM(p + 1, first window)
-        request_b(!t_role, t_p + 16u);                         // R: dy of window (p + 2, 0)
     }
 
     // ---- G^T dU G of the wave's 16 x 16 channel pairs; lane: output channels 16 cb + 4 lq + i, input channel 16 tbw + l15 ----
@@ -299,7 +323,8 @@ static Wino43DwPlan wino43_dw_plan(const ConvShape& s, int cus = kCUs) {
     if (g_w43dw_force == 2 && (s.C < 64 || s.F < 64)) return p;
     const int TH = s.H / 4, TW = s.W / 4;
     const unsigned long long T = (unsigned long long)s.N * TH * TW;
-    if (T * (unsigned long long)(TH * TW) >= 0xffffffffull) return p;  // magic_div is exact below that
+    if (T * (unsigned long long)(TH * TW) >= 0xffffffffull) return p;  // the multiply-high divisions are exact below that
+    if (T + 64 >= (1ull << 24) || (size_t)(s.C > s.F ? s.C : s.F) * s.HW * 4 >= (1u << 24)) return p;  // 24-bit multiplies
     p.T = (unsigned)T;
     p.fblocks = (s.F + WB_BF - 1) / WB_BF; p.cblocks = (s.C + WD4_BC - 1) / WD4_BC;
     const int nob = p.fblocks * p.cblocks;

@@ -31,6 +31,38 @@ __device__ __forceinline__ void wb_store_x4(f32x4 v, rsrc_i4 rs, unsigned voff, 
 // come in three groups of 3 + 3 ds_read_b128 (twelve positions), each requested while the group before is multiplied: 48
 // registers. Left to itself hipcc hoists all 18 reads to the top (72 registers), which with the 144 accumulators and the
 // 25 patch registers in flight no longer fits.
+// `between(g)` runs in front of fragment group g = 1, 2 and behind the last one (g = 3): memory requests placed there stall --
+// if the texture path is busy -- while the SIMD's other wave multiplies.
+template <bool FIRST, class Between>
+__device__ __forceinline__ void wb_mma(f32x4 (&acc)[36], const float* up, const float* vp, Between between) {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 a4[2][3], b4[2][3];
+#pragma unroll
+    for (int x = 0; x < 3; ++x) {
+        a4[0][x] = *reinterpret_cast<const f32x4*>(up + x * 1024);
+        b4[0][x] = *reinterpret_cast<const f32x4*>(vp + x * 512);
+    }
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 1 < 3) {
+#pragma unroll
+            for (int x = 0; x < 3; ++x) {
+                a4[(g + 1) & 1][x] = *reinterpret_cast<const f32x4*>(up + (3 * (g + 1) + x) * 1024);
+                b4[(g + 1) & 1][x] = *reinterpret_cast<const f32x4*>(vp + (3 * (g + 1) + x) * 512);
+            }
+        }
+#pragma unroll
+        for (int x = 0; x < 3; ++x)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int xi = 12 * g + 4 * x + j;
+                acc[xi] = mfma16(a4[g & 1][x][j], b4[g & 1][x][j], FIRST ? zero : acc[xi]);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        between(g + 1);
+    }
+}
 template <bool FIRST>
 __device__ __forceinline__ void wb_mma(f32x4 (&acc)[36], const float* up, const float* vp) {
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
