@@ -99,22 +99,25 @@ __global__ __launch_bounds__(64 * WB_NW, 2) void wino43_dw_kernel(const Wino43Dw
         qa_top = (ok && !is_dy && th > 0) ? qa_mid - row_bytes : kOOB;
         qa_bot = (!is_dy && 4 * th + 4 < a.H) ? qa_mid : kOOB;
         pf = (tw == 0 ? 1u : 0u) | (tw + 1 == a.TW ? 2u : 0u);
-        // edge duties: the 8-lane group's first and last tile
-        const bool duty = !is_dy && l7 >= 1 && l7 <= 6 && ch < chans;
-        const int row = l7 - 1;
-        // (the group's tiles are consecutive and a tile row has at least seven: at most one row / image boundary either way)
-        int twl = tw - l7, twr = tw + 7 - l7;
-        const int wl = twl < 0 ? 1 : 0, wr = twr >= a.TW ? 1 : 0;
-        twl += wl ? a.TW : 0; twr -= wr ? a.TW : 0;
-        int thl = th - wl, thr = th + wr;
-        const int wl2 = thl < 0 ? 1 : 0, wr2 = thr >= a.TH ? 1 : 0;
-        thl += wl2 ? a.TH : 0; thr -= wr2 ? a.TH : 0;
-        const unsigned nl = n - (unsigned)wl2, nr = n + (unsigned)wr2;
-        const int ihl = 4 * thl - 1 + row, ihr = 4 * thr - 1 + row;
-        const bool okl = duty && t - (unsigned)l7 < a.T && twl > 0 && ihl >= 0 && ihl < a.H;
-        const bool okr = duty && t - (unsigned)l7 + 7u < a.T && twr + 1 < a.TW && ihr >= 0 && ihr < a.H;
-        qa_l = okl ? __umul24(nl, img) + chan_off + (__umul24((unsigned)ihl, (unsigned)a.W) + (unsigned)(4 * twl - 1)) * 4u : kOOB;
-        qa_r = okr ? __umul24(nr, img) + chan_off + (__umul24((unsigned)ihr, (unsigned)a.W) + (unsigned)(4 * twr + 4)) * 4u : kOOB;
+        // edge duties: the 8-lane group's first and last tile (patch items only: a uniform branch around arithmetic, no request in it)
+        qa_l = kOOB; qa_r = kOOB;
+        if (!is_dy) {
+            const bool duty = l7 >= 1 && l7 <= 6 && ch < chans;
+            const int row = l7 - 1;
+            // (the group's tiles are consecutive and a tile row has at least seven: at most one row / image boundary either way)
+            int twl = tw - l7, twr = tw + 7 - l7;
+            const int wl = twl < 0 ? 1 : 0, wr = twr >= a.TW ? 1 : 0;
+            twl += wl ? a.TW : 0; twr -= wr ? a.TW : 0;
+            int thl = th - wl, thr = th + wr;
+            const int wl2 = thl < 0 ? 1 : 0, wr2 = thr >= a.TH ? 1 : 0;
+            thl += wl2 ? a.TH : 0; thr -= wr2 ? a.TH : 0;
+            const unsigned nl = n - (unsigned)wl2, nr = n + (unsigned)wr2;
+            const int ihl = 4 * thl - 1 + row, ihr = 4 * thr - 1 + row;
+            const bool okl = duty && t - (unsigned)l7 < a.T && twl > 0 && ihl >= 0 && ihl < a.H;
+            const bool okr = duty && t - (unsigned)l7 + 7u < a.T && twr + 1 < a.TW && ihr >= 0 && ihr < a.H;
+            if (okl) qa_l = __umul24(nl, img) + chan_off + (__umul24((unsigned)ihl, (unsigned)a.W) + (unsigned)(4 * twl - 1)) * 4u;
+            if (okr) qa_r = __umul24(nr, img) + chan_off + (__umul24((unsigned)ihr, (unsigned)a.W) + (unsigned)(4 * twr + 4)) * 4u;
+        }
     };
     // part 1: rows -1, 0, 1; part 2: rows 2, 3, 4; part 3: the edge duties
     auto issue_a = [&](int part) {
@@ -134,12 +137,15 @@ __global__ __launch_bounds__(64 * WB_NW, 2) void wino43_dw_kernel(const Wino43Dw
         issue_a(1); issue_a(2); issue_a(3);
     };
     auto prep_b = [&](bool live, unsigned t_window) {
-        const unsigned t = t_window + (unsigned)k4;
-        unsigned n; int th, tw;
-        coords(t, n, th, tw);
-        const bool ok = live && t < a.T && f_own < a.F;
-        qb_mid = ok ? __umul24(n, (unsigned)a.F * (unsigned)HW * 4u) + (unsigned)f_own * (unsigned)HW * 4u
-                          + (__umul24((unsigned)th, row_bytes) + (unsigned)tw * 4u) * 4u : kOOB;
+        qb_mid = kOOB;
+        if (live) {  // uniform
+            const unsigned t = t_window + (unsigned)k4;
+            unsigned n; int th, tw;
+            coords(t, n, th, tw);
+            if (t < a.T && f_own < a.F)
+                qb_mid = __umul24(n, (unsigned)a.F * (unsigned)HW * 4u) + (unsigned)f_own * (unsigned)HW * 4u
+                         + (__umul24((unsigned)th, row_bytes) + (unsigned)tw * 4u) * 4u;
+        }
     };
     auto issue_b = [&](int part) {   // part 1: rows 0, 1; part 2: rows 2, 3
         if (part > 2) return;
