@@ -26,6 +26,7 @@ bash tools/exp/sq_step.sh mobilenet > /dev/null 2>&1
 ROUND=r06 bash tools/exp/step_timeline.sh > /dev/null 2>&1; mv gpurun_out/r06_step_timeline.txt gpurun_out/r06_step_timeline_resnet18.txt
 ROUND=r06 bash tools/exp/step_timeline.sh --workload mobilenet > /dev/null 2>&1; mv gpurun_out/r06_step_timeline.txt gpurun_out/r06_step_timeline_mobilenet.txt
 PROF_BN=1 bash tools/exp/wb_pmc.sh > gpurun_out/r06_wino43b_sq_counters.txt 2>&1
+(PROF_BN=1 bash tools/exp/wdw_pmc.sh; SHAPE="128 128 28 28 128" PROF_BN=1 bash tools/exp/wdw_pmc.sh) > gpurun_out/r06_wino43_dw_sq_counters.txt 2>&1
 python3 -m pytest tests/test_product_dispatch_parity.py -q -s 2>&1 | grep -E "mask flips|worst|ran on|passed|failed" > gpurun_out/r06_product_dispatch_parity.log
 bash tools/exp/mob_dw_layers.sh 2>/dev/null | tail -16 > gpurun_out/r06_mobilenet_depthwise_layers.txt
 bash tools/exp/mob_pw_layers.sh 2>/dev/null | tail -16 > gpurun_out/r06_mobilenet_pointwise_layers.txt
