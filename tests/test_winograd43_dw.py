@@ -27,6 +27,7 @@ SHAPES = [
     (32, 128, 128, 28, 28),  # stage 2: 7 tiles per row, 2 x 4 channel blocks
     (24, 64, 128, 28, 36),   # H != W, 9 tiles per row, F != C
     (41, 64, 64, 32, 32),    # a tile count that is no multiple of the period or of the split
+    (16, 96, 160, 28, 28),   # channel counts that fill neither the last 32-channel nor the last 64-channel block
 ]
 
 
