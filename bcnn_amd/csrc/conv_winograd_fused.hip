@@ -1080,7 +1080,10 @@ size_t conv_dw_winograd_fused_workspace_floats(const ConvShape& s) { return wino
 
 bool conv_backward_weights_winograd_fused(const float* x, const float* dy, float* dw, const ConvShape& s, float* workspace,
                                           size_t workspace_floats) {
-    const bool yield_cus = conv_side_stream_deferred() && wino_dw_fused_plan(s).ok;  // (the workspace was sized for the full plan)
+    // (the workspace was sized for the full plan.) Only on planes from 28 x 28 up: there the chain's sweeps are long enough to need
+    // the CUs; with the 56 x 56 / 28 x 28 layers on conv_winograd43_dw.hip what is left here in ResNet-18 are the 14 x 14 / 7 x 7
+    // layers, which do better on the whole chip (-0.05 ms per step)
+    const bool yield_cus = conv_side_stream_deferred() && s.HW >= 784 && wino_dw_fused_plan(s).ok;
     const WinoDwPlan p = wino_dw_fused_plan(s, yield_cus ? kCUs * 3 / 4 : kCUs);
     if (!p.ok) return false;
     if (reinterpret_cast<uintptr_t>(workspace) & 15) return false;  // the finalize kernel reads the slabs 16 bytes at a time
