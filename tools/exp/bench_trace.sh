@@ -1,5 +1,6 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp
+export BENCH_NO_ALONE_LEG=1   # the traced steps are the timed region's: no untimed one-stream steps behind it
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/bt; rm -rf $O; mkdir -p $O
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/k -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-side-workloads ${BENCH_ARGS} > $O/bench.log 2>&1
 tail -1 $O/bench.log | cut -c1-200

@@ -2,6 +2,7 @@
 # one training step as a timeline: start (us from the step's first launch), duration, queue and name of every kernel, plus how
 # much of the step two kernels overlap (weight gradients run on a side stream). usage: step_timeline.sh [bench.py args]
 cd /tmp && export TMPDIR=/tmp
+export BENCH_NO_ALONE_LEG=1   # the traced steps are the timed region's: no untimed one-stream steps behind it
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/tl; rm -rf $O; mkdir -p $O
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/k -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-side-workloads "$@" > $O/bench.log 2>&1
 python3 - <<PY
